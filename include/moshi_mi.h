@@ -1,0 +1,214 @@
+/* moshi_mi.h — C ABI of libmoshi_mi.so: the MI355X-native (gfx950) engine for the 12.5 Hz
+ * full-duplex frame step of kyutai-labs/moshi:
+ *
+ *      MimiModel.encode  ->  LMGen.step  ->  MimiModel.decode
+ *
+ * Each entry point replaces one method of the reference's PyTorch model API (the reference has
+ * no FFI of its own for this path; its boundary is the Python surface of
+ * moshi/moshi/models/compression.py and moshi/moshi/models/lm.py).  The citation on every
+ * function is the reference method it stands in for (path:line under the reference checkout).
+ *
+ * Conventions
+ *   - Plain C, no torch types.  All tensor pointers are DEVICE pointers on the current HIP device
+ *     unless the comment says "host".  The caller owns every I/O buffer; a handle owns its packed
+ *     weights and all streaming state (conv histories, conv-transpose partials, ring KV caches,
+ *     delay token ring, offsets, exec masks).
+ *   - Every function returns 0 (MMI_OK) or a negative mmi_status; nothing throws across the ABI.
+ *     mmi_last_error() gives a thread-local human readable message for the last failure.
+ *   - `stream` is a hipStream_t passed as void*.  Work is enqueued on it; nothing synchronises
+ *     the device (same contract as the reference: "no hidden syncs in step", sampling.py:32-46).
+ *   - One handle = one GPU = one caller at a time (not re-entrant), like a reference model
+ *     instance (server.py:45,57 serialises sessions with a lock).  Independent handles on
+ *     different GPUs may be driven from different processes (one process per GPU).
+ *   - Integer tensors at the boundary are int64, as in the reference API.
+ */
+#ifndef MOSHI_MI_H_
+#define MOSHI_MI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMI_ABI_VERSION 1
+
+typedef enum mmi_status {
+    MMI_OK = 0,
+    MMI_ERR_INVALID = -1,        /* bad argument (null pointer, negative size...)                       */
+    MMI_ERR_SHAPE = -2,          /* batch/shape mismatch: reference raises AssertionError (lm.py:679-686) */
+    MMI_ERR_STATE = -3,          /* not streaming: reference raises RuntimeError (lm.py:673-676)          */
+    MMI_ERR_HIP = -4,            /* a HIP runtime call failed                                           */
+    MMI_ERR_MISSING_WEIGHT = -5, /* a state-dict key required by the config was not supplied             */
+    MMI_ERR_UNSUPPORTED = -6     /* config outside what the kernels implement                           */
+} mmi_status;
+
+typedef enum mmi_dtype { MMI_F32 = 0, MMI_BF16 = 1, MMI_I64 = 2, MMI_F16 = 3, MMI_I8 = 4 } mmi_dtype;
+
+typedef void* mmi_stream; /* hipStream_t */
+
+/* One state-dict entry, named exactly as in the reference checkpoints
+ * (loaders.py:356-358,413-422).  `data` is a device pointer. */
+typedef struct mmi_tensor_desc {
+    const char* name;
+    const void* data;
+    int32_t dtype; /* mmi_dtype */
+    int32_t ndim;
+    int64_t shape[4];
+} mmi_tensor_desc;
+
+int mmi_version(void);
+const char* mmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Mimi codec                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Mirrors loaders._seanet_kwargs / _quantizer_kwargs / _transformer_kwargs / _mimi_config
+ * (loaders.py:38-88).  Fixed by the kernels: causal, pad_mode "constant", true_skip, ELU(1.0),
+ * norm "none", n_residual_layers == 1 (dilation 1), transformer norm "layer_norm", gating "none",
+ * positional_embedding "rope", learnt conv resampling with the channel-wise upsample. */
+typedef struct mmi_mimi_cfg {
+    int32_t sample_rate;      /* 24000 */
+    int32_t frame_size;       /* samples per 12.5 Hz frame = 1920 (compression.py:244-246) */
+    int32_t channels;         /* 1 */
+    int32_t dimension;        /* 512 */
+    int32_t n_filters;        /* 64 */
+    int32_t n_ratios;         /* 4 */
+    int32_t ratios[8];        /* decoder order {8,6,5,4}; the encoder uses them reversed (seanet.py:154) */
+    int32_t kernel_size;      /* 7 */
+    int32_t last_kernel_size; /* 3 */
+    int32_t residual_kernel_size; /* 3 */
+    int32_t compress;         /* 2 */
+    int32_t resample_stride;  /* encoder_frame_rate / frame_rate = 2 (compression.py:197-207) */
+    int32_t tr_d_model;       /* 512 */
+    int32_t tr_num_heads;     /* 8 */
+    int32_t tr_num_layers;    /* 8 */
+    int32_t tr_dim_feedforward; /* 2048 */
+    int32_t tr_context;       /* 250 */
+    float tr_max_period;      /* 10000 */
+    int32_t q_dimension;      /* 256 */
+    int32_t q_bins;           /* 2048 */
+    int32_t q_n_q;            /* 32 total codebooks */
+    int32_t q_n_q_semantic;   /* 1 */
+} mmi_mimi_cfg;
+
+typedef struct mmi_mimi mmi_mimi;
+
+/* loaders.get_mimi (loaders.py:323-363): build the model from state-dict tensors (fp32).
+ * Weights are repacked into MFMA fragment order on the device; the descs may be freed after. */
+int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights,
+                    int32_t max_batch, mmi_mimi** out);
+void mmi_mimi_destroy(mmi_mimi* m);
+
+/* MimiModel.set_num_codebooks (compression.py:258-260). 1 <= n <= q_n_q. */
+int mmi_mimi_set_num_codebooks(mmi_mimi* m, int32_t n);
+int mmi_mimi_num_codebooks(const mmi_mimi* m);
+
+/* StreamingModule.streaming(batch) enter / exit (streaming.py:131-137, 110-129): allocate and
+ * zero the streaming state of `batch` rows; exec mask all ones. */
+int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream stream);
+int mmi_mimi_streaming_stop(mmi_mimi* m);
+
+/* StreamingModule.set_exec_mask (streaming.py:183-211): mask = device uint8[batch]. */
+int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream);
+/* StreamingModule.reset_streaming (streaming.py:139-156): mask = device uint8[batch] or NULL (= all rows). */
+int mmi_mimi_reset(mmi_mimi* m, const uint8_t* mask_or_null, mmi_stream stream);
+
+/* MimiModel.encode in streaming mode (compression.py:376-388, 338-374):
+ * pcm f32 [batch,1,n_frames*frame_size] -> codes i64 [batch,num_codebooks,n_frames]. */
+int mmi_mimi_encode_step(mmi_mimi* m, const float* pcm, int64_t* codes, int32_t batch, int32_t n_frames,
+                         mmi_stream stream);
+/* MimiModel.encode_to_latent(x, quantize=False) (compression.py:390-404):
+ * pcm -> unquantized latent f32 [batch,dimension,n_frames]. */
+int mmi_mimi_encode_latent_step(mmi_mimi* m, const float* pcm, float* latent, int32_t batch, int32_t n_frames,
+                                mmi_stream stream);
+/* SplitResidualVectorQuantizer.encode (vq.py:269-279) on a given latent (stateless):
+ * latent f32 [batch,dimension,n_frames] -> codes i64 [batch,num_codebooks,n_frames]. */
+int mmi_mimi_quantize(mmi_mimi* m, const float* latent, int64_t* codes, int32_t batch, int32_t n_frames,
+                      mmi_stream stream);
+/* MimiModel.decode_latent (compression.py:431-433; vq.py:281-287) (stateless):
+ * codes i64 [batch,K,n_frames] -> latent f32 [batch,dimension,n_frames]. */
+int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* latent, int32_t batch, int32_t n_codebooks,
+                           int32_t n_frames, mmi_stream stream);
+/* MimiModel.decode in streaming mode (compression.py:406-429):
+ * codes i64 [batch,K,n_frames] (values in [0,bins)) -> pcm f32 [batch,1,n_frames*frame_size]. */
+int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pcm, int32_t batch, int32_t n_codebooks,
+                         int32_t n_frames, mmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Moshi LM (Temporal + Depth transformer) and LMGen                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Mirrors loaders._lm_kwargs (loaders.py:90-119) for the options LMGen.step exercises on Moshi.
+ * Fixed by the kernels: norm "rms_norm_f32" (eps 1e-8), gating "silu", positional_embedding "rope"
+ * (interleaved) for the temporal transformer and "none" for the depformer, causal, no fuser / no CFG,
+ * depformer_multi_linear + depformer_weights_per_step, kv_repeat 1. */
+typedef struct mmi_lm_cfg {
+    int32_t dim;            /* 4096 */
+    int32_t num_heads;      /* 32 */
+    int32_t num_layers;     /* 32 */
+    int32_t ffn_hidden;     /* gating hidden size: 11264 (gating.py:55-58) */
+    int32_t context;        /* 3000 */
+    float max_period;       /* 10000 */
+    int32_t n_q;            /* 16 audio streams seen by the temporal transformer */
+    int32_t dep_q;          /* 8 generated by the depformer */
+    int32_t card;           /* 2048 */
+    int32_t text_card;      /* 32000 */
+    int32_t text_card_out;  /* 32000 */
+    int32_t depformer_dim;        /* 1024 */
+    int32_t depformer_num_heads;  /* 16 */
+    int32_t depformer_num_layers; /* 6 */
+    int32_t depformer_ffn_hidden; /* 2816 */
+    int32_t delays[64];     /* num_codebooks = n_q + 1 entries (text first) */
+    int32_t existing_text_padding_id; /* 3 */
+} mmi_lm_cfg;
+
+/* LMGen constructor arguments that change what step computes (lm.py:557-574). */
+typedef struct mmi_sampling {
+    int32_t use_sampling; /* 0 = greedy argmax */
+    float temp;           /* audio temperature 0.8 */
+    float temp_text;      /* 0.7 */
+    int32_t top_k;        /* 250 */
+    int32_t top_k_text;   /* 25 */
+    uint64_t seed;        /* seed of the on-device counter RNG used when no noise is supplied */
+} mmi_sampling;
+
+typedef struct mmi_lm mmi_lm;
+
+/* loaders.get_moshi_lm (loaders.py:366-446): build LMModel from bf16 state-dict tensors. */
+int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights,
+                  int32_t max_batch, mmi_lm** out);
+void mmi_lm_destroy(mmi_lm* lm);
+
+/* LMGen.streaming(batch) enter/exit (lm.py:605-666). */
+int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream);
+int mmi_lm_streaming_stop(mmi_lm* lm);
+int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream);        /* lm.py:544-547 */
+int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask_or_null, mmi_stream stream);        /* lm.py:537-542 */
+
+/* LMGen.step (lm.py:785-791, 668-783).
+ *   user_codes  i64 [batch, n_user(>= n_q - dep_q), 1]; extra rows are ignored (lm.py:688-689)
+ *   out_tokens  i64 [batch, dep_q + 1, 1]; rows not yet valid hold -2 (lm.py:781-782)
+ *   opt_text_logits  f32 [batch, text_card_out] or NULL   } parity taps: the logits the tokens were
+ *   opt_audio_logits f32 [batch, dep_q, card]   or NULL   } sampled from (bf16 values widened to f32)
+ *   opt_noise   f32 [batch, 1 + dep_q, max(top_k, top_k_text)] or NULL: Exp(1) draws used instead of the
+ *               on-device RNG, indexed by rank in the descending top-k (sampling.py:40-47,59-63)
+ *   valid (host int*): 0 while offset_cpu <= max_delay, i.e. where the reference returns None (lm.py:774-776)
+ */
+int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* out_tokens,
+                float* opt_text_logits, float* opt_audio_logits, const float* opt_noise, int32_t batch,
+                int32_t* valid, mmi_stream stream);
+
+/* Dominant-kernel timing tap for bench.py's roofline object: when enabled, steps run un-graphed and
+ * every launch of the widest weight-streaming GEMM is bracketed by hipEvents on `stream`. */
+int mmi_lm_profile_begin(mmi_lm* lm);
+/* Returns the mean duration (ms) and launch count since mmi_lm_profile_begin, plus the algorithmic
+ * bytes one such launch streams (packed weight bytes + activations in/out). Synchronises the stream. */
+int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,
+                       const char** kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOSHI_MI_H_ */

@@ -1,0 +1,869 @@
+// Mimi codec engine behind the C ABI (include/moshi_mi.h): MimiModel.encode / decode in streaming mode
+// (reference: moshi/moshi/models/compression.py:338-433) as a fixed per-frame launch list over the kernels
+// of mimi_kernels.h, captured into one hipGraph per direction.
+#include "mimi_kernels.h"
+#include "mmi_graph.h"
+
+#include <math.h>
+
+namespace {
+
+struct ConvW {          // one conv / linear as an implicit GEMM: rows = Cout, reduction = Cin*K
+    float* wpk = nullptr;
+    float* bias = nullptr;
+    int Cin = 0, Cout = 0, K = 1, S = 1, Mt = 0, Q = 0;
+};
+
+struct TrLayerW {
+    ConvW in_proj, out_proj, lin1, lin2;
+    float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+};
+
+struct Buf {            // activation buffer [B][C][ld]; first H columns = causal history of its consumer
+    float* p = nullptr;
+    int C = 0, ld = 0, H = 0;
+};
+
+}  // namespace
+
+struct mmi_mimi {
+    mmi_mimi_cfg cfg;
+    int max_batch = 0;
+    int n_codebooks = 8;
+    MmiArena wts;
+    // SEANet
+    std::vector<ConvW> enc_convs, dec_convs;   // in execution order
+    std::vector<TrLayerW> enc_tr, dec_tr;
+    ConvW downsample;
+    float* upsample_w = nullptr;               // [C][2*stride]
+    // RVQ
+    ConvW q_in, q_out;                         // stacked first|rest projections
+    float* E_all = nullptr;                    // [n_q][bins][D]  (0 = rvq_first.layers.0, 1.. = rvq_rest.layers.*)
+    double* e2_all = nullptr;                  // [n_q][bins]
+    // RVQ scratch (max_batch rows)
+    float* xq = nullptr;                       // [maxB][2*Dq] residuals (first | rest)
+    double* best_d = nullptr;
+    int* best_i = nullptr;
+    int* codes_i32 = nullptr;                  // [maxB][n_q]
+    float* q2 = nullptr;                       // [maxB][2*Dq]
+    float* lat_tmp = nullptr;                  // [maxB][dimension]
+    int nchunk = 0;
+    // streaming state
+    bool streaming = false;
+    int batch = 0;
+    MmiArena st;
+    uint8_t* exec = nullptr;
+    uint8_t* first = nullptr;
+    long* counters = nullptr;                  // [2][B]: encoder / decoder transformer offsets
+    Buf enc_in, latent, dec_codes_lat, dec_out;
+    float* enc_kv = nullptr;
+    float* dec_kv = nullptr;
+    std::vector<float*> partials;              // conv-transpose partial buffers
+    std::vector<long> partial_sizes;           // elements per batch row
+    HistDesc* enc_hist = nullptr;
+    HistDesc* dec_hist = nullptr;
+    int enc_nhist = 0, dec_nhist = 0, enc_hist_rows = 0, dec_hist_rows = 0;
+    MmiProgram enc_prog, dec_prog;
+    hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
+};
+
+namespace {
+
+// ---- weight import ---------------------------------------------------------------------------
+int need(const MmiWeights& W, const std::string& name, int ndim, const mmi_tensor_desc** out) {
+    const mmi_tensor_desc* d = W.find(name);
+    if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
+    if (d->dtype != MMI_F32) return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi weights must be fp32: " + name);
+    if (d->ndim != ndim) return mmi_fail(MMI_ERR_SHAPE, "unexpected rank for " + name);
+    *out = d;
+    return MMI_OK;
+}
+
+int pack_matrix(mmi_mimi* m, const float* W, int M, int Kd, long sm, long sk, ConvW* cw) {
+    cw->Mt = mmi_cdiv(M, 32);
+    cw->Q = mmi_cdiv(Kd, 8);
+    size_t n = (size_t)cw->Mt * cw->Q * 256;
+    MMI_HIP_CHECK(m->wts.alloc(&cw->wpk, n));
+    int blocks = (int)mmi_cdiv64((int64_t)n, 256);
+    MMI_LAUNCH(k_pack_a_f32, blocks, 256, 0, (hipStream_t)0, W, cw->wpk, M, Kd, sm, sk, cw->Mt, cw->Q);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+int copy_vec(mmi_mimi* m, const mmi_tensor_desc* d, int n, float** out) {
+    MMI_HIP_CHECK(m->wts.alloc(out, (size_t)n));
+    MMI_HIP_CHECK(hipMemcpy(*out, d->data, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice));
+    return MMI_OK;
+}
+
+// nn.Conv1d weight [Cout][Cin][K] (+ bias)
+int load_conv(mmi_mimi* m, const MmiWeights& W, const std::string& prefix, int Cin, int Cout, int K, int S, bool bias,
+              ConvW* cw) {
+    const mmi_tensor_desc* w;
+    int rc = need(W, prefix + ".weight", 3, &w);
+    if (rc) return rc;
+    if (w->shape[0] != Cout || w->shape[1] != Cin || w->shape[2] != K)
+        return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + prefix + ".weight");
+    cw->Cin = Cin; cw->Cout = Cout; cw->K = K; cw->S = S;
+    rc = pack_matrix(m, (const float*)w->data, Cout, Cin * K, (long)Cin * K, 1, cw);
+    if (rc) return rc;
+    if (bias) {
+        const mmi_tensor_desc* b;
+        rc = need(W, prefix + ".bias", 1, &b);
+        if (rc) return rc;
+        if (b->shape[0] != Cout) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + prefix + ".bias");
+        rc = copy_vec(m, b, Cout, &cw->bias);
+        if (rc) return rc;
+    }
+    return MMI_OK;
+}
+
+// nn.ConvTranspose1d weight [Cin][Cout][K] as a GEMM with rows (co,k): out rows = Cout*K, reduction = Cin
+int load_convtr(mmi_mimi* m, const MmiWeights& W, const std::string& prefix, int Cin, int Cout, int K, int S,
+                ConvW* cw) {
+    const mmi_tensor_desc* w;
+    int rc = need(W, prefix + ".weight", 3, &w);
+    if (rc) return rc;
+    if (w->shape[0] != Cin || w->shape[1] != Cout || w->shape[2] != K)
+        return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + prefix + ".weight");
+    if (K != 2 * S) return mmi_fail(MMI_ERR_UNSUPPORTED, "transposed conv needs kernel == 2*stride: " + prefix);
+    cw->Cin = Cin; cw->Cout = Cout * K; cw->K = 1; cw->S = 1;
+    rc = pack_matrix(m, (const float*)w->data, Cout * K, Cin, 1, (long)Cout * K, cw);
+    if (rc) return rc;
+    const mmi_tensor_desc* b;
+    rc = need(W, prefix + ".bias", 1, &b);
+    if (rc) return rc;
+    return copy_vec(m, b, Cout, &cw->bias);
+}
+
+// nn.Linear weight [out][in], no bias
+int load_linear(mmi_mimi* m, const MmiWeights& W, const std::string& name, int in, int out, ConvW* cw) {
+    const mmi_tensor_desc* w;
+    int rc = need(W, name, 2, &w);
+    if (rc) return rc;
+    if (w->shape[0] != out || w->shape[1] != in) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
+    cw->Cin = in; cw->Cout = out; cw->K = 1; cw->S = 1;
+    return pack_matrix(m, (const float*)w->data, out, in, in, 1, cw);
+}
+
+int load_vec(mmi_mimi* m, const MmiWeights& W, const std::string& name, int n, float** out) {
+    const mmi_tensor_desc* d;
+    int rc = need(W, name, 1, &d);
+    if (rc) return rc;
+    if (d->shape[0] != n) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
+    return copy_vec(m, d, n, out);
+}
+
+int load_transformer(mmi_mimi* m, const MmiWeights& W, const std::string& prefix, std::vector<TrLayerW>* layers) {
+    const mmi_mimi_cfg& c = m->cfg;
+    const int d = c.tr_d_model, ff = c.tr_dim_feedforward;
+    layers->resize(c.tr_num_layers);
+    for (int l = 0; l < c.tr_num_layers; ++l) {
+        TrLayerW& L = (*layers)[l];
+        std::string p = prefix + ".transformer.layers." + std::to_string(l);
+        int rc;
+        if ((rc = load_linear(m, W, p + ".self_attn.in_projs.0.weight", d, 3 * d, &L.in_proj))) return rc;
+        if ((rc = load_linear(m, W, p + ".self_attn.out_projs.0.weight", d, d, &L.out_proj))) return rc;
+        if ((rc = load_linear(m, W, p + ".linear1.weight", d, ff, &L.lin1))) return rc;
+        if ((rc = load_linear(m, W, p + ".linear2.weight", ff, d, &L.lin2))) return rc;
+        if ((rc = load_vec(m, W, p + ".norm1.weight", d, &L.n1w))) return rc;
+        if ((rc = load_vec(m, W, p + ".norm1.bias", d, &L.n1b))) return rc;
+        if ((rc = load_vec(m, W, p + ".norm2.weight", d, &L.n2w))) return rc;
+        if ((rc = load_vec(m, W, p + ".norm2.bias", d, &L.n2b))) return rc;
+        if ((rc = load_vec(m, W, p + ".layer_scale_1.scale", d, &L.ls1))) return rc;
+        if ((rc = load_vec(m, W, p + ".layer_scale_2.scale", d, &L.ls2))) return rc;
+    }
+    return MMI_OK;
+}
+
+int load_rvq(mmi_mimi* m, const MmiWeights& W) {
+    const mmi_mimi_cfg& c = m->cfg;
+    const int D = c.q_dimension, dim = c.dimension, bins = c.q_bins, nq = c.q_n_q;
+    // stacked input projection [2D][dim]: rows 0..D-1 = rvq_first.input_proj, D..2D-1 = rvq_rest.input_proj
+    const mmi_tensor_desc *wf, *wr, *of, *orr;
+    int rc;
+    if ((rc = need(W, "quantizer.rvq_first.input_proj.weight", 3, &wf))) return rc;
+    if ((rc = need(W, "quantizer.rvq_rest.input_proj.weight", 3, &wr))) return rc;
+    if ((rc = need(W, "quantizer.rvq_first.output_proj.weight", 3, &of))) return rc;
+    if ((rc = need(W, "quantizer.rvq_rest.output_proj.weight", 3, &orr))) return rc;
+    if (wf->shape[0] != D || wf->shape[1] != dim || of->shape[0] != dim || of->shape[1] != D)
+        return mmi_fail(MMI_ERR_SHAPE, "RVQ projection shape mismatch");
+    float* tmp = nullptr;
+    MMI_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)2 * D * dim * sizeof(float)));
+    MMI_HIP_CHECK(hipMemcpy(tmp, wf->data, (size_t)D * dim * sizeof(float), hipMemcpyDeviceToDevice));
+    MMI_HIP_CHECK(hipMemcpy(tmp + (size_t)D * dim, wr->data, (size_t)D * dim * sizeof(float), hipMemcpyDeviceToDevice));
+    m->q_in.Cin = dim; m->q_in.Cout = 2 * D; m->q_in.K = 1; m->q_in.S = 1;
+    rc = pack_matrix(m, tmp, 2 * D, dim, dim, 1, &m->q_in);
+    if (rc) { hipFree(tmp); return rc; }
+    MMI_HIP_CHECK(hipDeviceSynchronize());
+    // stacked output projection [dim][2D]: columns 0..D-1 = first, D..2D-1 = rest
+    int blocks = mmi_cdiv(dim * D, 256);
+    MMI_LAUNCH(k_copy2d_f32, blocks, 256, 0, (hipStream_t)0, (const float*)of->data, (long)D, tmp, (long)2 * D, dim, D);
+    MMI_LAUNCH(k_copy2d_f32, blocks, 256, 0, (hipStream_t)0, (const float*)orr->data, (long)D, tmp + D, (long)2 * D, dim, D);
+    MMI_CHECK_LAUNCH();
+    m->q_out.Cin = 2 * D; m->q_out.Cout = dim; m->q_out.K = 1; m->q_out.S = 1;
+    rc = pack_matrix(m, tmp, dim, 2 * D, 2 * D, 1, &m->q_out);
+    MMI_HIP_CHECK(hipDeviceSynchronize());
+    hipFree(tmp);
+    if (rc) return rc;
+
+    MMI_HIP_CHECK(m->wts.alloc(&m->E_all, (size_t)nq * bins * D));
+    MMI_HIP_CHECK(m->wts.alloc(&m->e2_all, (size_t)nq * bins));
+    for (int k = 0; k < nq; ++k) {
+        std::string p = k < c.q_n_q_semantic
+                            ? "quantizer.rvq_first.vq.layers." + std::to_string(k) + "._codebook."
+                            : "quantizer.rvq_rest.vq.layers." + std::to_string(k - c.q_n_q_semantic) + "._codebook.";
+        const mmi_tensor_desc *es, *cu;
+        if ((rc = need(W, p + "embedding_sum", 2, &es))) return rc;
+        if ((rc = need(W, p + "cluster_usage", 1, &cu))) return rc;
+        if (es->shape[0] != bins || es->shape[1] != D || cu->shape[0] != bins)
+            return mmi_fail(MMI_ERR_SHAPE, "codebook shape mismatch: " + p);
+        MMI_LAUNCH(k_codebook_prepare, bins, 64, 0, (hipStream_t)0, (const float*)es->data, (const float*)cu->data,
+                   m->E_all + (size_t)k * bins * D, m->e2_all + (size_t)k * bins, bins, D, 1e-5f);
+    }
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+int launch_conv(hipStream_t s, const ConvGemmArgs& a) {
+    const int Mt = a.Mt;
+    int NT = 4;
+    auto tiles = [&](int nt) { return Mt * mmi_cdiv(a.Ntot, 32 * nt); };
+    while (NT > 1 && tiles(NT) < 1024) NT >>= 1;
+    int KS = 1;
+    while (KS < 4 && tiles(NT) * KS < 1024 && a.Q / (KS * 2) >= 8) KS <<= 1;
+    if (KS > 1 && NT > 2) NT = 2;
+    const int nt_tiles = tiles(NT);
+    const int grid = mmi_cdiv(nt_tiles, 4 / KS);
+#define MMI_CG(NT_, KS_) MMI_LAUNCH((k_conv_gemm<NT_, KS_>), grid, 256, 0, s, a)
+    if (KS == 1) {
+        if (NT == 4) MMI_CG(4, 1); else if (NT == 2) MMI_CG(2, 1); else MMI_CG(1, 1);
+    } else if (KS == 2) {
+        if (NT == 2) MMI_CG(2, 2); else MMI_CG(1, 2);
+    } else {
+        if (NT == 2) MMI_CG(2, 4); else MMI_CG(1, 4);
+    }
+#undef MMI_CG
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+ConvGemmArgs conv_args(const ConvW& w, const Buf& in, int x_off, int T_out, const Buf& out, int out_off, int B,
+                       bool elu_in) {
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = in.p; a.x_ld = in.ld; a.x_bstride = (long)in.C * in.ld; a.x_off = x_off; a.H = in.H;
+    a.wpk = w.wpk; a.bias = w.bias;
+    a.out = out.p; a.out_ld = out.ld; a.out_off = out_off;
+    a.B = B; a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K; a.S = w.S; a.T_out = T_out;
+    a.Mt = w.Mt; a.Q = w.Q; a.Ntot = B * T_out;
+    a.elu_in = elu_in ? 1 : 0;
+    a.act_out = MMI_ACT_NONE;
+    return a;
+}
+
+int alloc_buf(mmi_mimi* m, int B, int C, int H, int T, Buf* b, hipStream_t s) {
+    b->C = C; b->H = H; b->ld = H + T;
+    size_t n = (size_t)B * C * b->ld;
+    MMI_HIP_CHECK(m->st.alloc(&b->p, n));
+    MMI_HIP_CHECK(hipMemsetAsync(b->p, 0, n * sizeof(float), s));
+    return MMI_OK;
+}
+
+void add_conv(MmiProgram& prog, ConvGemmArgs a) {
+    prog.add([a](hipStream_t s) { return launch_conv(s, a); });
+}
+
+// residual vector quantiser: latent [B][dim] (column `lat_off` of rows of length lat_ld) -> codes_i32 [B][n_q]
+void add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B) {
+    const mmi_mimi_cfg& c = m->cfg;
+    const int D = c.q_dimension, bins = c.q_bins;
+    Buf in; in.p = const_cast<float*>(latent); in.C = c.dimension; in.ld = lat_ld; in.H = lat_off;
+    Buf out; out.p = m->xq; out.C = 2 * D; out.ld = 1; out.H = 0;
+    add_conv(prog, conv_args(m->q_in, in, lat_off, 1, out, 0, B, false));
+    const int K = m->n_codebooks;
+    const int nchunk = m->nchunk;
+    const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 1) + (size_t)B * D) * sizeof(float);
+    for (int k = 0; k < K; ++k) {
+        const bool sem = k < c.q_n_q_semantic;
+        float* x = m->xq + (sem ? 0 : D);
+        const float* E = m->E_all + (size_t)k * bins * D;
+        const double* e2 = m->e2_all + (size_t)k * bins;
+        double* bd = m->best_d; int* bi = m->best_i; int* codes = m->codes_i32; const int nq = c.q_n_q;
+        prog.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_rvq_dist, nchunk, 256, smem, s, (const float*)x, 2 * D, E, e2, bd, bi, B, D, bins);
+            MMI_LAUNCH(k_rvq_select, B, 256, 0, s, (const double*)bd, (const int*)bi, nchunk, x, 2 * D, E, codes, nq, k, B, D);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+}
+
+// codes_i32 [B][n_q] (first K used) -> latent written to out buffer column out_off
+void add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B) {
+    const mmi_mimi_cfg& c = m->cfg;
+    const int D = c.q_dimension, bins = c.q_bins, nq = c.q_n_q, nsem = c.q_n_q_semantic;
+    float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all;
+    prog.add([=](hipStream_t s) {
+        MMI_LAUNCH(k_rvq_gather, mmi_cdiv(B * D, 256), 256, 0, s, codes, nq, K, E, bins, D, nsem, q2, B);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+    Buf in; in.p = m->q2; in.C = 2 * D; in.ld = 1; in.H = 0;
+    add_conv(prog, conv_args(m->q_out, in, 0, 1, out, out_off, B, false));
+}
+
+// one streaming transformer (ProjectedTransformer with conv_layout, transformer.py:932-983) working in place
+// on x = buf[:, :, off:off+T]
+int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& layers, const Buf& xb, int off, int T,
+                    float* kv, const long* offsets, int B, hipStream_t init_stream) {
+    const mmi_mimi_cfg& c = m->cfg;
+    const int d = c.tr_d_model, H = c.tr_num_heads, Dh = d / H, ff = c.tr_dim_feedforward, cap = c.tr_context;
+    Buf y, qkv, att, hb;
+    int rc;
+    if ((rc = alloc_buf(m, B, d, 0, T, &y, init_stream))) return rc;
+    if ((rc = alloc_buf(m, B, 3 * d, 0, T, &qkv, init_stream))) return rc;
+    if ((rc = alloc_buf(m, B, d, 0, T, &att, init_stream))) return rc;
+    if ((rc = alloc_buf(m, B, ff, 0, T, &hb, init_stream))) return rc;
+    const size_t kv_layer = (size_t)B * H * cap * Dh;
+    const size_t attn_smem = ((size_t)T * Dh + (size_t)T * cap + 256) * sizeof(float);
+    for (size_t l = 0; l < layers.size(); ++l) {
+        const TrLayerW& L = layers[l];
+        {   // x = x + ls1 * out_proj(attn(norm1(x)))
+            const float* xp = xb.p; int xld = xb.ld; float* yp = y.p; const float *w = L.n1w, *bb = L.n1b;
+            prog.add([=](hipStream_t s) {
+                MMI_LAUNCH(k_layernorm_ct, B * T, 64, 0, s, xp, xld, off, w, bb, yp, T, 0, d, T, 1e-5f);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            });
+            add_conv(prog, conv_args(L.in_proj, y, 0, T, qkv, 0, B, false));
+            MimiAttnArgs aa;
+            aa.qkv = qkv.p; aa.kc = kv + (2 * l) * kv_layer; aa.vc = kv + (2 * l + 1) * kv_layer;
+            aa.offsets = offsets; aa.out = att.p; aa.B = B; aa.H = H; aa.D = Dh; aa.T = T; aa.cap = cap;
+            aa.context = c.tr_context; aa.max_period = c.tr_max_period;
+            prog.add([=](hipStream_t s) {
+                MMI_LAUNCH(k_mimi_attn, B * H, 256, attn_smem, s, aa);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            });
+            ConvGemmArgs a = conv_args(L.out_proj, att, 0, T, xb, off, B, false);
+            a.res = xb.p; a.res_ld = xb.ld; a.res_off = off; a.scale = L.ls1;
+            add_conv(prog, a);
+        }
+        {   // x = x + ls2 * linear2(gelu(linear1(norm2(x))))
+            const float* xp = xb.p; int xld = xb.ld; float* yp = y.p; const float *w = L.n2w, *bb = L.n2b;
+            prog.add([=](hipStream_t s) {
+                MMI_LAUNCH(k_layernorm_ct, B * T, 64, 0, s, xp, xld, off, w, bb, yp, T, 0, d, T, 1e-5f);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            });
+            ConvGemmArgs a1 = conv_args(L.lin1, y, 0, T, hb, 0, B, false);
+            a1.act_out = MMI_ACT_GELU;
+            add_conv(prog, a1);
+            ConvGemmArgs a2 = conv_args(L.lin2, hb, 0, T, xb, off, B, false);
+            a2.res = xb.p; a2.res_ld = xb.ld; a2.res_off = off; a2.scale = L.ls2;
+            add_conv(prog, a2);
+        }
+    }
+    return MMI_OK;
+}
+
+int upload_hist(mmi_mimi* m, std::vector<HistDesc>& h, int B, HistDesc** dev, int* n, int* rows) {
+    int acc = 0;
+    std::vector<HistDesc> keep;
+    for (auto& d : h) {
+        if (d.H <= 0) continue;
+        d.row_begin = acc;
+        acc += B * d.C;
+        keep.push_back(d);
+    }
+    *n = (int)keep.size();
+    *rows = acc;
+    MMI_HIP_CHECK(m->st.alloc(dev, keep.size() ? keep.size() : 1));
+    if (!keep.empty())
+        MMI_HIP_CHECK(hipMemcpy(*dev, keep.data(), keep.size() * sizeof(HistDesc), hipMemcpyHostToDevice));
+    return MMI_OK;
+}
+
+HistDesc hist_of(const Buf& b, int T) {
+    HistDesc d;
+    d.p = b.p; d.C = b.C; d.ld = b.ld; d.H = b.H; d.T = T; d.row_begin = 0;
+    return d;
+}
+
+int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
+    const mmi_mimi_cfg& c = m->cfg;
+    MmiProgram& prog = m->enc_prog;
+    std::vector<HistDesc> hist;
+    int rc;
+    int T = c.frame_size;
+    size_t ci = 0;
+    // input PCM buffer with the first conv's history
+    if ((rc = alloc_buf(m, B, c.channels, c.kernel_size - 1, T, &m->enc_in, s0))) return rc;
+    hist.push_back(hist_of(m->enc_in, T));
+    Buf cur = m->enc_in;
+    int mult = 1;
+    {   // conv0: channels -> n_filters, K = kernel_size; consumer = resblock conv (K = residual_kernel_size)
+        Buf nxt;
+        if ((rc = alloc_buf(m, B, c.n_filters, c.residual_kernel_size - 1, T, &nxt, s0))) return rc;
+        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false));
+        hist.push_back(hist_of(nxt, T));
+        cur = nxt;
+    }
+    for (int i = 0; i < c.n_ratios; ++i) {
+        const int ratio = c.ratios[c.n_ratios - 1 - i];
+        const int ch = mult * c.n_filters;
+        // resblock: cur -> (ELU, conv K3 -> hidden) -> (ELU, conv K1 -> ch) + cur ; consumer = strided conv (K=2r, S=r)
+        Buf hid, nxt;
+        if ((rc = alloc_buf(m, B, ch / c.compress, 0, T, &hid, s0))) return rc;
+        if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
+        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true));
+        ConvGemmArgs a = conv_args(m->enc_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
+        a.res = cur.p; a.res_ld = cur.ld; a.res_off = cur.H;
+        add_conv(prog, a);
+        hist.push_back(hist_of(nxt, T));
+        cur = nxt;
+        // strided conv: ch -> 2ch ; consumer = next resblock conv (K3) or the final conv (last_kernel_size)
+        const int Tn = T / ratio;
+        const int Hn = (i + 1 < c.n_ratios) ? c.residual_kernel_size - 1 : c.last_kernel_size - 1;
+        Buf nx2;
+        if ((rc = alloc_buf(m, B, 2 * ch, Hn, Tn, &nx2, s0))) return rc;
+        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true));
+        hist.push_back(hist_of(nx2, Tn));
+        cur = nx2;
+        T = Tn;
+        mult *= 2;
+    }
+    // final conv -> dimension, written into the downsample conv's input buffer (history = stride)
+    const int stride = c.resample_stride;
+    Buf dsin;
+    if ((rc = alloc_buf(m, B, c.dimension, 2 * stride - stride, T, &dsin, s0))) return rc;
+    add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, dsin, dsin.H, B, true));
+    hist.push_back(hist_of(dsin, T));
+    // encoder transformer, in place on dsin[:, :, H:H+T]
+    {
+        const int Dh = c.tr_d_model / c.tr_num_heads;
+        size_t kvn = (size_t)2 * c.tr_num_layers * B * c.tr_num_heads * c.tr_context * Dh;
+        MMI_HIP_CHECK(m->st.alloc(&m->enc_kv, kvn));
+        MMI_HIP_CHECK(hipMemsetAsync(m->enc_kv, 0, kvn * sizeof(float), s0));
+        if ((rc = add_transformer(m, prog, m->enc_tr, dsin, dsin.H, T, m->enc_kv, m->counters, B, s0))) return rc;
+    }
+    const int T_tr = T;
+    // downsample (ConvDownsample1d learnt, replicate padding on the first frame)
+    if (T % stride != 0 || T / stride != 1)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "frame_size must map to exactly one latent column");
+    if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->latent, s0))) return rc;
+    {
+        ConvGemmArgs a = conv_args(m->downsample, dsin, 0, 1, m->latent, 0, B, false);
+        a.first = m->first; a.exec = m->exec;
+        add_conv(prog, a);
+    }
+    add_quantize_ops(m, prog, m->latent.p, 1, 0, B);
+    // commit
+    if ((rc = upload_hist(m, hist, B, &m->enc_hist, &m->enc_nhist, &m->enc_hist_rows))) return rc;
+    {
+        HistDesc* hd = m->enc_hist; int nh = m->enc_nhist, rows = m->enc_hist_rows;
+        const uint8_t* ex = m->exec; uint8_t* fi = m->first; long* cnt = m->counters;
+        prog.add([=](hipStream_t s) {
+            if (rows > 0) MMI_LAUNCH(k_commit_history, mmi_cdiv(rows, 256), 256, 0, s, (const HistDesc*)hd, nh, rows, ex);
+            MMI_LAUNCH(k_commit_counters, mmi_cdiv(B, 64), 64, 0, s, cnt, 1, T_tr, fi, ex, B);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+    return MMI_OK;
+}
+
+int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
+    const mmi_mimi_cfg& c = m->cfg;
+    MmiProgram& prog = m->dec_prog;
+    std::vector<HistDesc> hist;
+    int rc;
+    const int stride = c.resample_stride;
+    // dequantised latent [B][dim][1]
+    if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->dec_codes_lat, s0))) return rc;
+    add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B);
+    // upsample (depthwise transposed conv) into the decoder transformer buffer = input of decoder conv0
+    int T = stride;
+    Buf din;
+    if ((rc = alloc_buf(m, B, c.dimension, c.kernel_size - 1, T, &din, s0))) return rc;
+    hist.push_back(hist_of(din, T));
+    {
+        float* part = nullptr;
+        long pn = (long)c.dimension * stride;
+        MMI_HIP_CHECK(m->st.alloc(&part, (size_t)B * pn));
+        MMI_HIP_CHECK(hipMemsetAsync(part, 0, (size_t)B * pn * sizeof(float), s0));
+        m->partials.push_back(part); m->partial_sizes.push_back(pn);
+        const float* x = m->dec_codes_lat.p; const float* w = m->upsample_w; const uint8_t* ex = m->exec;
+        float* out = din.p; int old = din.ld, ooff = din.H; int C = c.dimension;
+        prog.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_upsample_dw, mmi_cdiv(B * C * stride, 256), 256, 0, s, x, 1, 0, w, part, ex, out, old, ooff, B, C,
+                       2 * stride, stride, 1);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+    {
+        const int Dh = c.tr_d_model / c.tr_num_heads;
+        size_t kvn = (size_t)2 * c.tr_num_layers * B * c.tr_num_heads * c.tr_context * Dh;
+        MMI_HIP_CHECK(m->st.alloc(&m->dec_kv, kvn));
+        MMI_HIP_CHECK(hipMemsetAsync(m->dec_kv, 0, kvn * sizeof(float), s0));
+        if ((rc = add_transformer(m, prog, m->dec_tr, din, din.H, T, m->dec_kv, m->counters + B, B, s0))) return rc;
+    }
+    const int T_tr = T;
+    size_t ci = 0;
+    int mult = 1 << c.n_ratios;
+    Buf cur;
+    {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
+        if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
+        add_conv(prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false));
+    }
+    for (int i = 0; i < c.n_ratios; ++i) {
+        const int ratio = c.ratios[i];
+        const int cin = mult * c.n_filters, cout = cin / 2, K = 2 * ratio;
+        // ELU + ConvTranspose1d: GEMM over channels, then overlap-add with the streaming partial
+        Buf tmp, up;
+        if ((rc = alloc_buf(m, B, cout * K, 0, T, &tmp, s0))) return rc;
+        const int Tn = T * ratio;
+        if ((rc = alloc_buf(m, B, cout, c.residual_kernel_size - 1, Tn, &up, s0))) return rc;
+        const ConvW& wtr = m->dec_convs[ci++];
+        {
+            ConvGemmArgs a = conv_args(wtr, cur, 0, T, tmp, 0, B, true);
+            a.bias = nullptr;  // bias is added once, in the combine step
+            add_conv(prog, a);
+        }
+        {
+            float* part = nullptr;
+            long pn = (long)cout * (K - ratio);
+            MMI_HIP_CHECK(m->st.alloc(&part, (size_t)B * pn));
+            MMI_HIP_CHECK(hipMemsetAsync(part, 0, (size_t)B * pn * sizeof(float), s0));
+            m->partials.push_back(part); m->partial_sizes.push_back(pn);
+            const float* tp = tmp.p; const float* bias = wtr.bias; const uint8_t* ex = m->exec;
+            float* out = up.p; int old = up.ld, ooff = up.H; int Tin = T;
+            prog.add([=](hipStream_t s) {
+                MMI_LAUNCH(k_convtr_combine, (int)mmi_cdiv64((int64_t)B * cout * Tin * ratio, 256), 256, 0, s, tp, bias, part,
+                           ex, out, old, ooff, B, cout, K, ratio, Tin);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            });
+        }
+        hist.push_back(hist_of(up, Tn));
+        T = Tn;
+        // resblock; consumer = next conv-transpose GEMM (no history) or the final conv (last_kernel_size)
+        Buf hid, nxt;
+        const int Hn = (i + 1 < c.n_ratios) ? 0 : c.last_kernel_size - 1;
+        if ((rc = alloc_buf(m, B, cout / c.compress, 0, T, &hid, s0))) return rc;
+        if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
+        add_conv(prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true));
+        ConvGemmArgs a = conv_args(m->dec_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
+        a.res = up.p; a.res_ld = up.ld; a.res_off = up.H;
+        add_conv(prog, a);
+        if (Hn > 0) hist.push_back(hist_of(nxt, T));
+        cur = nxt;
+        mult /= 2;
+    }
+    if (T != c.frame_size) return mmi_fail(MMI_ERR_UNSUPPORTED, "decoder does not reproduce frame_size samples");
+    if ((rc = alloc_buf(m, B, c.channels, 0, T, &m->dec_out, s0))) return rc;
+    add_conv(prog, conv_args(m->dec_convs[ci++], cur, 0, T, m->dec_out, 0, B, true));
+    if ((rc = upload_hist(m, hist, B, &m->dec_hist, &m->dec_nhist, &m->dec_hist_rows))) return rc;
+    {
+        HistDesc* hd = m->dec_hist; int nh = m->dec_nhist, rows = m->dec_hist_rows;
+        const uint8_t* ex = m->exec; long* cnt = m->counters + B;
+        prog.add([=](hipStream_t s) {
+            if (rows > 0) MMI_LAUNCH(k_commit_history, mmi_cdiv(rows, 256), 256, 0, s, (const HistDesc*)hd, nh, rows, ex);
+            MMI_LAUNCH(k_commit_counters, mmi_cdiv(B, 64), 64, 0, s, cnt, 1, T_tr, (uint8_t*)nullptr, ex, B);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+    return MMI_OK;
+}
+
+int check_cfg(const mmi_mimi_cfg& c) {
+    if (c.n_ratios < 1 || c.n_ratios > 8) return mmi_fail(MMI_ERR_UNSUPPORTED, "n_ratios out of range");
+    int hop = 1;
+    for (int i = 0; i < c.n_ratios; ++i) hop *= c.ratios[i];
+    if (hop * c.resample_stride != c.frame_size) return mmi_fail(MMI_ERR_UNSUPPORTED, "frame_size != hop*stride");
+    if (c.tr_d_model != c.dimension) return mmi_fail(MMI_ERR_UNSUPPORTED, "projected transformer (d_model != dimension)");
+    const int Dh = c.tr_d_model / c.tr_num_heads;
+    if (Dh * c.tr_num_heads != c.tr_d_model || (Dh & 1) || 256 % Dh != 0)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be even and divide 256");
+    if (c.compress < 1 || c.q_n_q_semantic < 1 || c.q_n_q < c.q_n_q_semantic)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "bad quantizer/compress config");
+    return MMI_OK;
+}
+
+int frame_count_ok(const mmi_mimi* m, int batch, int n_frames) {
+    if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming: call mmi_mimi_streaming_start first");
+    if (batch != m->batch) return mmi_fail(MMI_ERR_SHAPE, "batch size does not match the streaming batch");
+    if (n_frames <= 0) return mmi_fail(MMI_ERR_SHAPE, "length must be a positive multiple of the frame size");
+    return MMI_OK;
+}
+
+}  // namespace
+
+// ===============================================================================================
+// C ABI
+// ===============================================================================================
+extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights,
+                               int32_t max_batch, mmi_mimi** out) {
+    if (!cfg || !weights || !out || max_batch <= 0) return mmi_fail(MMI_ERR_INVALID, "mmi_mimi_create: bad argument");
+    int rc = check_cfg(*cfg);
+    if (rc) return rc;
+    mmi_mimi* m = new mmi_mimi();
+    m->cfg = *cfg;
+    m->max_batch = max_batch;
+    m->n_codebooks = cfg->q_n_q < 8 ? cfg->q_n_q : 8;
+    m->use_graph = mmi_graphs_enabled();
+    MmiWeights W{weights, n_weights};
+    const mmi_mimi_cfg& c = m->cfg;
+    auto fail = [&](int code) { mmi_mimi_destroy(m); return code; };
+
+    // ---- SEANet encoder (seanet.py:169-236): model.{0,3,6,...} strided, model.{1,4,...}.block.{1,3} resblocks
+    {
+        int idx = 0, mult = 1;
+        ConvW cw;
+        if ((rc = load_conv(m, W, "encoder.model.0.conv.conv", c.channels, c.n_filters, c.kernel_size, 1, true, &cw))) return fail(rc);
+        m->enc_convs.push_back(cw);
+        idx = 1;
+        for (int i = 0; i < c.n_ratios; ++i) {
+            const int ratio = c.ratios[c.n_ratios - 1 - i];
+            const int ch = mult * c.n_filters, hid = ch / c.compress;
+            std::string rb = "encoder.model." + std::to_string(idx) + ".block.";
+            if ((rc = load_conv(m, W, rb + "1.conv.conv", ch, hid, c.residual_kernel_size, 1, true, &cw))) return fail(rc);
+            m->enc_convs.push_back(cw);
+            if ((rc = load_conv(m, W, rb + "3.conv.conv", hid, ch, 1, 1, true, &cw))) return fail(rc);
+            m->enc_convs.push_back(cw);
+            idx += 2;  // resblock, ELU
+            if ((rc = load_conv(m, W, "encoder.model." + std::to_string(idx) + ".conv.conv", ch, 2 * ch, 2 * ratio, ratio, true, &cw))) return fail(rc);
+            m->enc_convs.push_back(cw);
+            idx += 1;
+            mult *= 2;
+        }
+        idx += 1;  // ELU
+        if ((rc = load_conv(m, W, "encoder.model." + std::to_string(idx) + ".conv.conv", mult * c.n_filters, c.dimension, c.last_kernel_size, 1, true, &cw))) return fail(rc);
+        m->enc_convs.push_back(cw);
+    }
+    // ---- SEANet decoder (seanet.py:315-388)
+    {
+        int mult = 1 << c.n_ratios;
+        ConvW cw;
+        if ((rc = load_conv(m, W, "decoder.model.0.conv.conv", c.dimension, mult * c.n_filters, c.kernel_size, 1, true, &cw))) return fail(rc);
+        m->dec_convs.push_back(cw);
+        int idx = 1;
+        for (int i = 0; i < c.n_ratios; ++i) {
+            const int ratio = c.ratios[i];
+            const int cin = mult * c.n_filters, cout = cin / 2, hid = cout / c.compress;
+            idx += 1;  // ELU
+            if ((rc = load_convtr(m, W, "decoder.model." + std::to_string(idx) + ".convtr.convtr", cin, cout, 2 * ratio, ratio, &cw))) return fail(rc);
+            m->dec_convs.push_back(cw);
+            idx += 1;
+            std::string rb = "decoder.model." + std::to_string(idx) + ".block.";
+            if ((rc = load_conv(m, W, rb + "1.conv.conv", cout, hid, c.residual_kernel_size, 1, true, &cw))) return fail(rc);
+            m->dec_convs.push_back(cw);
+            if ((rc = load_conv(m, W, rb + "3.conv.conv", hid, cout, 1, 1, true, &cw))) return fail(rc);
+            m->dec_convs.push_back(cw);
+            idx += 1;
+            mult /= 2;
+        }
+        idx += 1;  // ELU
+        if ((rc = load_conv(m, W, "decoder.model." + std::to_string(idx) + ".conv.conv", c.n_filters, c.channels, c.last_kernel_size, 1, true, &cw))) return fail(rc);
+        m->dec_convs.push_back(cw);
+    }
+    if ((rc = load_transformer(m, W, "encoder_transformer", &m->enc_tr))) return fail(rc);
+    if ((rc = load_transformer(m, W, "decoder_transformer", &m->dec_tr))) return fail(rc);
+    // ---- resampling (resample.py:14-119)
+    if ((rc = load_conv(m, W, "downsample.conv.conv.conv", c.dimension, c.dimension, 2 * c.resample_stride, c.resample_stride, false, &m->downsample))) return fail(rc);
+    {
+        const mmi_tensor_desc* w;
+        if ((rc = need(W, "upsample.convtr.convtr.convtr.weight", 3, &w))) return fail(rc);
+        if (w->shape[0] != c.dimension || w->shape[1] != 1 || w->shape[2] != 2 * c.resample_stride)
+            return fail(mmi_fail(MMI_ERR_SHAPE, "shape mismatch for upsample weight"));
+        if ((rc = copy_vec(m, w, c.dimension * 2 * c.resample_stride, &m->upsample_w))) return fail(rc);
+    }
+    if ((rc = load_rvq(m, W))) return fail(rc);
+    // ---- RVQ scratch
+    m->nchunk = mmi_cdiv(c.q_bins, MMI_RVQ_CHUNK);
+    if (hipSuccess != m->wts.alloc(&m->xq, (size_t)max_batch * 2 * c.q_dimension) ||
+        hipSuccess != m->wts.alloc(&m->best_d, (size_t)m->nchunk * max_batch) ||
+        hipSuccess != m->wts.alloc(&m->best_i, (size_t)m->nchunk * max_batch) ||
+        hipSuccess != m->wts.alloc(&m->codes_i32, (size_t)max_batch * c.q_n_q) ||
+        hipSuccess != m->wts.alloc(&m->q2, (size_t)max_batch * 2 * c.q_dimension) ||
+        hipSuccess != m->wts.alloc(&m->lat_tmp, (size_t)max_batch * c.dimension))
+        return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (RVQ scratch)"));
+    if (hipDeviceSynchronize() != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "weight packing failed"));
+    if (m->use_graph && hipStreamCreate(&m->cap_stream) != hipSuccess)
+        return fail(mmi_fail(MMI_ERR_HIP, "hipStreamCreate failed"));
+    *out = m;
+    return MMI_OK;
+}
+
+extern "C" void mmi_mimi_destroy(mmi_mimi* m) {
+    if (!m) return;
+    mmi_mimi_streaming_stop(m);
+    m->wts.release();
+    if (m->cap_stream) hipStreamDestroy(m->cap_stream);
+    delete m;
+}
+
+extern "C" int mmi_mimi_set_num_codebooks(mmi_mimi* m, int32_t n) {
+    if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (n < 1 || n > m->cfg.q_n_q) return mmi_fail(MMI_ERR_INVALID, "num_codebooks out of range");
+    if (m->streaming) return mmi_fail(MMI_ERR_STATE, "set_num_codebooks while streaming");
+    m->n_codebooks = n;
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_num_codebooks(const mmi_mimi* m) { return m ? m->n_codebooks : 0; }
+
+extern "C" int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream stream) {
+    if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (m->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");  // streaming.py:113
+    if (batch <= 0 || batch > m->max_batch) return mmi_fail(MMI_ERR_SHAPE, "batch exceeds max_batch");
+    hipStream_t s = (hipStream_t)stream;
+    m->batch = batch;
+    int rc = MMI_OK;
+    auto fail = [&](int code) { m->streaming = true; mmi_mimi_streaming_stop(m); return code; };
+    if (hipSuccess != m->st.alloc(&m->exec, (size_t)batch) || hipSuccess != m->st.alloc(&m->first, (size_t)batch) ||
+        hipSuccess != m->st.alloc(&m->counters, (size_t)2 * batch))
+        return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (state)"));
+    MMI_HIP_CHECK(hipMemsetAsync(m->exec, 1, batch, s));
+    MMI_HIP_CHECK(hipMemsetAsync(m->first, 1, batch, s));
+    MMI_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)2 * batch * sizeof(long), s));
+    if ((rc = build_encoder(m, batch, s))) return fail(rc);
+    if ((rc = build_decoder(m, batch, s))) return fail(rc);
+    MMI_HIP_CHECK(hipStreamSynchronize(s));
+    m->streaming = true;
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_streaming_stop(mmi_mimi* m) {
+    if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!m->streaming) return MMI_OK;
+    hipDeviceSynchronize();
+    m->enc_prog.clear();
+    m->dec_prog.clear();
+    m->st.release();
+    m->partials.clear();
+    m->partial_sizes.clear();
+    m->streaming = false;
+    m->batch = 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream) {
+    if (!m || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    MMI_LAUNCH(k_set_mask, mmi_cdiv(m->batch, 64), 64, 0, (hipStream_t)stream, m->exec, mask, m->batch);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_reset(mmi_mimi* m, const uint8_t* mask, mmi_stream stream) {
+    if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = m->batch;
+    if (m->enc_hist_rows > 0)
+        MMI_LAUNCH(k_reset_history, mmi_cdiv(m->enc_hist_rows, 256), 256, 0, s, (const HistDesc*)m->enc_hist, m->enc_nhist, m->enc_hist_rows, mask);
+    if (m->dec_hist_rows > 0)
+        MMI_LAUNCH(k_reset_history, mmi_cdiv(m->dec_hist_rows, 256), 256, 0, s, (const HistDesc*)m->dec_hist, m->dec_nhist, m->dec_hist_rows, mask);
+    for (size_t i = 0; i < m->partials.size(); ++i)
+        MMI_LAUNCH(k_reset_rows_f32, (int)mmi_cdiv64((int64_t)B * m->partial_sizes[i], 256), 256, 0, s, m->partials[i], m->partial_sizes[i], B, mask);
+    MMI_LAUNCH(k_reset_counters, mmi_cdiv(B, 64), 64, 0, s, m->counters, 2, m->first, m->exec, B, mask);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+static int encode_impl(mmi_mimi* m, const float* pcm, int64_t* codes, float* latent, int32_t batch, int32_t n_frames,
+                       hipStream_t s) {
+    int rc = frame_count_ok(m, batch, n_frames);
+    if (rc) return rc;
+    if (!pcm) return mmi_fail(MMI_ERR_INVALID, "null pcm");
+    const mmi_mimi_cfg& c = m->cfg;
+    const int F = c.frame_size, K = m->n_codebooks;
+    for (int f = 0; f < n_frames; ++f) {
+        // stage the frame behind the first conv's history
+        MMI_LAUNCH(k_copy2d_f32, (int)mmi_cdiv64((int64_t)batch * c.channels * F, 256), 256, 0, s, pcm + (long)f * F,
+                   (long)n_frames * F, m->enc_in.p + m->enc_in.H, (long)m->enc_in.ld, batch * c.channels, F);
+        if ((rc = m->enc_prog.run(s, m->use_graph, m->cap_stream))) return rc;
+        if (codes)
+            MMI_LAUNCH(k_codes_out, mmi_cdiv(batch * K, 256), 256, 0, s, (const int*)m->codes_i32, c.q_n_q, (long*)codes, batch, K, n_frames, f);
+        if (latent)
+            MMI_LAUNCH(k_copy2d_f32, mmi_cdiv(batch * c.dimension, 256), 256, 0, s, (const float*)m->latent.p, 1L, latent + f,
+                       (long)n_frames, batch * c.dimension, 1);
+        MMI_CHECK_LAUNCH();
+    }
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_encode_step(mmi_mimi* m, const float* pcm, int64_t* codes, int32_t batch, int32_t n_frames,
+                                    mmi_stream stream) {
+    if (!codes) return mmi_fail(MMI_ERR_INVALID, "null codes");
+    return encode_impl(m, pcm, codes, nullptr, batch, n_frames, (hipStream_t)stream);
+}
+
+extern "C" int mmi_mimi_encode_latent_step(mmi_mimi* m, const float* pcm, float* latent, int32_t batch, int32_t n_frames,
+                                           mmi_stream stream) {
+    if (!latent) return mmi_fail(MMI_ERR_INVALID, "null latent");
+    return encode_impl(m, pcm, nullptr, latent, batch, n_frames, (hipStream_t)stream);
+}
+
+extern "C" int mmi_mimi_quantize(mmi_mimi* m, const float* latent, int64_t* codes, int32_t batch, int32_t n_frames,
+                                 mmi_stream stream) {
+    if (!m || !latent || !codes) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (batch <= 0 || batch > m->max_batch || n_frames <= 0) return mmi_fail(MMI_ERR_SHAPE, "bad batch / frames");
+    hipStream_t s = (hipStream_t)stream;
+    const mmi_mimi_cfg& c = m->cfg;
+    for (int f = 0; f < n_frames; ++f) {
+        MmiProgram prog;
+        add_quantize_ops(m, prog, latent, n_frames, f, batch);
+        int rc = prog.run_eager(s);
+        if (rc) return rc;
+        MMI_LAUNCH(k_codes_out, mmi_cdiv(batch * m->n_codebooks, 256), 256, 0, s, (const int*)m->codes_i32, c.q_n_q, (long*)codes, batch,
+                   m->n_codebooks, n_frames, f);
+        MMI_CHECK_LAUNCH();
+    }
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* latent, int32_t batch, int32_t n_codebooks,
+                                      int32_t n_frames, mmi_stream stream) {
+    if (!m || !latent || !codes) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (batch <= 0 || batch > m->max_batch || n_frames <= 0 || n_codebooks < 1 || n_codebooks > m->cfg.q_n_q)
+        return mmi_fail(MMI_ERR_SHAPE, "bad batch / codebooks / frames");
+    hipStream_t s = (hipStream_t)stream;
+    const mmi_mimi_cfg& c = m->cfg;
+    Buf out; out.p = latent; out.C = c.dimension; out.ld = n_frames; out.H = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
+        MmiProgram prog;
+        add_dequant_ops(m, prog, n_codebooks, out, f, batch);
+        int rc = prog.run_eager(s);
+        if (rc) return rc;
+    }
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pcm, int32_t batch, int32_t n_codebooks,
+                                    int32_t n_frames, mmi_stream stream) {
+    int rc = frame_count_ok(m, batch, n_frames);
+    if (rc) return rc;
+    if (!codes || !pcm) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (n_codebooks != m->n_codebooks) return mmi_fail(MMI_ERR_SHAPE, "codes must carry num_codebooks rows");
+    hipStream_t s = (hipStream_t)stream;
+    const mmi_mimi_cfg& c = m->cfg;
+    const int F = c.frame_size;
+    for (int f = 0; f < n_frames; ++f) {
+        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
+        MMI_CHECK_LAUNCH();
+        if ((rc = m->dec_prog.run(s, m->use_graph, m->cap_stream))) return rc;
+        MMI_LAUNCH(k_copy2d_f32, (int)mmi_cdiv64((int64_t)batch * c.channels * F, 256), 256, 0, s, (const float*)m->dec_out.p, (long)F,
+                   pcm + (long)f * F, (long)n_frames * F, batch * c.channels, F);
+        MMI_CHECK_LAUNCH();
+    }
+    return MMI_OK;
+}

@@ -1,0 +1,78 @@
+// Small helpers shared by the Mimi and LM engines (host + device).
+#pragma once
+#include <mmi_device.h>  // resolved through -I: csrc/ for the gfx950 build
+#include "../../include/moshi_mi.h"
+
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <functional>
+
+#define MMI_HD __host__ __device__ __forceinline__
+
+// bf16 <-> f32, round-to-nearest-even, NaN kept quiet: identical to torch's float->bfloat16 cast.
+MMI_HD float mmi_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+MMI_HD uint16_t mmi_f32_to_bf16(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+// round an fp32 value to the nearest bf16 and return it widened again ("bf16 rounding point")
+MMI_HD float mmi_round_bf16(float f) { return mmi_bf16_to_f32(mmi_f32_to_bf16(f)); }
+
+static inline int mmi_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t mmi_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- error plumbing ------------------------------------------------------------------------
+void mmi_set_error(const std::string& msg);
+int mmi_fail(int code, const std::string& msg);
+
+#define MMI_HIP_CHECK(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return mmi_fail(MMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+#define MMI_CHECK_LAUNCH()                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                           \
+        if (e_ != hipSuccess)                                                                        \
+            return mmi_fail(MMI_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_));    \
+    } while (0)
+
+// ---- weight table lookup -------------------------------------------------------------------
+struct MmiWeights {
+    const mmi_tensor_desc* descs;
+    int n;
+    const mmi_tensor_desc* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i)
+            if (descs[i].name && name == descs[i].name) return &descs[i];
+        return nullptr;
+    }
+};
+
+// device allocation bookkeeping: every engine frees what it allocated
+struct MmiArena {
+    std::vector<void*> ptrs;
+    size_t bytes = 0;
+    template <class T>
+    hipError_t alloc(T** p, size_t count) {
+        void* q = nullptr;
+        size_t nb = count * sizeof(T);
+        if (nb == 0) nb = sizeof(T);
+        hipError_t e = hipMalloc(&q, nb);
+        if (e != hipSuccess) return e;
+        ptrs.push_back(q);
+        bytes += nb;
+        *p = (T*)q;
+        return hipSuccess;
+    }
+    void release() {
+        for (void* p : ptrs) hipFree(p);
+        ptrs.clear();
+        bytes = 0;
+    }
+};

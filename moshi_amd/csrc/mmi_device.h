@@ -1,0 +1,58 @@
+// Device-side primitives for the gfx950 (MI355X / CDNA4) build.  Every kernel in csrc/ is written
+// against this small vocabulary: 64-lane wave shuffles, the four MFMA shapes we use, non-temporal
+// 16-byte weight loads and the launch macro.  This file is the ONLY place the amdgcn builtins are
+// named, so the kernels read as algorithms rather than intrinsic soup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mmi_bf16x8 __attribute__((ext_vector_type(8)));
+
+#define MMI_WAVE 64
+#define MMI_SHARED __shared__
+#define MMI_DYN_SHARED(T, name)                                                   \
+    extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[];  \
+    T* name = reinterpret_cast<T*>(name##_raw_)
+#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
+
+__device__ __forceinline__ int mmi_lane() { return (int)(threadIdx.x & 63u); }
+
+template <class T>
+__device__ __forceinline__ T mmi_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+template <class T>
+__device__ __forceinline__ T mmi_shfl(T v, int src) { return __shfl(v, src, 64); }
+
+// D(32x32) += A(32x2) * B(2x32), exact fp32 fma chain.  lane l: a = A[l&31][l>>5], b = B[l>>5][l&31];
+// d[r] = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 mmi_mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// D(16x16) += A(16x4) * B(4x16).  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; d[r] = D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ f32x4 mmi_mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// D(32x32) += A(32x16) * B(16x32), bf16 in / fp32 acc.  lane l: a[e] = A[l&31][8*(l>>5)+e],
+// b[e] = B[8*(l>>5)+e][l&31]; d as the 32x32 map above.
+__device__ __forceinline__ f32x16 mmi_mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mmi_bf16x8, a),
+                                                   __builtin_bit_cast(mmi_bf16x8, b), c, 0, 0, 0);
+}
+// D(16x16) += A(16x32) * B(32x16).  lane l: a[e] = A[l&15][8*(l>>4)+e], b[e] = B[8*(l>>4)+e][l&15];
+// d[r] = D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ f32x4 mmi_mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mmi_bf16x8, a),
+                                                   __builtin_bit_cast(mmi_bf16x8, b), c, 0, 0, 0);
+}
+
+// streamed-once weights: non-temporal so they do not evict the activations / KV the other kernels reuse
+__device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_nontemporal_load(p); }
+
+__device__ __forceinline__ float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }  // IEEE, matches torch.rsqrt closely
+__device__ __forceinline__ unsigned mmi_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }

@@ -1,0 +1,167 @@
+"""State-dict layout of the two models (names/shapes exactly as the reference checkpoints carry them,
+SURVEY.md Appendix A; reference: seanet.py:169-236,315-388, transformer.py:407-418, vq.py:76-84,
+core_vq.py:158-160, lm.py:135-232) and seeded synthetic weights of that layout.
+
+There is no network and no released checkpoint in this environment, so benchmarks and parity tests use
+synthetic weights: drawn on the CPU generator from a seed (bit-reproducible across machines for one torch
+build), with magnitudes that keep activations O(1).  The golden-vector generator loads the very same tensors
+into the reference implementation (`load_state_dict`), which is what makes its outputs comparable.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+
+from .config import LMConfig, MimiConfig
+
+Spec = List[Tuple[str, Tuple[int, ...], str]]  # (name, shape, kind)
+
+
+def mimi_state_spec(cfg: MimiConfig) -> Spec:
+    spec: Spec = []
+
+    def conv(prefix: str, cout: int, cin: int, k: int, bias: bool = True):
+        spec.append((prefix + ".weight", (cout, cin, k), f"fan:{cin * k}"))
+        if bias:
+            spec.append((prefix + ".bias", (cout,), f"fan:{cin * k}"))
+
+    nf, nr = cfg.n_filters, len(cfg.ratios)
+    # encoder
+    conv("encoder.model.0.conv.conv", nf, cfg.channels, cfg.kernel_size)
+    idx, mult = 1, 1
+    for ratio in reversed(cfg.ratios):
+        ch, hid = mult * nf, mult * nf // cfg.compress
+        conv(f"encoder.model.{idx}.block.1.conv.conv", hid, ch, cfg.residual_kernel_size)
+        conv(f"encoder.model.{idx}.block.3.conv.conv", ch, hid, 1)
+        idx += 2
+        conv(f"encoder.model.{idx}.conv.conv", 2 * ch, ch, 2 * ratio)
+        idx += 1
+        mult *= 2
+    idx += 1
+    conv(f"encoder.model.{idx}.conv.conv", cfg.dimension, mult * nf, cfg.last_kernel_size)
+    # decoder
+    mult = 2 ** nr
+    conv("decoder.model.0.conv.conv", mult * nf, cfg.dimension, cfg.kernel_size)
+    idx = 1
+    for ratio in cfg.ratios:
+        cin, cout = mult * nf, mult * nf // 2
+        idx += 1
+        spec.append((f"decoder.model.{idx}.convtr.convtr.weight", (cin, cout, 2 * ratio), f"fan:{cin * 2}"))
+        spec.append((f"decoder.model.{idx}.convtr.convtr.bias", (cout,), f"fan:{cin * 2}"))
+        idx += 1
+        conv(f"decoder.model.{idx}.block.1.conv.conv", cout // cfg.compress, cout, cfg.residual_kernel_size)
+        conv(f"decoder.model.{idx}.block.3.conv.conv", cout, cout // cfg.compress, 1)
+        idx += 1
+        mult //= 2
+    idx += 1
+    conv(f"decoder.model.{idx}.conv.conv", cfg.channels, nf, cfg.last_kernel_size)
+    # transformers
+    d, ff = cfg.tr_d_model, cfg.tr_dim_feedforward
+    for name in ("encoder_transformer", "decoder_transformer"):
+        for l in range(cfg.tr_num_layers):
+            p = f"{name}.transformer.layers.{l}"
+            spec.append((p + ".self_attn.in_projs.0.weight", (3 * d, d), f"fan:{d}"))
+            spec.append((p + ".self_attn.out_projs.0.weight", (d, d), f"fan:{d}"))
+            spec.append((p + ".norm1.weight", (d,), "norm_w"))
+            spec.append((p + ".norm1.bias", (d,), "norm_b"))
+            spec.append((p + ".norm2.weight", (d,), "norm_w"))
+            spec.append((p + ".norm2.bias", (d,), "norm_b"))
+            spec.append((p + ".linear1.weight", (ff, d), f"fan:{d}"))
+            spec.append((p + ".linear2.weight", (d, ff), f"fan:{ff}"))
+            spec.append((p + ".layer_scale_1.scale", (d,), "layer_scale"))
+            spec.append((p + ".layer_scale_2.scale", (d,), "layer_scale"))
+    # resampling
+    s = cfg.resample_stride
+    spec.append(("downsample.conv.conv.conv.weight", (cfg.dimension, cfg.dimension, 2 * s), f"fan:{cfg.dimension * 2 * s}"))
+    spec.append(("upsample.convtr.convtr.convtr.weight", (cfg.dimension, 1, 2 * s), "fan:2"))
+    # quantiser
+    D, bins = cfg.q_dimension, cfg.q_bins
+    for part, n in (("rvq_first", cfg.q_n_q_semantic), ("rvq_rest", cfg.q_n_q - cfg.q_n_q_semantic)):
+        spec.append((f"quantizer.{part}.input_proj.weight", (D, cfg.dimension, 1), f"fan:{cfg.dimension}"))
+        spec.append((f"quantizer.{part}.output_proj.weight", (cfg.dimension, D, 1), f"fan:{D}"))
+        for k in range(n):
+            p = f"quantizer.{part}.vq.layers.{k}._codebook."
+            spec.append((p + "_initialized", (1,), "one"))
+            spec.append((p + "cluster_usage", (bins,), "usage"))
+            spec.append((p + "embedding_sum", (bins, D), f"codebook:{k}"))
+    return spec
+
+
+def lm_state_spec(cfg: LMConfig) -> Spec:
+    spec: Spec = []
+    d, dd = cfg.dim, cfg.depformer_dim
+    h, dh = cfg.ffn_hidden, cfg.depformer_ffn_hidden
+    for i in range(cfg.n_q):
+        spec.append((f"emb.{i}.weight", (cfg.card + 1, d), f"emb:{d}"))
+    spec.append(("text_emb.weight", (cfg.text_card + 1, d), f"emb:{d}"))
+    spec.append(("text_linear.weight", (cfg.text_card, d), f"fan:{d}"))
+    spec.append(("out_norm.alpha", (1, 1, d), "alpha"))
+    for l in range(cfg.num_layers):
+        p = f"transformer.layers.{l}"
+        spec.append((p + ".self_attn.in_projs.0.weight", (3 * d, d), f"fan:{d}"))
+        spec.append((p + ".self_attn.out_projs.0.weight", (d, d), f"fan:{d}"))
+        spec.append((p + ".norm1.alpha", (1, 1, d), "alpha"))
+        spec.append((p + ".norm2.alpha", (1, 1, d), "alpha"))
+        spec.append((p + ".gating.linear_in.weight", (2 * h, d), f"fan:{d}"))
+        spec.append((p + ".gating.linear_out.weight", (d, h), f"fan:{h}"))
+    for k in range(cfg.dep_q):
+        spec.append((f"depformer_in.{k}.weight", (dd, d), f"fan:{d}"))
+    for k in range(cfg.dep_q - 1):
+        spec.append((f"depformer_emb.{k}.weight", (cfg.card + 1, dd), f"emb:{dd}"))
+    spec.append(("depformer_text_emb.weight", (cfg.text_card + 1, dd), f"emb:{dd}"))
+    for l in range(cfg.depformer_num_layers):
+        p = f"depformer.layers.{l}"
+        for k in range(cfg.dep_q):
+            spec.append((p + f".self_attn.in_projs.{k}.weight", (3 * dd, dd), f"fan:{dd}"))
+            spec.append((p + f".self_attn.out_projs.{k}.weight", (dd, dd), f"fan:{dd}"))
+        spec.append((p + ".norm1.alpha", (1, 1, dd), "alpha"))
+        spec.append((p + ".norm2.alpha", (1, 1, dd), "alpha"))
+        for k in range(cfg.dep_q):
+            spec.append((p + f".gating.{k}.linear_in.weight", (2 * dh, dd), f"fan:{dd}"))
+            spec.append((p + f".gating.{k}.linear_out.weight", (dd, dh), f"fan:{dh}"))
+    for k in range(cfg.dep_q):
+        spec.append((f"linears.{k}.weight", (cfg.card, dd), f"fan:{dd}"))
+    return spec
+
+
+def _draw(shape, kind: str, gen: torch.Generator, device, dtype) -> torch.Tensor:
+    """One synthetic tensor.  Drawn on `device` when it is a GPU (fast for the 7B benchmark model)."""
+    def rnd(fn, *a):
+        return fn(*a, generator=gen, device=device, dtype=torch.float32)
+    if kind.startswith("fan:"):
+        fan = int(kind[4:])
+        t = (rnd(torch.rand, shape) * 2 - 1) * math.sqrt(3.0 / fan)   # unit-gain uniform
+    elif kind.startswith("emb:"):
+        t = rnd(torch.randn, shape) / math.sqrt(int(kind[4:]))
+    elif kind.startswith("codebook"):
+        t = rnd(torch.randn, shape)
+    elif kind == "usage":
+        t = rnd(torch.rand, shape) * 1.5 + 0.5
+    elif kind == "norm_w" or kind == "alpha":
+        t = 1.0 + 0.1 * rnd(torch.randn, shape)
+    elif kind == "norm_b":
+        t = 0.05 * rnd(torch.randn, shape)
+    elif kind == "layer_scale":
+        t = 0.3 + 0.05 * rnd(torch.randn, shape)   # larger than the 0.01 init so the transformer matters in tests
+    elif kind == "one":
+        t = torch.ones(shape, device=device, dtype=torch.float32)
+    else:
+        raise ValueError(kind)
+    return t.to(dtype)
+
+
+def random_state_dict(spec: Spec, seed: int, device="cpu", dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    return {name: _draw(shape, kind, gen, device, dtype) for name, shape, kind in spec}
+
+
+def random_mimi_state_dict(cfg: MimiConfig, seed: int = 1234, device="cpu") -> Dict[str, torch.Tensor]:
+    return random_state_dict(mimi_state_spec(cfg), seed, device, torch.float32)
+
+
+def random_lm_state_dict(cfg: LMConfig, seed: int = 4242, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    return random_state_dict(lm_state_spec(cfg), seed, device, dtype)

@@ -1,0 +1,290 @@
+// hipsim runtime — see hipsim.h.  TEST INFRASTRUCTURE ONLY.
+#include "hipsim.h"
+
+#include <ucontext.h>
+#include <sys/mman.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace hipsim {
+
+thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+
+namespace {
+
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr int kMaxThreads = 1024;
+
+enum State { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    int state;
+    dim3 tid;
+};
+
+struct Worker {
+    std::vector<Fiber> fibers;
+    char* stacks = nullptr;          // kMaxThreads * kStackBytes, lazily committed
+    ucontext_t sched;
+    int cur = -1;
+    int nthreads = 0;
+    const std::function<void()>* body = nullptr;
+    std::vector<Slot> slots;         // nwaves * 64
+    std::vector<unsigned char> dyn;  // dynamic shared memory
+    Worker() {
+        fibers.resize(kMaxThreads);
+        stacks = (char*)mmap(nullptr, (size_t)kMaxThreads * kStackBytes, PROT_READ | PROT_WRITE,
+                             MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (stacks == MAP_FAILED) { perror("hipsim mmap"); abort(); }
+        slots.resize((kMaxThreads / 64) * 64);
+    }
+    ~Worker() { munmap(stacks, (size_t)kMaxThreads * kStackBytes); }
+};
+
+thread_local Worker* t_worker = nullptr;
+
+void trampoline() {
+    Worker* w = t_worker;
+    (*w->body)();
+    Fiber& f = w->fibers[w->cur];
+    f.state = DONE;
+    swapcontext(&f.ctx, &w->sched);
+}
+
+void yield_with(int st) {
+    Worker* w = t_worker;
+    Fiber& f = w->fibers[w->cur];
+    f.state = st;
+    swapcontext(&f.ctx, &w->sched);
+}
+
+void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
+               const std::function<void()>& body) {
+    const int n = (int)(block.x * block.y * block.z);
+    if (n > kMaxThreads) { fprintf(stderr, "hipsim: block too large (%d)\n", n); abort(); }
+    w->nthreads = n;
+    w->body = &body;
+    if (w->dyn.size() < dyn_bytes + 64) w->dyn.resize(dyn_bytes + 64);
+    t_blockIdx = bid; t_blockDim = block; t_gridDim = grid;
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = w->fibers[i];
+        f.state = RUNNABLE;
+        f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = w->stacks + (size_t)i * kStackBytes;
+        f.ctx.uc_stack.ss_size = kStackBytes;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    const int nwaves = (n + 63) / 64;
+    int live = n;
+    while (live > 0) {
+        bool progressed = false;
+        for (int wv = 0; wv < nwaves; ++wv) {
+            const int lo = wv * 64, hi = std::min(n, lo + 64);
+            for (;;) {
+                bool ran = false;
+                for (int i = lo; i < hi; ++i) {
+                    Fiber& f = w->fibers[i];
+                    if (f.state != RUNNABLE) continue;
+                    w->cur = i;
+                    t_threadIdx = f.tid;
+                    swapcontext(&w->sched, &f.ctx);
+                    ran = true;
+                    if (f.state == DONE) --live;
+                }
+                progressed |= ran;
+                int nl = 0, nw = 0;
+                for (int i = lo; i < hi; ++i) {
+                    if (w->fibers[i].state != DONE) ++nl;
+                    if (w->fibers[i].state == WAIT_WAVE) ++nw;
+                }
+                if (nl > 0 && nw == nl) {
+                    for (int i = lo; i < hi; ++i)
+                        if (w->fibers[i].state == WAIT_WAVE) w->fibers[i].state = RUNNABLE;
+                    progressed = true;
+                    continue;
+                }
+                break;
+            }
+        }
+        if (live > 0) {
+            int nb = 0;
+            for (int i = 0; i < n; ++i) if (w->fibers[i].state == WAIT_BLOCK) ++nb;
+            if (nb == live) {
+                for (int i = 0; i < n; ++i)
+                    if (w->fibers[i].state == WAIT_BLOCK) w->fibers[i].state = RUNNABLE;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            fprintf(stderr, "hipsim: DEADLOCK in block (%u,%u,%u): divergent barrier? live=%d\n", bid.x, bid.y,
+                    bid.z, live);
+            for (int i = 0; i < n; ++i)
+                if (w->fibers[i].state != DONE) fprintf(stderr, "  thread %d state %d\n", i, w->fibers[i].state);
+            abort();
+        }
+    }
+}
+
+// ---- worker pool ---------------------------------------------------------------------------
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    int nworkers = 0;
+    // current job
+    uint64_t job_id = 0;
+    dim3 grid, block;
+    size_t dyn = 0;
+    const std::function<void()>* body = nullptr;
+    std::atomic<long> next{0};
+    long total = 0;
+    int active = 0;
+    bool stop = false;
+
+    void worker_main() {
+        Worker* w = new Worker();
+        t_worker = w;
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || job_id != seen; });
+                if (stop) break;
+                seen = job_id;
+            }
+            for (;;) {
+                long b = next.fetch_add(1);
+                if (b >= total) break;
+                dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y),
+                         (unsigned)(b / ((long)grid.x * grid.y)));
+                run_block(w, grid, block, bid, dyn, *body);
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (--active == 0) cv_done.notify_all();
+            }
+        }
+        delete w;
+    }
+
+    void ensure(int n) {
+        if (nworkers == n) return;
+        shutdown();
+        stop = false;
+        nworkers = n;
+        for (int i = 0; i < n; ++i) threads.emplace_back([this] { worker_main(); });
+    }
+    void shutdown() {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            stop = true;
+            cv_work.notify_all();
+        }
+        for (auto& t : threads) t.join();
+        threads.clear();
+        nworkers = 0;
+    }
+    ~Pool() { shutdown(); }
+};
+
+Pool& pool() {
+    static Pool* p = new Pool();  // leaked on purpose: threads may outlive static destruction order
+    return *p;
+}
+int g_num_workers = 0;
+std::mutex g_launch_mu;
+
+}  // namespace
+
+int num_workers() {
+    if (g_num_workers <= 0) {
+        const char* e = getenv("HIPSIM_WORKERS");
+        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (n <= 0) n = 1;
+        if (n > 16) n = 16;
+        g_num_workers = n;
+    }
+    return g_num_workers;
+}
+void set_num_workers(int n) { g_num_workers = n; }
+
+void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>& body) {
+    std::lock_guard<std::mutex> g(g_launch_mu);
+    Pool& p = pool();
+    p.ensure(num_workers());
+    {
+        std::unique_lock<std::mutex> lk(p.mu);
+        p.grid = grid; p.block = block; p.dyn = dyn_bytes; p.body = &body;
+        p.total = (long)grid.x * grid.y * grid.z;
+        p.next.store(0);
+        p.active = p.nworkers;
+        ++p.job_id;
+        p.cv_work.notify_all();
+        p.cv_done.wait(lk, [&] { return p.active == 0; });
+    }
+}
+
+void sync_block() { yield_with(WAIT_BLOCK); }
+void sync_wave() { yield_with(WAIT_WAVE); }
+int lane_id() { return t_worker->cur & 63; }
+int wave_live_lanes() {
+    Worker* w = t_worker;
+    int lo = (w->cur / 64) * 64, hi = std::min(w->nthreads, lo + 64), n = 0;
+    for (int i = lo; i < hi; ++i) if (w->fibers[i].state != DONE) ++n;
+    return n;
+}
+Slot* wave_slots() { return t_worker->slots.data() + (t_worker->cur / 64) * 64; }
+void* dyn_smem() {
+    uintptr_t p = (uintptr_t)t_worker->dyn.data();
+    return (void*)((p + 63) & ~(uintptr_t)63);
+}
+
+}  // namespace hipsim
+
+// ---- HIP host API stubs --------------------------------------------------------------------
+struct hipsimStream { int dummy; };
+struct hipsimEvent { std::chrono::steady_clock::time_point t; };
+struct hipsimGraph { int dummy; };
+struct hipsimGraphExec { int dummy; };
+
+hipError_t hipMalloc(void** p, size_t n) {
+    void* q = nullptr;
+    if (posix_memalign(&q, 256, n ? ((n + 255) / 256) * 256 : 256) != 0) return hipErrorOutOfMemory;
+    memset(q, 0xCD, n);  // poison: catches reads of uninitialised device memory
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipsimStream(); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipsim error"; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorStreamCaptureUnsupported; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorStreamCaptureUnsupported; }
+hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }

@@ -1,0 +1,161 @@
+// hipsim shadow of moshi_amd/csrc/mmi_device.h — TEST INFRASTRUCTURE ONLY (see hipsim.h).
+// Same vocabulary, implemented on the host: wave shuffles and MFMA go through the per-wave
+// exchange area.  MFMA lane/register maps follow /opt/skills/guides/cdna_hip_programming.md §3.
+#pragma once
+#include "hipsim.h"
+#include <stdint.h>
+#include <cmath>
+#include <algorithm>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define threadIdx hipsim::t_threadIdx
+#define blockIdx hipsim::t_blockIdx
+#define blockDim hipsim::t_blockDim
+#define gridDim hipsim::t_gridDim
+#define __syncthreads() hipsim::sync_block()
+
+#define MMI_WAVE 64
+#define MMI_SHARED static thread_local
+#define MMI_DYN_SHARED(T, name) T* name = reinterpret_cast<T*>(hipsim::dyn_smem())
+#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+
+using std::min;
+using std::max;
+
+inline int mmi_lane() { return hipsim::lane_id(); }
+
+template <class T>
+inline T mmi_shfl(T v, int src) {
+    static_assert(sizeof(T) <= 64, "slot too small");
+    hipsim::Slot* s = hipsim::wave_slots();
+    memcpy(s[hipsim::lane_id()].b, &v, sizeof(T));
+    hipsim::sync_wave();
+    T r;
+    memcpy(&r, s[src & 63].b, sizeof(T));
+    hipsim::sync_wave();
+    return r;
+}
+template <class T>
+inline T mmi_shfl_xor(T v, int mask) { return mmi_shfl(v, hipsim::lane_id() ^ mask); }
+
+namespace hipsim_detail {
+inline float bf(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+struct OpF32 { float a, b; };
+struct OpBF { uint16_t a[8], b[8]; };
+}  // namespace hipsim_detail
+
+inline f32x16 mmi_mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpF32 me{a, b};
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x16 d;
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            OpF32 oa, ob;
+            memcpy(&oa, s[i + 32 * k].b, sizeof(oa));
+            memcpy(&ob, s[j + 32 * k].b, sizeof(ob));
+            acc = fmaf(oa.a, ob.b, acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
+inline f32x4 mmi_mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpF32 me{a, b};
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x4 d;
+    const int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            OpF32 oa, ob;
+            memcpy(&oa, s[i + 16 * k].b, sizeof(oa));
+            memcpy(&ob, s[j + 16 * k].b, sizeof(ob));
+            acc = fmaf(oa.a, ob.b, acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
+inline f32x16 mmi_mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpBF me;
+    memcpy(me.a, &a, 16);
+    memcpy(me.b, &b, 16);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x16 d;
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            OpBF oa, ob;
+            memcpy(&oa, s[i + 32 * (k >> 3)].b, sizeof(oa));
+            memcpy(&ob, s[j + 32 * (k >> 3)].b, sizeof(ob));
+            acc = fmaf(bf(oa.a[k & 7]), bf(ob.b[k & 7]), acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
+inline f32x4 mmi_mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpBF me;
+    memcpy(me.a, &a, 16);
+    memcpy(me.b, &b, 16);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x4 d;
+    const int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            OpBF oa, ob;
+            memcpy(&oa, s[i + 16 * (k >> 3)].b, sizeof(oa));
+            memcpy(&ob, s[j + 16 * (k >> 3)].b, sizeof(ob));
+            acc = fmaf(bf(oa.a[k & 7]), bf(ob.b[k & 7]), acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
+inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
+inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
+inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline unsigned mmi_atomic_add(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
