@@ -1,0 +1,190 @@
+"""Benchmark of the 12.5 Hz full-duplex frame step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload duplex|mimi|lm] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic input: B concurrent sessions each advance by
+one 80 ms frame (Mimi encode -> LMGen.step -> Mimi decode).  `value` = frames/s summed over all ranks; sessions
+shard data-parallel (one process per GPU, no data-path collective), so scaling is weak.
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. the `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm"])
+    ap.add_argument("--batch", type=int, default=32, help="sessions per GPU (BASELINE.json configs[3]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        return rank, local, world, dist
+    torch.cuda.set_device(0)
+    return 0, 0, 1, None
+
+
+def mimi_algorithmic_bytes(cfg, B, frames_so_far):
+    """weights once per step for the whole batch + per-stream KV/ring/IO traffic (fp32 here)."""
+    from moshi_amd.weights import mimi_state_spec
+    used = 0
+    for name, shape, _ in mimi_state_spec(cfg):
+        if "_codebook" in name:
+            continue
+        n = 1
+        for s in shape:
+            n *= s
+        used += n
+    used += 8 * cfg.q_bins * cfg.q_dimension           # the 8 active codebooks
+    w = 4 * used
+    T = cfg.resample_stride
+    Lp = min(T * frames_so_far, cfg.tr_context)
+    kv = 4 * 2 * cfg.tr_num_layers * 2 * cfg.tr_d_model * (Lp + T)
+    rings = 2 * 4 * 24198 if cfg.dimension == 512 else 0
+    io = 4 * 2 * cfg.frame_size + 8 * 8 * 2
+    return w + B * (kv + rings + io)
+
+
+def cpu_baseline_mimi(cfg, sd, seconds=12.0):
+    """`port` baseline: the numpy oracle (oracle/mimi_oracle.py) on the host cores, B=1, bounded sample."""
+    from oracle.mimi_oracle import MimiOracle
+    orc = MimiOracle(sd, cfg, num_codebooks=8)
+    orc.streaming(1)
+    rng = np.random.default_rng(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        x = (0.1 * rng.standard_normal((1, 1, cfg.frame_size))).astype(np.float32)
+        orc.decode(orc.encode(x))
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds or n >= 200:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} Mimi encode+decode frames, B=1, numpy oracle (BLAS threads = host cores)"}
+
+
+def main():
+    args = parse()
+    rank, local, world, dist = dist_setup(args.gpus)
+    dev = torch.device("cuda", local)
+    from moshi_amd import MimiConfig, MimiModel
+    from moshi_amd.weights import random_mimi_state_dict
+
+    workload = args.workload
+    have_lm = (ROOT / "moshi_amd" / "lm.py").exists()
+    if workload == "auto":
+        workload = "duplex" if have_lm else "mimi"
+    B = args.batch
+    mcfg = MimiConfig()
+    msd = random_mimi_state_dict(mcfg, seed=1234, device=dev)
+    mimi = MimiModel(msd, mcfg, device=dev, max_batch=B, num_codebooks=8)
+    mimi.streaming_forever(B)
+    lm_gen = None
+    if workload in ("duplex", "lm"):
+        from bench_lm import make_lm  # noqa
+        lm_gen = make_lm(dev, B, args)
+
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
+    user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)
+
+    def step():
+        nonlocal user_codes
+        if workload == "mimi":
+            codes = mimi.encode(pcm)
+            return mimi.decode(codes)
+        if workload == "lm":
+            return lm_gen.step(user_codes)
+        codes = mimi.encode(pcm)
+        tokens = lm_gen.step(codes)
+        if tokens is None:
+            return None
+        return mimi.decode(tokens[:, 1:].clamp(min=0))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dt = float(t.item())
+    torch.cuda.synchronize(dev)
+
+    ms = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+    out = {
+        "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if workload != "mimi" else "f32", "data": "synthetic",
+        "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
+                                "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
+                                "lm": "Moshi-7B LMGen.step (BASELINE configs[2])"}[workload],
+                   "sessions_per_gpu": B, "parallelism": f"dp{world} (independent sessions, no collective)",
+                   "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model"},
+    }
+    if rank == 0:
+        if workload == "mimi":
+            frames = args.warmup + args.steps
+            nbytes = mimi_algorithmic_bytes(mcfg, B, frames)
+            ach = nbytes / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "whole Mimi step (all kernels)", "algorithmic_bytes": nbytes}
+        elif lm_gen is not None:
+            from bench_lm import roofline_lm
+            out["roofline"] = roofline_lm(lm_gen, step, args, sync)
+        if not args.no_cpu_baseline:
+            cpu_sd = {k: v.cpu() for k, v in msd.items()}
+            base = cpu_baseline_mimi(mcfg, cpu_sd)
+            if workload != "mimi":
+                from bench_lm import cpu_baseline_duplex
+                base = cpu_baseline_duplex(base, args)
+            out["cpu_baseline"] = base
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
