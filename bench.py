@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm"])
     ap.add_argument("--batch", type=int, default=32, help="sessions per GPU (BASELINE.json configs[3]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger", type=int, default=8, help="frames between session starts (SURVEY.md 8d C4)")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
     return ap.parse_args()
 
@@ -134,6 +135,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    staggered = 0
+    if lm_gen is not None:
+        from bench_lm import stagger
+        staggered = stagger(mimi if workload == "duplex" else None, lm_gen, step, B, args.stagger, dev)
     for _ in range(args.warmup):
         step()
     sync()
@@ -160,7 +165,10 @@ def main():
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
                                 "lm": "Moshi-7B LMGen.step (BASELINE configs[2])"}[workload],
                    "sessions_per_gpu": B, "parallelism": f"dp{world} (independent sessions, no collective)",
-                   "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model"},
+                   "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model",
+                   "sampling": "temp .8/.7 top-k 250/25 (LMGen defaults), on-device RNG",
+                   "session_stagger_frames": args.stagger if lm_gen is not None else 0,
+                   "kv_positions_at_end": ([args.stagger * b + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
     }
     if rank == 0:
         if workload == "mimi":

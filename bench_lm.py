@@ -1,0 +1,102 @@
+"""LM half of bench.py: Moshi-7B construction, staggered session starts, dominant-kernel roofline, CPU proxy."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def make_lm(dev, B, args):
+    from moshi_amd.config import LMConfig
+    from moshi_amd.lm import LMGen, LMModel
+    from moshi_amd.weights import random_lm_state_dict
+    cfg = LMConfig()
+    if args.lm_layers:
+        cfg.num_layers = args.lm_layers
+    sd = random_lm_state_dict(cfg, seed=4242, device=dev)       # drawn on the GPU: 7.7 B parameters in bf16
+    lm = LMModel(sd, cfg, device=dev, max_batch=B)
+    del sd
+    torch.cuda.empty_cache()
+    gen = LMGen(lm, use_sampling=True, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25, seed=1234 + int(os.environ.get("RANK", "0")))
+    gen.streaming_forever(B)
+    return gen
+
+
+def stagger(mimi, lm_gen, step_fn, B, frames_apart, dev):
+    """sessions start staggered (row b has run frames_apart*b frames when timing starts)."""
+    if frames_apart <= 0 or B == 1:
+        return 0
+    n = frames_apart * (B - 1)
+    rows = torch.arange(B, device=dev)
+    for f in range(n):
+        mask = rows >= (B - 1 - f // frames_apart)
+        if mimi is not None:
+            mimi.set_exec_mask(mask)
+        lm_gen.set_exec_mask(mask)
+        step_fn()
+    ones = torch.ones(B, dtype=torch.bool, device=dev)
+    if mimi is not None:
+        mimi.set_exec_mask(ones)
+    lm_gen.set_exec_mask(ones)
+    return n
+
+
+def lm_step_algorithmic_bytes(cfg, L_per_row):
+    """weights once per step + per-stream KV read/write (bf16)."""
+    d, dd, h, dh = cfg.dim, cfg.depformer_dim, cfg.ffn_hidden, cfg.depformer_ffn_hidden
+    per_layer = 3 * d * d + d * d + 2 * h * d + d * h
+    dep = cfg.depformer_num_layers * cfg.dep_q * (3 * dd * dd + dd * dd + 2 * dh * dd + dd * dh)
+    nw = cfg.num_layers * per_layer + cfg.text_card * d + dep + cfg.dep_q * dd * d + cfg.dep_q * cfg.card * dd
+    kv = sum(2 * cfg.num_layers * 2 * d * (min(int(L), cfg.context) + 1) for L in L_per_row)
+    return 2 * nw + kv
+
+
+def roofline_lm(lm_gen, step_fn, args, sync):
+    """Dominant kernel = the temporal FFN linear_in GEMM (184.5 MB of weights per launch, 32 launches per step).
+    Timed live with hipEvents on the launch stream over `steps` un-graphed steps (include/moshi_mi.h profile tap)."""
+    lib, h = lm_gen._lib, lm_gen.lm_model._handle
+    sync()
+    lib.check(lib.mmi_lm_profile_begin(h))
+    for _ in range(max(4, min(args.steps, 20))):
+        step_fn()
+    mean_ms, n, nbytes, name = C.c_double(), C.c_int64(), C.c_int64(), C.c_char_p()
+    lib.check(lib.mmi_lm_profile_end(h, C.byref(mean_ms), C.byref(n), C.byref(nbytes), C.byref(name)))
+    ach = nbytes.value / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "kernel": name.value.decode() if name.value else "", "avg_launch_ms": mean_ms.value,
+            "launches_timed": n.value, "algorithmic_bytes_per_launch": nbytes.value}
+
+
+def cpu_baseline_duplex(mimi_base, args):
+    """`port` baseline for the full frame on the host cores: the numpy oracles.  Mimi is timed directly (mimi_base);
+    the LM oracle is timed at reduced depth (1 and 2 temporal layers, full depformer, B=1) and extrapolated linearly to
+    32 layers - a layer-scaled proxy, as BASELINE.md section 3 allows when the full 7B fp32 oracle (30 GB) is too heavy."""
+    from moshi_amd.config import LMConfig
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle
+    times = {}
+    for nl in (1, 2):
+        cfg = LMConfig(num_layers=nl, context=64)
+        o = LMOracle(random_lm_state_dict(cfg, seed=1, device="cpu"), cfg)
+        o.streaming(1)
+        codes = np.zeros((1, 8, 1), np.int64)
+        o.step(codes, use_sampling=False)
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            o.step(codes, use_sampling=False)
+        times[nl] = (time.perf_counter() - t0) / n
+        del o
+    full_layers = 32 if not args.lm_layers else args.lm_layers
+    per_layer = max(times[2] - times[1], 0.0)
+    lm_s = times[1] + (full_layers - 1) * per_layer
+    mimi_s = 1.0 / mimi_base["value"]
+    return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle timed at 1 and 2 "
+                       f"temporal layers + full depformer ({times[1]:.2f} s, {times[2]:.2f} s per step) and extrapolated "
+                       f"linearly to {full_layers} layers = {lm_s:.2f} s/step (layer-scaled proxy)")}

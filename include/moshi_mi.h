@@ -200,6 +200,12 @@ int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* 
                 float* opt_text_logits, float* opt_audio_logits, const float* opt_noise, int32_t batch,
                 int32_t* valid, mmi_stream stream);
 
+/* Teacher forcing for the NEXT step only: tokens i64 [batch, 1 + dep_q] (text, then the dep_q audio codebooks);
+ * entries >= 0 replace the sampled token at that site (the logits taps are still produced), entries < 0 keep
+ * sampling.  Covers LMGen.step's `depformer_replace_tokens` argument (lm.py:751-755) and lets the parity tests
+ * replay the reference's token history exactly. */
+int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream);
+
 /* Dominant-kernel timing tap for bench.py's roofline object: when enabled, steps run un-graphed and
  * every launch of the widest weight-streaming GEMM is bracketed by hipEvents on `stream`. */
 int mmi_lm_profile_begin(mmi_lm* lm);

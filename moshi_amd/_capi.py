@@ -78,6 +78,7 @@ SIGNATURES = {
     "mmi_lm_set_exec_mask": (C.c_int, [_P, _P, _P]),
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),
     "mmi_lm_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "mmi_lm_force_next_tokens": (C.c_int, [_P, _P, _P]),
     "mmi_lm_profile_begin": (C.c_int, [_P]),
     "mmi_lm_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_char_p)]),

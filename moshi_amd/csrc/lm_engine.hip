@@ -1,11 +1,612 @@
-// placeholder until the LM engine lands (next milestone): the ABI symbols exist and fail loudly.
-#include "mmi_common.h"
-extern "C" int mmi_lm_create(const mmi_lm_cfg*, const mmi_tensor_desc*, int32_t, int32_t, mmi_lm**) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" void mmi_lm_destroy(mmi_lm*) {}
-extern "C" int mmi_lm_streaming_start(mmi_lm*, int32_t, const mmi_sampling*, mmi_stream) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_streaming_stop(mmi_lm*) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_set_exec_mask(mmi_lm*, const uint8_t*, mmi_stream) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_reset(mmi_lm*, const uint8_t*, mmi_stream) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_step(mmi_lm*, const int64_t*, int32_t, int64_t*, float*, float*, const float*, int32_t, int32_t*, mmi_stream) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_profile_begin(mmi_lm*) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
-extern "C" int mmi_lm_profile_end(mmi_lm*, double*, int64_t*, int64_t*, const char**) { return mmi_fail(MMI_ERR_UNSUPPORTED, "LM engine not built yet"); }
+// Moshi LM engine behind the C ABI (include/moshi_mi.h): LMGen.step (reference: moshi/moshi/models/lm.py:668-850)
+// = delay-ring bookkeeping + LMModel.forward_text (temporal transformer, lm.py:379-408) + text sampling +
+// depformer_step (8 sequential depth-transformer micro-steps, lm.py:809-850, 450-493) as one fixed launch list over
+// the kernels of lm_kernels.h, captured into a single hipGraph.
+#include "lm_kernels.h"
+#include "mmi_graph.h"
+
+#include <math.h>
+
+namespace {
+
+struct GemmW {              // one packed nn.Linear
+    u32x4* wp = nullptr;
+    int N = 0, K = 0, TN = 32, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, rows interleaved
+    size_t bytes = 0;
+};
+
+struct LayerW {
+    GemmW in_proj, out_proj, ffn_in, ffn_out;
+    uint16_t *n1 = nullptr, *n2 = nullptr;
+};
+
+struct DepLayerW {
+    std::vector<GemmW> in_proj, out_proj, ffn_in, ffn_out;   // per step
+    uint16_t *n1 = nullptr, *n2 = nullptr;                   // shared by the steps
+};
+
+struct EvPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct mmi_lm {
+    mmi_lm_cfg cfg;
+    int max_batch = 0;
+    int NC = 0, CT = 0, max_delay = 0;
+    MmiArena wts;
+    // weights
+    uint16_t* emb = nullptr;        // [n_q][card+1][dim]
+    uint16_t* text_emb = nullptr;   // [text_card+1][dim]
+    std::vector<LayerW> layers;
+    uint16_t* out_norm = nullptr;
+    GemmW text_linear;
+    std::vector<GemmW> dep_in, dep_lin;
+    std::vector<uint16_t*> dep_emb; // [0] = depformer_text_emb, [k>=1] = depformer_emb[k-1]
+    std::vector<DepLayerW> dep_layers;
+    int* delays_dev = nullptr;
+    size_t weight_bytes = 0;
+    // streaming state
+    bool streaming = false;
+    int batch = 0;
+    mmi_sampling samp;
+    int kmax = 0;
+    MmiArena st;
+    uint8_t* exec = nullptr;
+    long* offsets = nullptr;
+    int* cache = nullptr;
+    int* user_i32 = nullptr;
+    int* tokens = nullptr;          // [B][NC] model input
+    int* text_tok = nullptr;        // [B]
+    int* audio_tok = nullptr;       // [B][dep_q]
+    int* out_i32 = nullptr;         // [B][dep_q+1]
+    uint16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *hb = nullptr;
+    uint16_t *tout = nullptr, *text_logits = nullptr;
+    uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
+    float *opart = nullptr, *ml = nullptr;
+    uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
+    uint16_t *dkc = nullptr, *dvc = nullptr;        // [dep_layers][B][Hd][dep_q][Dhd]
+    float* noise = nullptr;                         // [B][1+dep_q][kmax]
+    int* use_noise = nullptr;
+    int* forced = nullptr;                          // [B][1+dep_q]
+    int* use_forced = nullptr;
+    bool forced_armed = false;
+    unsigned long long* rng = nullptr;
+    long offset_cpu = 0;
+    MmiProgram prog;
+    hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
+    // profiling tap
+    bool profiling = false;
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    hipStream_t prof_stream = nullptr;
+    long prof_bytes = 0;
+};
+
+namespace {
+
+int need(const MmiWeights& W, const std::string& name, int ndim, const mmi_tensor_desc** out) {
+    const mmi_tensor_desc* d = W.find(name);
+    if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
+    if (d->dtype != MMI_BF16) return mmi_fail(MMI_ERR_UNSUPPORTED, "LM weights must be bf16: " + name);
+    if (d->ndim != ndim) return mmi_fail(MMI_ERR_SHAPE, "unexpected rank for " + name);
+    *out = d;
+    return MMI_OK;
+}
+
+int pick_tn(int n_rows) { return (n_rows / 32) >= 512 ? 32 : 16; }
+
+// nn.Linear weight [N][K] -> packed; gate_hidden > 0: [2*hidden][K] gate|value matrix
+int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g) {
+    const mmi_tensor_desc* d;
+    int rc = need(W, name, 2, &d);
+    if (rc) return rc;
+    if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
+    if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
+    g->K = K;
+    g->gate = gate_hidden > 0 ? 1 : 0;
+    g->N = gate_hidden > 0 ? gate_hidden : N;
+    g->TN = pick_tn(gate_hidden > 0 ? 2 * gate_hidden : N);
+    const int rows_per_tile = gate_hidden > 0 ? g->TN / 2 : g->TN;
+    g->NT = mmi_cdiv(g->N, rows_per_tile);
+    g->KSTEPS = mmi_cdiv(K, g->TN == 32 ? 16 : 32);
+    size_t n = (size_t)g->NT * g->KSTEPS * 512;
+    uint16_t* p = nullptr;
+    MMI_HIP_CHECK(lm->wts.alloc(&p, n));
+    g->wp = reinterpret_cast<u32x4*>(p);
+    g->bytes = n * sizeof(uint16_t);
+    lm->weight_bytes += g->bytes;
+    MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
+               g->TN, g->NT, g->KSTEPS, gate_hidden);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+int load_copy(mmi_lm* lm, const MmiWeights& W, const std::string& name, int ndim, size_t n, uint16_t** out, uint16_t* into = nullptr) {
+    const mmi_tensor_desc* d;
+    int rc = need(W, name, ndim, &d);
+    if (rc) return rc;
+    size_t have = 1;
+    for (int i = 0; i < d->ndim; ++i) have *= (size_t)d->shape[i];
+    if (have != n) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
+    uint16_t* dst = into;
+    if (!dst) MMI_HIP_CHECK(lm->wts.alloc(&dst, n));
+    MMI_HIP_CHECK(hipMemcpy(dst, d->data, n * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+    if (out) *out = dst;
+    return MMI_OK;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+template <int TN, int WAVES>
+int launch_gemm_mt(hipStream_t s, const GemmW& g, const GemmArgs& a, int mt) {
+    switch (mt) {
+        case 1: MMI_LAUNCH((k_gemm_bf16<TN, 1, WAVES>), g.NT, WAVES * 64, 0, s, a); break;
+        case 2: MMI_LAUNCH((k_gemm_bf16<TN, 2, WAVES>), g.NT, WAVES * 64, 0, s, a); break;
+        case 4:
+            if constexpr (TN == 16) { MMI_LAUNCH((k_gemm_bf16<TN, 4, WAVES>), g.NT, WAVES * 64, 0, s, a); break; }
+            return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the 32-row GEMM tile");
+        default: return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
+    }
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
+    a.wp = g.wp; a.N = g.N; a.K = g.K; a.KSTEPS = g.KSTEPS;
+    const int bt = g.TN;
+    int mt = mmi_cdiv(a.B, bt);
+    if (mt == 3) mt = 4;
+    const int waves = g.KSTEPS >= 64 ? 8 : 4;
+    EvPair* ev = nullptr;
+    if (lm->profiling && is_dominant) {
+        if (lm->ev_used == lm->ev_pool.size()) {
+            EvPair p;
+            MMI_HIP_CHECK(hipEventCreate(&p.a));
+            MMI_HIP_CHECK(hipEventCreate(&p.b));
+            lm->ev_pool.push_back(p);
+        }
+        ev = &lm->ev_pool[lm->ev_used++];
+        lm->prof_stream = s;
+        MMI_HIP_CHECK(hipEventRecord(ev->a, s));
+    }
+    int rc;
+    if (g.TN == 32) rc = waves == 8 ? launch_gemm_mt<32, 8>(s, g, a, mt) : launch_gemm_mt<32, 4>(s, g, a, mt);
+    else rc = waves == 8 ? launch_gemm_mt<16, 8>(s, g, a, mt) : launch_gemm_mt<16, 4>(s, g, a, mt);
+    if (rc) return rc;
+    if (ev) MMI_HIP_CHECK(hipEventRecord(ev->b, s));
+    return MMI_OK;
+}
+
+void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_ld, int epi, const uint16_t* resid,
+              const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0, bool dominant = false) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.out = out; a.out_ld = out_ld; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
+    a.tok_stride = tok_stride; a.B = lm->batch;
+    GemmW gw = g;
+    lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); });
+}
+
+void add_rmsnorm(mmi_lm* lm, const uint16_t* x, const uint16_t* alpha, uint16_t* y, int D) {
+    const int B = lm->batch;
+    lm->prog.add([=](hipStream_t s) {
+        MMI_LAUNCH(k_rmsnorm_bf16, B, 256, 0, s, x, alpha, y, D, 1e-8f);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+}
+
+void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride) {
+    SampleArgs sa;
+    sa.logits = logits; sa.ld = ld; sa.V = V;
+    sa.k = text ? lm->samp.top_k_text : lm->samp.top_k;
+    sa.temp = text ? lm->samp.temp_text : lm->samp.temp;
+    sa.use_sampling = lm->samp.use_sampling;
+    if (sa.k <= 0) sa.k = V;   // top_k == 0: plain multinomial over the whole vocabulary is not implemented -> see below
+    sa.noise = lm->noise + (size_t)site * lm->kmax;
+    sa.noise_ld = (1 + lm->cfg.dep_q) * lm->kmax;
+    sa.use_noise = lm->use_noise; sa.rng = lm->rng; sa.site = site; sa.out = out; sa.out_stride = out_stride;
+    sa.B = lm->batch;
+    sa.forced = lm->forced + site; sa.forced_stride = 1 + lm->cfg.dep_q; sa.use_forced = lm->use_forced;
+    const int B = lm->batch;
+    const bool big = V > 4096;
+    lm->prog.add([=](hipStream_t s) {
+        if (big) MMI_LAUNCH((k_sample<1024>), B, 1024, 0, s, sa);
+        else MMI_LAUNCH((k_sample<256>), B, 256, 0, s, sa);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+}
+
+int launch_attn_split(hipStream_t s, const LmAttnArgs& a) {
+    dim3 grid(a.B * a.H, a.NS);
+    switch (a.Dh) {
+        case 128: MMI_LAUNCH((k_lm_attn_split<128>), grid, 256, 0, s, a); break;
+        case 64: MMI_LAUNCH((k_lm_attn_split<64>), grid, 256, 0, s, a); break;
+        case 32: MMI_LAUNCH((k_lm_attn_split<32>), grid, 256, 0, s, a); break;
+        default: return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be 32, 64 or 128");
+    }
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+TokArgs tok_args(mmi_lm* lm) {
+    TokArgs t;
+    t.cache = lm->cache; t.offsets = lm->offsets; t.exec = lm->exec; t.delays = lm->delays_dev;
+    t.B = lm->batch; t.NC = lm->NC; t.CT = lm->CT; t.dep_q = lm->cfg.dep_q; t.max_delay = lm->max_delay;
+    t.card = lm->cfg.card; t.text_card = lm->cfg.text_card;
+    return t;
+}
+
+int build_program(mmi_lm* lm) {
+    const mmi_lm_cfg& c = lm->cfg;
+    const int B = lm->batch, d = c.dim, H = c.num_heads, Dh = d / H;
+    const int dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
+    const int n_user = c.n_q - c.dep_q;
+    MmiProgram& P = lm->prog;
+    // ---- token ring in, embeddings
+    {
+        TokArgs t = tok_args(lm);
+        const int* user = lm->user_i32; int* tokens = lm->tokens;
+        const uint16_t *emb = lm->emb, *temb = lm->text_emb; uint16_t* x = lm->x; const int NC = lm->NC, card1 = c.card + 1;
+        P.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_lm_prepare, mmi_cdiv(B * NC, 128), 128, 0, s, t, user, n_user, tokens);
+            MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+    // ---- temporal transformer
+    const int NS = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    const size_t kv_layer = (size_t)B * H * c.context * Dh;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerW& L = lm->layers[l];
+        add_rmsnorm(lm, lm->x, L.n1, lm->xn, d);
+        add_gemm(lm, L.in_proj, lm->xn, lm->qkv, 3 * d, MMI_EPI_STORE, nullptr);
+        LmAttnArgs a;
+        a.qkv = lm->qkv; a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
+        a.offsets = lm->offsets; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
+        a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
+        P.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_lm_rope_kv, B * H, 64, 0, s, a);
+            int rc = launch_attn_split(s, a);
+            if (rc) return rc;
+            MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, a);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+        add_gemm(lm, L.out_proj, lm->att, lm->x, d, MMI_EPI_RESID, lm->x);
+        add_rmsnorm(lm, lm->x, L.n2, lm->xn, d);
+        add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
+        add_gemm(lm, L.ffn_out, lm->hb, lm->x, d, MMI_EPI_RESID, lm->x);
+    }
+    add_rmsnorm(lm, lm->x, lm->out_norm, lm->tout, d);
+    add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, MMI_EPI_STORE, nullptr);
+    add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1);
+    // ---- depformer: dep_q sequential micro-steps
+    const size_t dkv_layer = (size_t)B * Hd * c.dep_q * Dhd;
+    for (int k = 0; k < c.dep_q; ++k) {
+        const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
+        const int prev_stride = k == 0 ? 1 : c.dep_q;
+        add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
+        for (int l = 0; l < c.depformer_num_layers; ++l) {
+            const DepLayerW& L = lm->dep_layers[l];
+            add_rmsnorm(lm, lm->dx, L.n1, lm->dxn, dd);
+            add_gemm(lm, L.in_proj[k], lm->dxn, lm->dqkv, 3 * dd, MMI_EPI_STORE, nullptr);
+            DepAttnArgs da;
+            da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
+            da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
+            P.add([=](hipStream_t s) {
+                MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            });
+            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, MMI_EPI_RESID, lm->dx);
+            add_rmsnorm(lm, lm->dx, L.n2, lm->dxn, dd);
+            add_gemm(lm, L.ffn_in[k], lm->dxn, lm->dhb, c.depformer_ffn_hidden, MMI_EPI_GATE, nullptr);
+            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, MMI_EPI_RESID, lm->dx);
+        }
+        uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
+        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, MMI_EPI_STORE, nullptr);
+        add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q);
+    }
+    // ---- token ring out
+    {
+        TokArgs t = tok_args(lm);
+        const int *tt = lm->text_tok, *at = lm->audio_tok; int* out = lm->out_i32; unsigned long long* rng = lm->rng;
+        P.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_lm_commit, mmi_cdiv(B, 64), 64, 0, s, t, tt, at, out, rng);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
+    return MMI_OK;
+}
+
+int check_cfg(const mmi_lm_cfg& c) {
+    if (c.dim % c.num_heads || c.depformer_dim % c.depformer_num_heads) return mmi_fail(MMI_ERR_UNSUPPORTED, "dim % heads != 0");
+    const int Dh = c.dim / c.num_heads, Dhd = c.depformer_dim / c.depformer_num_heads;
+    if (Dh != 32 && Dh != 64 && Dh != 128) return mmi_fail(MMI_ERR_UNSUPPORTED, "temporal head dim must be 32/64/128");
+    if (Dhd > 64 || Dhd < 1) return mmi_fail(MMI_ERR_UNSUPPORTED, "depformer head dim must be <= 64");
+    if (c.dep_q < 1 || c.dep_q > 16 || c.n_q < c.dep_q || c.n_q + 1 > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "bad n_q / dep_q");
+    if (c.dim % 8 || c.depformer_dim % 8 || c.ffn_hidden % 8 || c.depformer_ffn_hidden % 8)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "feature sizes must be multiples of 8");
+    return MMI_OK;
+}
+
+}  // namespace
+
+// ===============================================================================================
+// C ABI
+// ===============================================================================================
+extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights, int32_t max_batch,
+                             mmi_lm** out) {
+    if (!cfg || !weights || !out || max_batch <= 0) return mmi_fail(MMI_ERR_INVALID, "mmi_lm_create: bad argument");
+    if (max_batch > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "max_batch > 64 sessions per GPU is not supported yet");
+    int rc = check_cfg(*cfg);
+    if (rc) return rc;
+    mmi_lm* lm = new mmi_lm();
+    lm->cfg = *cfg;
+    lm->max_batch = max_batch;
+    lm->use_graph = mmi_graphs_enabled();
+    const mmi_lm_cfg& c = lm->cfg;
+    lm->NC = c.n_q + 1;
+    lm->max_delay = 0;
+    for (int i = 0; i < lm->NC; ++i) lm->max_delay = c.delays[i] > lm->max_delay ? c.delays[i] : lm->max_delay;
+    lm->CT = lm->max_delay + 2;
+    MmiWeights W{weights, n_weights};
+    auto fail = [&](int code) { mmi_lm_destroy(lm); return code; };
+    const int d = c.dim, dd = c.depformer_dim;
+    // embeddings (lm.py:135-139, 189-196): row gathers, kept as stored
+    {
+        const size_t per = (size_t)(c.card + 1) * d;
+        if (hipSuccess != lm->wts.alloc(&lm->emb, per * c.n_q)) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory"));
+        for (int i = 0; i < c.n_q; ++i)
+            if ((rc = load_copy(lm, W, "emb." + std::to_string(i) + ".weight", 2, per, nullptr, lm->emb + per * i))) return fail(rc);
+        if ((rc = load_copy(lm, W, "text_emb.weight", 2, (size_t)(c.text_card + 1) * d, &lm->text_emb))) return fail(rc);
+        lm->dep_emb.resize(c.dep_q);
+        if ((rc = load_copy(lm, W, "depformer_text_emb.weight", 2, (size_t)(c.text_card + 1) * dd, &lm->dep_emb[0]))) return fail(rc);
+        for (int k = 1; k < c.dep_q; ++k)
+            if ((rc = load_copy(lm, W, "depformer_emb." + std::to_string(k - 1) + ".weight", 2, (size_t)(c.card + 1) * dd, &lm->dep_emb[k]))) return fail(rc);
+    }
+    // temporal transformer (lm.py:146-158)
+    lm->layers.resize(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerW& L = lm->layers[l];
+        std::string p = "transformer.layers." + std::to_string(l);
+        if ((rc = load_linear(lm, W, p + ".self_attn.in_projs.0.weight", 3 * d, d, 0, &L.in_proj))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".self_attn.out_projs.0.weight", d, d, 0, &L.out_proj))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".gating.linear_in.weight", 2 * c.ffn_hidden, d, c.ffn_hidden, &L.ffn_in))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".gating.linear_out.weight", d, c.ffn_hidden, 0, &L.ffn_out))) return fail(rc);
+        if ((rc = load_copy(lm, W, p + ".norm1.alpha", 3, d, &L.n1))) return fail(rc);
+        if ((rc = load_copy(lm, W, p + ".norm2.alpha", 3, d, &L.n2))) return fail(rc);
+    }
+    if ((rc = load_copy(lm, W, "out_norm.alpha", 3, d, &lm->out_norm))) return fail(rc);
+    if ((rc = load_linear(lm, W, "text_linear.weight", c.text_card_out, d, 0, &lm->text_linear))) return fail(rc);
+    // depformer (lm.py:179-232; per-step weights transformer.py:291-318)
+    lm->dep_in.resize(c.dep_q);
+    lm->dep_lin.resize(c.dep_q);
+    for (int k = 0; k < c.dep_q; ++k) {
+        if ((rc = load_linear(lm, W, "depformer_in." + std::to_string(k) + ".weight", dd, d, 0, &lm->dep_in[k]))) return fail(rc);
+        if ((rc = load_linear(lm, W, "linears." + std::to_string(k) + ".weight", c.card, dd, 0, &lm->dep_lin[k]))) return fail(rc);
+    }
+    lm->dep_layers.resize(c.depformer_num_layers);
+    for (int l = 0; l < c.depformer_num_layers; ++l) {
+        DepLayerW& L = lm->dep_layers[l];
+        std::string p = "depformer.layers." + std::to_string(l);
+        L.in_proj.resize(c.dep_q); L.out_proj.resize(c.dep_q); L.ffn_in.resize(c.dep_q); L.ffn_out.resize(c.dep_q);
+        for (int k = 0; k < c.dep_q; ++k) {
+            std::string ks = std::to_string(k);
+            if ((rc = load_linear(lm, W, p + ".self_attn.in_projs." + ks + ".weight", 3 * dd, dd, 0, &L.in_proj[k]))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".self_attn.out_projs." + ks + ".weight", dd, dd, 0, &L.out_proj[k]))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_in.weight", 2 * c.depformer_ffn_hidden, dd, c.depformer_ffn_hidden, &L.ffn_in[k]))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_out.weight", dd, c.depformer_ffn_hidden, 0, &L.ffn_out[k]))) return fail(rc);
+        }
+        if ((rc = load_copy(lm, W, p + ".norm1.alpha", 3, dd, &L.n1))) return fail(rc);
+        if ((rc = load_copy(lm, W, p + ".norm2.alpha", 3, dd, &L.n2))) return fail(rc);
+    }
+    if (hipSuccess != lm->wts.alloc(&lm->delays_dev, (size_t)lm->NC)) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory"));
+    if (hipSuccess != hipMemcpy(lm->delays_dev, c.delays, lm->NC * sizeof(int), hipMemcpyHostToDevice)) return fail(mmi_fail(MMI_ERR_HIP, "memcpy"));
+    if (hipDeviceSynchronize() != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "weight packing failed"));
+    if (lm->use_graph && hipStreamCreate(&lm->cap_stream) != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "hipStreamCreate failed"));
+    *out = lm;
+    return MMI_OK;
+}
+
+extern "C" void mmi_lm_destroy(mmi_lm* lm) {
+    if (!lm) return;
+    mmi_lm_streaming_stop(lm);
+    lm->wts.release();
+    for (auto& e : lm->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
+    delete lm;
+}
+
+extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream) {
+    if (!lm || !sampling) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (lm->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");
+    if (batch <= 0 || batch > lm->max_batch) return mmi_fail(MMI_ERR_SHAPE, "batch exceeds max_batch");
+    if (sampling->top_k > 256 || sampling->top_k_text > 256) return mmi_fail(MMI_ERR_UNSUPPORTED, "top_k > 256");
+    if (sampling->use_sampling && (sampling->top_k <= 0 || sampling->top_k_text <= 0))
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "sampling without top-k is not implemented");
+    hipStream_t s = (hipStream_t)stream;
+    const mmi_lm_cfg& c = lm->cfg;
+    lm->batch = batch;
+    lm->samp = *sampling;
+    lm->kmax = sampling->top_k > sampling->top_k_text ? sampling->top_k : sampling->top_k_text;
+    if (lm->kmax < 1) lm->kmax = 1;
+    lm->offset_cpu = 0;
+    const int B = batch, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
+    const int NS = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    auto fail = [&](int code) { lm->streaming = true; mmi_lm_streaming_stop(lm); return code; };
+    MmiArena& A = lm->st;
+    const size_t kvn = (size_t)c.num_layers * B * H * c.context * Dh;
+    const size_t dkvn = (size_t)c.depformer_num_layers * B * Hd * c.dep_q * Dhd;
+    bool ok = true;
+    ok &= hipSuccess == A.alloc(&lm->exec, (size_t)B);
+    ok &= hipSuccess == A.alloc(&lm->offsets, (size_t)B);
+    ok &= hipSuccess == A.alloc(&lm->cache, (size_t)B * lm->NC * lm->CT);
+    ok &= hipSuccess == A.alloc(&lm->user_i32, (size_t)B * (c.n_q - c.dep_q));
+    ok &= hipSuccess == A.alloc(&lm->tokens, (size_t)B * lm->NC);
+    ok &= hipSuccess == A.alloc(&lm->text_tok, (size_t)B);
+    ok &= hipSuccess == A.alloc(&lm->audio_tok, (size_t)B * c.dep_q);
+    ok &= hipSuccess == A.alloc(&lm->out_i32, (size_t)B * (c.dep_q + 1));
+    ok &= hipSuccess == A.alloc(&lm->x, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->xn, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->qkv, (size_t)B * 3 * d);
+    ok &= hipSuccess == A.alloc(&lm->qrot, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->att, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->hb, (size_t)B * c.ffn_hidden);
+    ok &= hipSuccess == A.alloc(&lm->tout, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->text_logits, (size_t)B * c.text_card_out);
+    ok &= hipSuccess == A.alloc(&lm->kc, kvn);
+    ok &= hipSuccess == A.alloc(&lm->vc, kvn);
+    ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
+    ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
+    ok &= hipSuccess == A.alloc(&lm->dx, (size_t)B * dd);
+    ok &= hipSuccess == A.alloc(&lm->dxn, (size_t)B * dd);
+    ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);
+    ok &= hipSuccess == A.alloc(&lm->datt, (size_t)B * dd);
+    ok &= hipSuccess == A.alloc(&lm->dhb, (size_t)B * c.depformer_ffn_hidden);
+    ok &= hipSuccess == A.alloc(&lm->dlogits, (size_t)c.dep_q * B * c.card);
+    ok &= hipSuccess == A.alloc(&lm->dkc, dkvn);
+    ok &= hipSuccess == A.alloc(&lm->dvc, dkvn);
+    ok &= hipSuccess == A.alloc(&lm->noise, (size_t)B * (1 + c.dep_q) * lm->kmax);
+    ok &= hipSuccess == A.alloc(&lm->use_noise, (size_t)1);
+    ok &= hipSuccess == A.alloc(&lm->forced, (size_t)B * (1 + c.dep_q));
+    ok &= hipSuccess == A.alloc(&lm->use_forced, (size_t)1);
+    ok &= hipSuccess == A.alloc(&lm->rng, (size_t)2);
+    if (!ok) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (LM streaming state)"));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->exec, 1, B, s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->offsets, 0, B * sizeof(long), s));
+    MMI_LAUNCH(k_fill_i32, mmi_cdiv(B * lm->NC * lm->CT, 256), 256, 0, s, lm->cache, -2, (long)B * lm->NC * lm->CT);   // lm.py:608-613
+    MMI_HIP_CHECK(hipMemsetAsync(lm->kc, 0, kvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->vc, 0, kvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->dkc, 0, dkvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->dvc, 0, dkvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
+    lm->forced_armed = false;
+    MMI_HIP_CHECK(hipMemsetAsync(lm->text_tok, 0, B * sizeof(int), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->audio_tok, 0, (size_t)B * c.dep_q * sizeof(int), s));
+    unsigned long long r0[2] = {sampling->seed, 0ull};
+    MMI_HIP_CHECK(hipMemcpyAsync(lm->rng, r0, sizeof(r0), hipMemcpyHostToDevice, s));
+    MMI_CHECK_LAUNCH();
+    int rc = build_program(lm);
+    if (rc) return fail(rc);
+    MMI_HIP_CHECK(hipStreamSynchronize(s));
+    lm->streaming = true;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_streaming_stop(mmi_lm* lm) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!lm->streaming) return MMI_OK;
+    hipDeviceSynchronize();
+    lm->prog.clear();
+    lm->st.release();
+    lm->streaming = false;
+    lm->batch = 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) {
+    if (!lm || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    MMI_HIP_CHECK(hipMemcpyAsync(lm->exec, mask, lm->batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    TokArgs t = tok_args(lm);
+    MMI_LAUNCH(k_lm_reset, mmi_cdiv(lm->batch, 64), 64, 0, (hipStream_t)stream, t, mask, lm->exec);
+    MMI_CHECK_LAUNCH();
+    lm->offset_cpu = 0;   // lm.py:540: any reset, even partial, zeroes the host-side step counter
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* out_tokens, float* opt_text_logits,
+                           float* opt_audio_logits, const float* opt_noise, int32_t batch, int32_t* valid, mmi_stream stream) {
+    if (!lm || !user_codes || !out_tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming)
+        return mmi_fail(MMI_ERR_STATE, "You should wrap those calls with a `with lm_gen.streaming(): ...`.");   // lm.py:673-676
+    if (batch != lm->batch) return mmi_fail(MMI_ERR_SHAPE, "Got a different batch size than the streaming batch");   // lm.py:681
+    const mmi_lm_cfg& c = lm->cfg;
+    const int need_user = c.n_q - c.dep_q;
+    if (n_user < need_user) return mmi_fail(MMI_ERR_SHAPE, "not enough user tokens");   // lm.py:683-686
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch;
+    MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(B * need_user, 256), 256, 0, s, (const long*)user_codes, (long)n_user, lm->user_i32, B, need_user);
+    if (opt_noise) {
+        MMI_HIP_CHECK(hipMemcpyAsync(lm->noise, opt_noise, (size_t)B * (1 + c.dep_q) * lm->kmax * sizeof(float), hipMemcpyDeviceToDevice, s));
+        MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 1, 1, s));
+    } else {
+        MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
+    }
+    MMI_CHECK_LAUNCH();
+    int rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
+    if (rc) return rc;
+    MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(B * (c.dep_q + 1), 256), 256, 0, s, (const int*)lm->out_i32, (long*)out_tokens, B * (c.dep_q + 1));
+    if (opt_text_logits)
+        MMI_LAUNCH(k_bf16_to_f32, (int)mmi_cdiv64((int64_t)B * c.text_card_out, 256), 256, 0, s, (const uint16_t*)lm->text_logits, opt_text_logits, (long)B * c.text_card_out);
+    if (opt_audio_logits) {
+        // internal layout [dep_q][B][card] -> caller's [B][dep_q][card]
+        for (int k = 0; k < c.dep_q; ++k)
+            for (int b = 0; b < B; ++b)
+                MMI_LAUNCH(k_bf16_to_f32, mmi_cdiv(c.card, 256), 256, 0, s, (const uint16_t*)(lm->dlogits + ((size_t)k * B + b) * c.card),
+                           opt_audio_logits + ((size_t)b * c.dep_q + k) * c.card, (long)c.card);
+    }
+    MMI_CHECK_LAUNCH();
+    if (lm->forced_armed) {   // forcing applies to one step only
+        MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
+        lm->forced_armed = false;
+    }
+    lm->offset_cpu += 1;
+    if (valid) *valid = lm->offset_cpu > lm->max_delay ? 1 : 0;   // lm.py:774-776
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream) {
+    if (!lm || !tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = lm->batch * (1 + lm->cfg.dep_q);
+    MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(n, 256), 256, 0, s, (const long*)tokens, (long)(1 + lm->cfg.dep_q), lm->forced, lm->batch, 1 + lm->cfg.dep_q);
+    MMI_CHECK_LAUNCH();
+    MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 1, 1, s));
+    lm->forced_armed = true;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    lm->profiling = true;
+    lm->ev_used = 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,
+                                  const char** kernel_name) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (!lm->profiling) return mmi_fail(MMI_ERR_STATE, "profiling was not started");
+    lm->profiling = false;
+    if (lm->prof_stream || lm->ev_used) MMI_HIP_CHECK(hipStreamSynchronize(lm->prof_stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < lm->ev_used; ++i) {
+        float ms = 0.f;
+        MMI_HIP_CHECK(hipEventElapsedTime(&ms, lm->ev_pool[i].a, lm->ev_pool[i].b));
+        tot += ms;
+    }
+    if (mean_ms) *mean_ms = lm->ev_used ? tot / (double)lm->ev_used : 0.0;
+    if (n_launches) *n_launches = (int64_t)lm->ev_used;
+    if (bytes_per_launch) {
+        const mmi_lm_cfg& c = lm->cfg;
+        // algorithmic bytes of one FFN linear_in launch: packed weights + activations in + gated activations out
+        *bytes_per_launch = (int64_t)2 * c.ffn_hidden * c.dim * 2 + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
+    }
+    if (kernel_name) *kernel_name = "k_gemm_bf16 (temporal FFN linear_in + SiLU gate)";
+    lm->ev_used = 0;
+    return MMI_OK;
+}

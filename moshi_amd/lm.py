@@ -1,0 +1,280 @@
+"""`LMModel` / `LMGen` - host-side mirror of the reference's Moshi LM generation API on the HIP engine.
+
+Same constructor arguments, method names, shapes, dtypes, `None`-during-delay behaviour and exception types as
+the reference (moshi/moshi/models/lm.py:49-320 `LMModel` attributes, :556-850 `LMGen`), so that callers such as
+`server.py:59-72,144` or `run_inference.py:89-90,160-171` can switch.  All arithmetic happens in libmoshi_mi.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from contextlib import contextmanager
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _capi
+from .config import LMConfig
+
+
+def _lm_cfg_struct(cfg: LMConfig) -> _capi.LMCfg:
+    s = _capi.LMCfg()
+    s.dim = cfg.dim
+    s.num_heads = cfg.num_heads
+    s.num_layers = cfg.num_layers
+    s.ffn_hidden = cfg.ffn_hidden
+    s.context = cfg.context
+    s.max_period = cfg.max_period
+    s.n_q = cfg.n_q
+    s.dep_q = cfg.dep_q
+    s.card = cfg.card
+    s.text_card = cfg.text_card
+    s.text_card_out = cfg.text_card
+    s.depformer_dim = cfg.depformer_dim
+    s.depformer_num_heads = cfg.depformer_num_heads
+    s.depformer_num_layers = cfg.depformer_num_layers
+    s.depformer_ffn_hidden = cfg.depformer_ffn_hidden
+    assert len(cfg.delays) == cfg.n_q + 1, f"expected {cfg.n_q + 1} delays, got {len(cfg.delays)}."
+    for i, d in enumerate(cfg.delays):
+        s.delays[i] = d
+    s.existing_text_padding_id = cfg.existing_text_padding_id
+    return s
+
+
+class LMModel:
+    """Weights + architecture of the Moshi LM on the engine (reference: lm.py:49-320).
+
+    Args:
+        state_dict: bf16 tensors named as in the reference checkpoints.
+        config: architecture hyper-parameters (defaults = Moshi-7B, loaders.py:90-119).
+        device: a ROCm `cuda` device for the product library.
+        max_batch: largest number of concurrent sessions `LMGen.streaming` will be asked for.
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[LMConfig] = None,
+                 device: torch.device | str = "cuda", max_batch: int = 32, lib: Optional[_capi.Lib] = None):
+        self.config = config or LMConfig()
+        self.device = torch.device(device)
+        if lib is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("moshi_amd.LMModel runs on an MI355X (device='cuda'); there is no CPU path")
+            lib = _capi.load()
+        self._lib = lib
+        self._handle = C.c_void_p()
+        sd = {k: v.detach().to(device=self.device, dtype=torch.bfloat16) for k, v in state_dict.items()}
+        descs, keep = _capi.tensor_descs(sd)
+        cfg = _lm_cfg_struct(self.config)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        lib.check(lib.mmi_lm_create(C.byref(cfg), descs, len(sd), max_batch, C.byref(self._handle)))
+        del keep, sd
+        self.max_batch = max_batch
+        self.training = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                self._lib.mmi_lm_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # attributes callers read
+    @property
+    def dep_q(self) -> int:
+        return self.config.dep_q
+
+    @property
+    def n_q(self) -> int:
+        return self.config.n_q
+
+    @property
+    def card(self) -> int:
+        return self.config.card
+
+    @property
+    def text_card(self) -> int:
+        return self.config.text_card
+
+    @property
+    def delays(self) -> List[int]:
+        return list(self.config.delays)
+
+    @property
+    def dim(self) -> int:
+        return self.config.dim
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    @property
+    def num_codebooks(self) -> int:
+        return self.config.n_q + 1
+
+    @property
+    def num_audio_codebooks(self) -> int:
+        return self.config.n_q
+
+    @property
+    def audio_offset(self) -> int:
+        return 1
+
+    @property
+    def initial_token_id(self) -> int:
+        return self.config.card
+
+    @property
+    def text_initial_token_id(self) -> int:
+        return self.config.text_card
+
+    @property
+    def text_padding_token_id(self) -> int:
+        return self.config.existing_text_padding_id
+
+    @property
+    def zero_token_id(self) -> int:
+        return -1
+
+    @property
+    def ungenerated_token_id(self) -> int:
+        return -2
+
+
+class LMGen:
+    """Streaming generation (reference: lm.py:556-850).  Options outside Moshi's own inference path (CFG,
+    condition tensors, hooks) are rejected loudly rather than silently ignored."""
+
+    def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
+                 top_k: int = 250, top_k_text: int = 25, cfg_coef: float = 1.0, check: bool = False,
+                 condition_tensors=None, on_text_hook=None, on_text_logits_hook=None, on_audio_hook=None,
+                 support_out_of_sync: bool = False, cfg_is_masked_until=None, cfg_is_no_text: bool = False,
+                 seed: int = 0):
+        assert not lm_model.training, "generation shouldn't be used in training mode."
+        if cfg_coef != 1.0 or condition_tensors is not None or cfg_is_masked_until is not None or cfg_is_no_text:
+            raise NotImplementedError("CFG / conditioning are outside the Moshi-7B step (SURVEY.md 8f-3)")
+        if on_text_hook or on_text_logits_hook or on_audio_hook:
+            raise NotImplementedError("per-step hooks are not supported by the fused step (use step_with_taps)")
+        self.lm_model = lm_model
+        self.use_sampling = use_sampling
+        self.temp = temp
+        self.temp_text = temp_text
+        self.top_k = top_k
+        self.top_k_text = top_k_text
+        self.cfg_coef = cfg_coef
+        self.check = check
+        self.support_out_of_sync = support_out_of_sync
+        self.max_delay = max(lm_model.delays)
+        self.seed = seed
+        self._lib = lm_model._lib
+        self._batch: Optional[int] = None
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.lm_model.device
+
+    def _stream(self):
+        return _capi.stream_ptr(self.device)
+
+    def _mask_ptr(self, mask: Optional[torch.Tensor]):
+        if mask is None:
+            return None, None
+        m = mask.to(device=self.device, dtype=torch.bool).contiguous().view(torch.uint8)
+        assert m.numel() == self._batch
+        return m, m.data_ptr()
+
+    # ---- streaming lifecycle -------------------------------------------------------------------
+    @property
+    def is_streaming(self) -> bool:
+        return self._batch is not None
+
+    def streaming_forever(self, batch_size: int) -> None:
+        s = _capi.Sampling()
+        s.use_sampling = 1 if self.use_sampling else 0
+        s.temp, s.temp_text = self.temp, self.temp_text
+        s.top_k, s.top_k_text = self.top_k, self.top_k_text
+        s.seed = self.seed
+        self._lib.check(self._lib.mmi_lm_streaming_start(self.lm_model._handle, int(batch_size), C.byref(s), self._stream()))
+        self._batch = int(batch_size)
+
+    def _stop_streaming(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._lib.check(self._lib.mmi_lm_streaming_stop(self.lm_model._handle))
+        self._batch = None
+
+    @contextmanager
+    def streaming(self, batch_size: int):
+        self.streaming_forever(batch_size)
+        try:
+            yield self
+        finally:
+            self._stop_streaming()
+
+    def reset_streaming(self, reset_mask: Optional[torch.Tensor] = None) -> None:
+        assert self.is_streaming
+        keep, ptr = self._mask_ptr(reset_mask)
+        self._lib.check(self._lib.mmi_lm_reset(self.lm_model._handle, ptr, self._stream()))
+
+    def set_exec_mask(self, exec_mask: torch.Tensor) -> None:
+        assert self.is_streaming
+        keep, ptr = self._mask_ptr(exec_mask)
+        self._lib.check(self._lib.mmi_lm_set_exec_mask(self.lm_model._handle, ptr, self._stream()))
+
+    # ---- step ------------------------------------------------------------------------------------
+    def _step(self, input_tokens: torch.Tensor, want_taps: bool, noise: Optional[torch.Tensor],
+              forced: Optional[torch.Tensor]):
+        if not self.is_streaming:
+            raise RuntimeError("You should wrap those calls with a `with lm_gen.streaming(): ...`.")
+        assert input_tokens.dim() == 3, "Shape should be [B, K, T]."
+        B, Ki, S = input_tokens.shape
+        assert B == self._batch, f"Got a batch size {B}, expected {self._batch}"
+        assert S == 1, "Only support being given steps one by one."
+        cfg = self.lm_model.config
+        needed = cfg.n_q - cfg.dep_q
+        assert Ki >= needed, f"We expect {needed} tokens from the user stream, got {Ki}."
+        codes = input_tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(B, cfg.dep_q + 1, 1, device=self.device, dtype=torch.int64)
+        tl = al = None
+        tlp = alp = None
+        if want_taps:
+            tl = torch.empty(B, cfg.text_card, device=self.device, dtype=torch.float32)
+            al = torch.empty(B, cfg.dep_q, cfg.card, device=self.device, dtype=torch.float32)
+            tlp, alp = tl.data_ptr(), al.data_ptr()
+        npz = None
+        if noise is not None:
+            kmax = max(self.top_k, self.top_k_text, 1)
+            noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
+            assert noise.shape == (B, 1 + cfg.dep_q, kmax), f"noise must be [B, 1+dep_q, {kmax}]"
+            npz = noise.data_ptr()
+        if forced is not None:
+            f = forced.to(device=self.device, dtype=torch.int64).contiguous().view(B, 1 + cfg.dep_q)
+            self._lib.check(self._lib.mmi_lm_force_next_tokens(self.lm_model._handle, f.data_ptr(), self._stream()))
+        valid = C.c_int32(0)
+        self._lib.check(self._lib.mmi_lm_step(self.lm_model._handle, codes.data_ptr(), Ki, out.data_ptr(), tlp, alp, npz, B,
+                                              C.byref(valid), self._stream()))
+        if not self.support_out_of_sync and not valid.value:
+            return None, tl, al
+        return out, tl, al
+
+    @torch.no_grad()
+    def step(self, input_tokens: torch.Tensor, depformer_replace_tokens: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """[B, >=8, 1] int64 user codes -> [B, 1 + dep_q, 1] int64 (text + generated audio) or None during the delay."""
+        forced = None
+        if depformer_replace_tokens is not None:   # lm.py:751-755
+            assert depformer_replace_tokens.dim() == 3
+            B = depformer_replace_tokens.shape[0]
+            forced = torch.full((B, 1 + self.lm_model.dep_q), -1, dtype=torch.int64, device=self.device)
+            forced[:, 1:] = depformer_replace_tokens.to(self.device).squeeze(-1)
+        out, _, _ = self._step(input_tokens, False, None, forced)
+        return out
+
+    @torch.no_grad()
+    def step_with_taps(self, input_tokens: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                       forced_tokens: Optional[torch.Tensor] = None
+                       ) -> Tuple[Optional[torch.Tensor], torch.Tensor, torch.Tensor]:
+        """`step` plus the parity taps: text logits [B, text_card] and audio logits [B, dep_q, card] (fp32 copies of
+        the bf16 logits the tokens were sampled from); `noise` replaces the RNG, `forced_tokens` teacher-forces."""
+        return self._step(input_tokens, True, noise, forced_tokens)

@@ -1,0 +1,269 @@
+"""ORACLE (test infrastructure - never imported by the product path).
+
+A numpy restatement of the reference's `LMGen.step` for Moshi (moshi/moshi/models/lm.py:668-850) with the
+eager bf16 numerics of the reference PyTorch path: every nn.Linear output, norm output, RoPE output, activation
+and residual add is rounded to bf16 (round-to-nearest-even), accumulation and norm/rope/softmax math are fp32.
+Used by tests/, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` leg as the CHECKER of the HIP engine.
+
+Pinned: tests/test_oracle_pinned.py checks it against golden vectors produced by running the reference itself
+(tests/golden/make_golden_lm.py).  The reference's scaled-dot-product attention is an ATen backend kernel whose
+internal blocking/rounding is not part of the reference sources; here it is restated from its definition (fp32
+softmax(QK^T/sqrt(d) + mask) V, output rounded to bf16), which the stated logits tolerance covers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+f32 = np.float32
+
+
+def bf16r(x: np.ndarray) -> np.ndarray:
+    """Round fp32 values to the nearest bf16 (ties to even) and return them as fp32."""
+    x = np.ascontiguousarray(x, dtype=f32)
+    u = x.view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(f32)
+
+
+def _np(t) -> np.ndarray:
+    if isinstance(t, np.ndarray):
+        return t.astype(f32)
+    return t.detach().cpu().float().numpy()
+
+
+def linear(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """nn.Linear(bias=False) on bf16 tensors: fp32 accumulate, bf16 result."""
+    return bf16r((x @ w.T).astype(f32))
+
+
+def rms_norm(x: np.ndarray, alpha: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """transformer.py:45-58 with dtype=float32 (`rms_norm_f32`)."""
+    var = f32(eps) + np.mean(x * x, axis=-1, keepdims=True, dtype=f32)
+    return bf16r(x * (alpha.reshape(1, -1) * (f32(1.0) / np.sqrt(var))).astype(f32))
+
+
+def silu(x: np.ndarray) -> np.ndarray:
+    return (x / (f32(1.0) + np.exp(-x))).astype(f32)
+
+
+def gated_ffn(x: np.ndarray, w_in: np.ndarray, w_out: np.ndarray) -> np.ndarray:
+    """gating.py:13-22 in eager bf16: linear_in -> silu(gate) * value -> linear_out."""
+    h = linear(x, w_in)
+    H = h.shape[-1] // 2
+    act = bf16r(silu(h[:, :H]))
+    return linear(bf16r(act * h[:, H:]), w_out)
+
+
+def rope_1(q: np.ndarray, k: np.ndarray, offset: np.ndarray, max_period: float):
+    """rope.py:11-82 for T=1, layout [B, H, D], interleaved; fp32 math, bf16 result."""
+    B, H, D = q.shape
+    ds = np.arange(D // 2, dtype=f32)
+    freqs = np.exp(ds * f32(-math.log(max_period) * 2 / D)).astype(f32)
+    ang = (freqs[None, :] * offset.astype(f32)[:, None]).astype(f32)[:, None, :]
+    c, s = np.cos(ang).astype(f32), np.sin(ang).astype(f32)
+
+    def rot(x):
+        x = x.reshape(B, H, D // 2, 2)
+        xr, xi = x[..., 0], x[..., 1]
+        return bf16r(np.stack([xr * c - xi * s, xr * s + xi * c], -1).reshape(B, H, D))
+
+    return rot(q), rot(k)
+
+
+def sample_token(logits: np.ndarray, use_sampling: bool, temp: float, top_k: int, noise: Optional[np.ndarray]) -> np.ndarray:
+    """sampling.py:86-106 on fp32 logits [B, V].  `noise` [B, k]: the Exp(1) draws of `multinomial` (:40-47), indexed by
+    rank in the descending top-k (torch.topk order; ties by index)."""
+    B, V = logits.shape
+    if not use_sampling or temp <= 0:
+        return logits.argmax(-1)
+    x = (logits / f32(temp)).astype(f32)
+    x = x - x.max(-1, keepdims=True)
+    e = np.exp(x).astype(f32)
+    p = (e / e.sum(-1, keepdims=True, dtype=f32)).astype(f32)
+    k = min(top_k, V)
+    out = np.zeros(B, np.int64)
+    for b in range(B):
+        order = np.lexsort((np.arange(V), -p[b]))[:k]          # value descending, index ascending
+        score = p[b][order] / noise[b, :k]
+        out[b] = order[int(score.argmax())]
+    return out
+
+
+class LMOracle:
+    def __init__(self, state_dict, cfg):
+        self.cfg = cfg
+        sd = {k: _np(v) for k, v in state_dict.items()}
+        c = cfg
+        self.emb = [sd[f"emb.{i}.weight"] for i in range(c.n_q)]
+        self.text_emb = sd["text_emb.weight"]
+        self.text_linear = sd["text_linear.weight"]
+        self.out_norm = sd["out_norm.alpha"].reshape(-1)
+        self.layers = []
+        for l in range(c.num_layers):
+            p = f"transformer.layers.{l}"
+            self.layers.append(dict(in_proj=sd[p + ".self_attn.in_projs.0.weight"], out_proj=sd[p + ".self_attn.out_projs.0.weight"],
+                                    n1=sd[p + ".norm1.alpha"].reshape(-1), n2=sd[p + ".norm2.alpha"].reshape(-1),
+                                    w_in=sd[p + ".gating.linear_in.weight"], w_out=sd[p + ".gating.linear_out.weight"]))
+        self.dep_in = [sd[f"depformer_in.{k}.weight"] for k in range(c.dep_q)]
+        self.dep_emb = [sd["depformer_text_emb.weight"]] + [sd[f"depformer_emb.{k}.weight"] for k in range(c.dep_q - 1)]
+        self.dep_layers = []
+        for l in range(c.depformer_num_layers):
+            p = f"depformer.layers.{l}"
+            self.dep_layers.append(dict(
+                in_proj=[sd[p + f".self_attn.in_projs.{k}.weight"] for k in range(c.dep_q)],
+                out_proj=[sd[p + f".self_attn.out_projs.{k}.weight"] for k in range(c.dep_q)],
+                n1=sd[p + ".norm1.alpha"].reshape(-1), n2=sd[p + ".norm2.alpha"].reshape(-1),
+                w_in=[sd[p + f".gating.{k}.linear_in.weight"] for k in range(c.dep_q)],
+                w_out=[sd[p + f".gating.{k}.linear_out.weight"] for k in range(c.dep_q)]))
+        self.linears = [sd[f"linears.{k}.weight"] for k in range(c.dep_q)]
+        self.B = 0
+
+    # ---- streaming state (lm.py:605-666; transformer.py:448-486) -----------------------------------
+    def streaming(self, B: int):
+        c = self.cfg
+        self.B = B
+        self.exec_mask = np.ones(B, bool)
+        self.CT = max(c.delays) + 2
+        self.cache = np.full((B, c.n_q + 1, self.CT), -2, np.int64)
+        self.offsets = np.zeros(B, np.int64)
+        self.offset_cpu = 0
+        H, Dh = c.num_heads, c.dim // c.num_heads
+        self.kv = [np.zeros((2, B, H, c.context, Dh), f32) for _ in range(c.num_layers)]
+        self.tr_offset = np.zeros(B, np.int64)          # MHA offset == RingKVCache.end_offset for every layer
+
+    def reset_streaming(self, mask=None):
+        mask = np.ones(self.B, bool) if mask is None else np.asarray(mask, bool)
+        self.exec_mask[mask] = True
+        self.offsets[mask] = 0
+        self.tr_offset[mask] = 0
+        self.offset_cpu = 0
+
+    def set_exec_mask(self, mask):
+        self.exec_mask = np.asarray(mask, bool).copy()
+
+    # ---- temporal transformer (lm.py:379-408; transformer.py:533-597, 752-802) -------------------------
+    def _embed(self, emb: np.ndarray, tok: np.ndarray) -> np.ndarray:
+        """ScaledEmbedding.forward (lm_utils.py:102-124): clamp(min=0) gather, zero vector for token -1."""
+        y = emb[np.maximum(tok, 0)]
+        return np.where((tok == -1)[:, None], f32(0), y).astype(f32)
+
+    def forward_text(self, tokens: np.ndarray):
+        c = self.cfg
+        B = tokens.shape[0]
+        x = None
+        for i in range(c.n_q):
+            e = self._embed(self.emb[i], tokens[:, i + 1])
+            x = e if x is None else bf16r(x + e)
+        x = bf16r(x + self._embed(self.text_emb, tokens[:, 0]))
+        H, Dh, cap = c.num_heads, c.dim // c.num_heads, c.context
+        off = self.tr_offset
+        for l, L in enumerate(self.layers):
+            qkv = linear(rms_norm(x, L["n1"]), L["in_proj"]).reshape(B, 3, H, Dh)
+            q, k = rope_1(qkv[:, 0], qkv[:, 1], off, c.max_period)
+            v = qkv[:, 2]
+            cache = self.kv[l]
+            att = np.zeros((B, H, Dh), f32)
+            for b in range(B):
+                slot = int(off[b] % cap)
+                cache[0, b, :, slot] = k[b]              # written unconditionally (transformer.py:243-250)
+                cache[1, b, :, slot] = v[b]
+                last = int(off[b])
+                end_new = last + 1 if self.exec_mask[b] else last
+                idx = np.arange(cap)
+                delta = idx - (last % cap)
+                pos = np.where(delta <= 0, last + delta, last + delta - cap)
+                pos = np.where(idx >= end_new, -1, pos)
+                # non-executing rows: the reference masks with the un-advanced end_offset; their output is don't-care
+                dq = last - pos
+                ok = (pos >= 0) & (dq >= 0) & (dq < c.context)
+                if not ok.any():
+                    continue
+                s = (cache[0, b][:, ok] @ q[b][:, :, None])[..., 0] / f32(math.sqrt(Dh))   # [H, n]
+                s = s - s.max(-1, keepdims=True)
+                p = np.exp(s).astype(f32)
+                p = p / p.sum(-1, keepdims=True, dtype=f32)
+                att[b] = np.einsum("hn,hnd->hd", p, cache[1, b][:, ok]).astype(f32)
+            att = bf16r(att.reshape(B, H * Dh))
+            x = bf16r(x + linear(att, L["out_proj"]))
+            x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"], L["w_out"]))
+        tout = rms_norm(x, self.out_norm)
+        return tout, linear(tout, self.text_linear)
+
+    # ---- depformer (lm.py:450-493, 809-850) ------------------------------------------------------------
+    def depformer_step(self, text_token, tout, use_sampling, temp, top_k, noise, forced):
+        c = self.cfg
+        B = tout.shape[0]
+        Hd, Dhd = c.depformer_num_heads, c.depformer_dim // c.depformer_num_heads
+        prev = text_token
+        keys: List[List[np.ndarray]] = [[] for _ in self.dep_layers]
+        vals: List[List[np.ndarray]] = [[] for _ in self.dep_layers]
+        tokens, logits_all = [], []
+        for k in range(c.dep_q):
+            x = bf16r(linear(tout, self.dep_in[k]) + self._embed(self.dep_emb[k], prev))
+            for l, L in enumerate(self.dep_layers):
+                qkv = linear(rms_norm(x, L["n1"]), L["in_proj"][k]).reshape(B, 3, Hd, Dhd)
+                keys[l].append(qkv[:, 1]); vals[l].append(qkv[:, 2])
+                K = np.stack(keys[l], 2); V = np.stack(vals[l], 2)                       # [B, Hd, k+1, Dhd]
+                s = np.einsum("bhd,bhnd->bhn", qkv[:, 0], K).astype(f32) / f32(math.sqrt(Dhd))
+                s = s - s.max(-1, keepdims=True)
+                p = np.exp(s).astype(f32)
+                p = p / p.sum(-1, keepdims=True, dtype=f32)
+                att = bf16r(np.einsum("bhn,bhnd->bhd", p, V).astype(f32).reshape(B, Hd * Dhd))
+                x = bf16r(x + linear(att, L["out_proj"][k]))
+                x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"][k], L["w_out"][k]))
+            lg = linear(x, self.linears[k])
+            nz = None if noise is None else noise[:, 1 + k]
+            tok = sample_token(lg, use_sampling, temp, top_k, nz)
+            if forced is not None:
+                tok = np.where(forced[:, 1 + k] >= 0, forced[:, 1 + k], tok)
+            tokens.append(tok); logits_all.append(lg)
+            prev = tok
+        return np.stack(tokens, 1), np.stack(logits_all, 1)
+
+    # ---- LMGen._step (lm.py:668-783) ---------------------------------------------
+    def step(self, user_codes: np.ndarray, use_sampling: bool = False, temp: float = 0.8, temp_text: float = 0.7,
+             top_k: int = 250, top_k_text: int = 25, noise: Optional[np.ndarray] = None,
+             forced: Optional[np.ndarray] = None, support_out_of_sync: bool = False):
+        c = self.cfg
+        B = self.B
+        delays = np.asarray(c.delays)
+        need = c.n_q - c.dep_q
+        codes = np.asarray(user_codes)[:, :need, 0]
+        CT = self.CT
+        ex = self.exec_mask
+        for j in range(need):
+            ch = c.dep_q + 1 + j
+            wp = (self.offsets + delays[ch]) % CT
+            for b in range(B):
+                if ex[b]:
+                    self.cache[b, ch, wp[b]] = codes[b, j]
+        is_init = (self.offsets[:, None] <= delays[None, :]) | ~ex[:, None]
+        inp = self.cache[np.arange(B)[:, None], np.arange(c.n_q + 1)[None, :], (self.offsets % CT)[:, None]]
+        initial = np.array([c.text_card] + [c.card] * c.n_q)
+        inp = np.where(is_init, initial[None, :], inp)
+        tout, text_logits = self.forward_text(inp)
+        self.tr_offset = np.where(ex, self.tr_offset + 1, self.tr_offset)
+        text_token = sample_token(text_logits, use_sampling, temp_text, top_k_text, None if noise is None else noise[:, 0])
+        if forced is not None:
+            text_token = np.where(forced[:, 0] >= 0, forced[:, 0], text_token)
+        audio_tokens, audio_logits = self.depformer_step(text_token, tout, use_sampling, temp, top_k, noise, forced)
+        self.offsets = np.where(ex, self.offsets + 1, self.offsets)
+        self.offset_cpu += 1
+        pos = self.offsets % CT
+        for b in range(B):
+            if ex[b]:
+                self.cache[b, 0, pos[b]] = text_token[b]
+                self.cache[b, 1:c.dep_q + 1, pos[b]] = audio_tokens[b]
+        taps = (text_logits, audio_logits, text_token, audio_tokens)
+        max_delay = int(delays.max())
+        if not support_out_of_sync and self.offset_cpu <= max_delay:
+            return None, taps
+        gd = delays[:c.dep_q + 1]
+        index = (self.offsets[:, None] - max_delay + gd[None, :]) % CT
+        out = self.cache[np.arange(B)[:, None], np.arange(c.dep_q + 1)[None, :], index]
+        hide = (self.offsets <= max_delay) | ~ex
+        out = np.where(hide[:, None], -2, out)
+        return out[:, :, None], taps

@@ -212,9 +212,10 @@ class TransformerLayer:
         bias = (pos_k[:, None, :] >= 0) & (delta >= 0) & (delta < self.context)        # [B, T, cap]
         att = np.einsum("bhtd,bhsd->bhts", q, keys, optimize=True).astype(f32) / f32(math.sqrt(D))
         att = np.where(bias[:, None], att, -np.inf)
-        att = att - att.max(-1, keepdims=True)
-        p = np.exp(att).astype(f32)
-        p = (p / p.sum(-1, keepdims=True, dtype=f32)).astype(f32)
+        with np.errstate(invalid="ignore"):   # a row that never executed has no valid key: NaN, as in the reference
+            att = att - att.max(-1, keepdims=True)
+            p = np.exp(att).astype(f32)
+            p = (p / p.sum(-1, keepdims=True, dtype=f32)).astype(f32)
         o = np.einsum("bhts,bhsd->bhtd", p, values, optimize=True).astype(f32)
         o = o.transpose(0, 2, 1, 3).reshape(B, T, d)
         self.offset = np.where(exec_mask, self.offset + T, self.offset)

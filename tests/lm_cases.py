@@ -1,0 +1,169 @@
+"""Parity cases for LMGen.step shared by the simulator tests (CPU) and the GPU tests."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from moshi_amd.config import LMConfig, tiny_lm_config
+from moshi_amd.lm import LMGen, LMModel
+from moshi_amd.weights import random_lm_state_dict
+from oracle.lm_oracle import LMOracle
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+# Logits tolerance (bf16 model, fp32 accumulation; only summation order / attention-backend rounding differ):
+#   max |d| <= LOGIT_MAX_REL * max|ref|   and   mean |d| <= LOGIT_MEAN_REL * max|ref|   per (row, sampling site).
+# Measured: the numpy oracle sits at max 3.1 % / mean 0.9 % (median 1.2 % / 0.4 %) from the reference PyTorch CPU path
+# on the golden vectors - pure bf16 rounding-order noise through 2 + 8x2 transformer layers.
+LOGIT_MAX_REL, LOGIT_MEAN_REL = 0.05, 0.012
+
+
+def logits_close(a: np.ndarray, ref: np.ndarray) -> bool:
+    scale = float(np.abs(ref).max()) + 1e-6
+    d = np.abs(a - ref)
+    return float(d.max()) <= LOGIT_MAX_REL * scale and float(d.mean()) <= LOGIT_MEAN_REL * scale
+
+
+def near_tie(ref_logits: np.ndarray, tok_a: int, tok_b: int) -> bool:
+    """Two implementations may pick different tokens only where the reference logits nearly tie."""
+    scale = float(np.abs(ref_logits).max()) + 1e-6
+    return abs(float(ref_logits[tok_a]) - float(ref_logits[tok_b])) <= 2 * LOGIT_MAX_REL * scale
+
+
+def make_engine(cfg, sd, device, lib, max_batch, **gen_kwargs):
+    lm = LMModel(sd, cfg, device=device, max_batch=max_batch, lib=lib)
+    return LMGen(lm, **gen_kwargs)
+
+
+def check_golden_greedy(device, lib):
+    """Replays the reference's greedy run (exec masks + partial reset), teacher-forced with the reference's own
+    tokens so that a near-tie cannot cascade: ring outputs must be identical, logits within tolerance."""
+    g = np.load(GOLDEN / "lm_tiny.npz")
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+    gen = make_engine(cfg, sd, device, lib, 3, use_sampling=False, support_out_of_sync=True)
+    S, B = g["masks"].shape
+    agree = total = 0
+    with gen.streaming(B):
+        for s in range(S):
+            if s == int(g["reset_step"][0]):
+                gen.reset_streaming(torch.from_numpy(g["reset_mask"]).to(device))
+            gen.set_exec_mask(torch.from_numpy(g["masks"][s]).to(device))
+            forced = np.concatenate([g["g_text_tok"][s][:, None], g["g_audio_tok"][s]], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(g["codes"][s]).to(device),
+                                             forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            for b in range(B):
+                if not g["masks"][s, b]:
+                    assert (out[b] == -2).all()            # lm.py:781-782
+                    continue
+                assert np.array_equal(out[b], g["g_tokens"][s, b]), f"step {s} row {b}: ring output differs"
+                assert logits_close(tl[b], g["g_text_logits"][s, b]), f"step {s} row {b}: text logits"
+                t_eng, t_ref = int(tl[b].argmax()), int(g["g_text_tok"][s, b])
+                assert t_eng == t_ref or near_tie(g["g_text_logits"][s, b], t_eng, t_ref)
+                for k in range(cfg.dep_q):
+                    assert logits_close(al[b, k], g["g_audio_logits"][s, b, k]), f"step {s} row {b} cb {k}: audio logits"
+                    a_eng, a_ref = int(al[b, k].argmax()), int(g["g_audio_tok"][s, b, k])
+                    assert a_eng == a_ref or near_tie(g["g_audio_logits"][s, b, k], a_eng, a_ref)
+                    agree += a_eng == a_ref
+                    total += 1
+    assert agree >= 0.85 * total, f"greedy agreement with the reference too low: {agree}/{total}"
+
+
+def check_golden_sampled(device, lib):
+    """Replays the reference's sampled run with the Exp(1) draws recorded at its `multinomial`."""
+    g = np.load(GOLDEN / "lm_tiny.npz")
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+    gen = make_engine(cfg, sd, device, lib, 3, use_sampling=True, temp=0.8, temp_text=0.7, top_k=20, top_k_text=10,
+                      support_out_of_sync=True)
+    S, B = g["s_text_tok"].shape
+    same = total = 0
+    with gen.streaming(B):
+        for s in range(S):
+            forced = np.concatenate([g["s_text_tok"][s][:, None], g["s_audio_tok"][s]], 1)
+            # first pass WITHOUT forcing on a scratch copy is not possible (state); instead: force the history and
+            # compare the engine's own noisy choice through the oracle-free identity  argmax(p/q)  on its logits taps
+            out, tl, al = gen.step_with_taps(torch.from_numpy(g["codes2"][s]).to(device),
+                                             noise=torch.from_numpy(g["s_noise"][s]).to(device),
+                                             forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            assert np.array_equal(out, g["s_tokens"][s])
+            from oracle.lm_oracle import sample_token
+            tt = sample_token(tl, True, 0.7, 10, g["s_noise"][s][:, 0])
+            same += int((tt == g["s_text_tok"][s]).sum()); total += B
+            for k in range(cfg.dep_q):
+                assert logits_close(al[:, k], g["s_audio_logits"][s][:, k])
+                at = sample_token(al[:, k], True, 0.8, 20, g["s_noise"][s][:, 1 + k])
+                same += int((at == g["s_audio_tok"][s][:, k]).sum()); total += B
+    assert same >= 0.9 * total, f"sampled-token agreement given the reference's noise: {same}/{total}"
+
+
+def engine_sampling_matches_oracle_rule(device, lib):
+    """The engine's in-kernel sampler (softmax -> top-k -> argmax(p/q)) against the oracle's restatement of
+    sampling.py:86-106 on the engine's OWN logits with supplied noise: must be identical token for token."""
+    from oracle.lm_oracle import sample_token
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=5)
+    B = 4
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=True, temp=0.8, temp_text=0.7, top_k=20, top_k_text=10,
+                      support_out_of_sync=True)
+    rng = np.random.default_rng(1)
+    with gen.streaming(B):
+        for s in range(4):
+            codes = rng.integers(0, cfg.card, (B, 8, 1))
+            noise = rng.exponential(1.0, (B, 1 + cfg.dep_q, 20)).astype(np.float32)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), noise=torch.from_numpy(noise).to(device))
+            tl, al = tl.cpu().numpy(), al.cpu().numpy()
+            # the step output holds text of this step (delay 0) only after the ring delay; re-derive from taps instead
+            tt = sample_token(tl, True, 0.7, 10, noise[:, 0])
+            toks = [sample_token(al[:, k], True, 0.8, 20, noise[:, 1 + k]) for k in range(cfg.dep_q)]
+            if s >= 1:
+                o = out.cpu().numpy()[:, :, 0]
+                # channels with delay 1 (acoustic codebooks 1..) are emitted in the step they are sampled
+                for k in range(1, cfg.dep_q):
+                    assert np.array_equal(o[:, 1 + k], toks[k]), (s, k)
+                assert np.array_equal(o[:, 0], prev_tt) and np.array_equal(o[:, 1], prev_a0)
+            prev_tt, prev_a0 = tt, toks[0]
+
+
+def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True):
+    sd = random_lm_state_dict(cfg, seed=seed)
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(B)
+    rng = np.random.default_rng(seed)
+    with gen.streaming(B):
+        for s in range(S):
+            mask = np.ones(B, bool)
+            if use_masks and B > 1:
+                mask = rng.random(B) > 0.3
+                mask[0] = True
+                if s == S // 2:
+                    r = np.zeros(B, bool); r[B - 1] = True
+                    orc.reset_streaming(r); gen.reset_streaming(torch.from_numpy(r).to(device))
+                    mask[B - 1] = True
+            orc.set_exec_mask(mask); gen.set_exec_mask(torch.from_numpy(mask).to(device))
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            for b in range(B):
+                if not mask[b]:
+                    continue
+                assert np.array_equal(out[b], oo[b]), f"step {s} row {b}: ring output differs"
+                assert logits_close(tl[b], otl[b]), f"step {s} row {b}: text logits {np.abs(tl[b]-otl[b]).max()}"
+                for k in range(cfg.dep_q):
+                    assert logits_close(al[b, k], oal[b, k]), f"step {s} row {b} cb {k}: {np.abs(al[b,k]-oal[b,k]).max()}"
+                    a_e, a_o = int(al[b, k].argmax()), int(oat[b, k])
+                    assert a_e == a_o or near_tie(oal[b, k], a_e, a_o)
+
+
+def smoke_lm(dev):
+    """One tiny LMGen.step on the GPU against the oracle (called by __graft_entry__.smoke)."""
+    cfg = tiny_lm_config()
+    oracle_vs_engine(dev, None, cfg, seed=3, B=2, S=3, use_masks=False)
+    print("smoke: LMGen.step ring outputs identical to the oracle, logits within tolerance")

@@ -1,0 +1,44 @@
+"""LMGen.step kernels on the CPU kernel simulator against the reference golden vectors and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from moshi_amd.config import tiny_lm_config
+from moshi_amd.weights import random_lm_state_dict
+from tests import lm_cases
+
+
+def test_greedy_schedule_matches_reference_golden(sim_lib):
+    lm_cases.check_golden_greedy("cpu", sim_lib)
+
+
+def test_sampled_run_matches_reference_golden_given_its_noise(sim_lib):
+    lm_cases.check_golden_sampled("cpu", sim_lib)
+
+
+def test_in_kernel_sampler_follows_the_reference_rule(sim_lib):
+    lm_cases.engine_sampling_matches_oracle_rule("cpu", sim_lib)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_matches_oracle_with_masks_and_reset(sim_lib, B):
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=40 + B, B=B, S=5)
+
+
+def test_none_during_delay_and_errors(sim_lib):
+    g = np.load(lm_cases.GOLDEN / "lm_tiny.npz")
+    cfg = tiny_lm_config()
+    gen = lm_cases.make_engine(cfg, random_lm_state_dict(cfg, seed=17), "cpu", sim_lib, 3, use_sampling=False)
+    with pytest.raises(RuntimeError, match="streaming"):
+        gen.step(torch.zeros(3, 8, 1, dtype=torch.long))
+    with gen.streaming(3):
+        pattern = [gen.step(torch.from_numpy(g["codes"][s])) is None for s in range(3)]
+        assert pattern == list(g["none_pattern"])            # lm.py:774-776
+        with pytest.raises(AssertionError):
+            gen.step(torch.zeros(2, 8, 1, dtype=torch.long))  # batch mismatch (lm.py:681)
+        with pytest.raises(AssertionError):
+            gen.step(torch.zeros(3, 7, 1, dtype=torch.long))  # too few user codebooks (lm.py:683-686)
+        out = gen.step(torch.zeros(3, 9, 1, dtype=torch.long))  # extra rows are ignored (lm.py:688-689)
+        assert out.shape == (3, 9, 1) and out.dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        lm_cases.LMGen(gen.lm_model, cfg_coef=2.0)

@@ -37,8 +37,11 @@ def test_full_size_matches_oracle(factory):
 
 
 def test_rvq_indices_bit_exact_on_many_vectors(factory):
-    """>= 1e5 index decisions: 4096 latents x 32 codebooks against the oracle's cdist restatement, with an fp64 audit
-    of any disagreement (a disagreement is only legitimate at a near-tie below fp32 resolution)."""
+    """131 072 index decisions (4096 latents x 32 levels) against the oracle's fp32 cdist restatement.
+    The engine evaluates distances in fp64, i.e. it returns the exact nearest centroid; the fp32 reference formula
+    can only disagree with that at a near-tie below its own resolution (relative gaps down to
+    3e-6 occur about once in 1e5 decisions).  Any disagreement is therefore audited in fp64: it must be such a
+    near-tie AND the engine must hold the exact argmin."""
     from oracle.mimi_oracle import MimiOracle
     cfg = MimiConfig()
     sd = random_mimi_state_dict(cfg, seed=1234)
@@ -49,8 +52,20 @@ def test_rvq_indices_bit_exact_on_many_vectors(factory):
     ce = m.quantize(torch.from_numpy(lat).to(DEV)).cpu().numpy()
     co = orc.quantize(lat)
     assert ce.shape == co.shape == (64, 32, 64)
-    first_bad = (ce != co).any(1)            # [B, T]: rows where some level differs (later levels then cascade)
-    assert first_bad.sum() == 0, f"{int(first_bad.sum())} of {first_bad.size} vectors differ from the oracle"
+    bad = np.argwhere((ce != co).any(1))
+    assert len(bad) <= 4, f"{len(bad)} of 4096 vectors differ from the oracle - more than near-ties can explain"
+    for b, t in bad:
+        k = int(np.argmax(ce[b, :, t] != co[b, :, t]))          # first level that differs; the prefix is identical
+        part = 0 if k < cfg.q_n_q_semantic else 1
+        x = (orc.in_proj[part].astype(np.float64) @ lat[b, :, t].astype(np.float64)).astype(np.float32)
+        k0 = 0 if part == 0 else cfg.q_n_q_semantic
+        for kk in range(k0, k):
+            x = (x - orc.codebooks[kk][co[b, kk, t]]).astype(np.float32)
+        E = orc.codebooks[k].astype(np.float64)
+        d = ((E - x.astype(np.float64)) ** 2).sum(-1)
+        de, do = d[ce[b, k, t]], d[co[b, k, t]]
+        assert abs(de - do) <= 2e-5 * min(de, do), f"not a near-tie: {de} vs {do}"
+        assert de <= do, "the engine must hold the exact (fp64) nearest centroid"
 
 
 def test_batch_rows_are_independent_and_graph_equals_eager(factory, monkeypatch):

@@ -50,3 +50,39 @@ def test_mimi_oracle_full_size_matches_reference():
         assert close(orc.decode(g["codes"][f]), g["pcm"][f], 2e-5, 2e-5)
     # streaming codes == non-streaming codes in the reference
     assert np.array_equal(np.concatenate(list(g["codes"]), -1), g["codes_nonstreaming"])
+
+
+def test_lm_oracle_matches_reference_golden():
+    """oracle/lm_oracle.py against LMGen.step of the reference (greedy, exec masks, partial reset), teacher-forced
+    with the reference's tokens; tolerance as stated in tests/lm_cases.py."""
+    from moshi_amd.config import tiny_lm_config
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle, sample_token
+    from tests import lm_cases
+    g = np.load(GOLDEN / "lm_tiny.npz")
+    cfg = tiny_lm_config()
+    o = LMOracle(random_lm_state_dict(cfg, seed=int(g["seed"][0])), cfg)
+    S, B = g["masks"].shape
+    o.streaming(B)
+    for s in range(S):
+        if s == int(g["reset_step"][0]):
+            o.reset_streaming(g["reset_mask"])
+        o.set_exec_mask(g["masks"][s])
+        forced = np.concatenate([g["g_text_tok"][s][:, None], g["g_audio_tok"][s]], 1)
+        out, (tl, al, tt, at) = o.step(g["codes"][s], use_sampling=False, forced=forced, support_out_of_sync=True)
+        m = g["masks"][s]
+        assert np.array_equal(out[m], g["g_tokens"][s][m])
+        for b in np.nonzero(m)[0]:
+            assert lm_cases.logits_close(tl[b], g["g_text_logits"][s, b])
+            for k in range(cfg.dep_q):
+                assert lm_cases.logits_close(al[b, k], g["g_audio_logits"][s, b, k])
+    # sampled rule: the reference's tokens follow from its own logits and recorded noise.  torch.topk leaves the order of
+    # EQUAL values unspecified (bf16 logits do tie), so a disagreement is only accepted between exactly tied logits.
+    S2 = g["s_text_tok"].shape[0]
+    for s in range(S2):
+        sites = [(g["s_text_logits"][s], 0.7, 10, g["s_noise"][s][:, 0], g["s_text_tok"][s])]
+        sites += [(g["s_audio_logits"][s][:, k], 0.8, 20, g["s_noise"][s][:, 1 + k], g["s_audio_tok"][s][:, k]) for k in range(cfg.dep_q)]
+        for lg, temp, k, nz, ref_tok in sites:
+            tok = sample_token(lg, True, temp, k, nz)
+            for b in range(B):
+                assert tok[b] == ref_tok[b] or lg[b, tok[b]] == lg[b, ref_tok[b]], "sampling rule restatement disagrees"
