@@ -11,7 +11,7 @@ namespace {
 
 struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
-    int N = 0, K = 0, TN = 32, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, rows interleaved
+    int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
     size_t bytes = 0;
 };
 
@@ -32,6 +32,7 @@ struct EvPair { hipEvent_t a, b; };
 struct mmi_lm {
     mmi_lm_cfg cfg;
     int max_batch = 0;
+    int T = 32;                     // MFMA tile of the whole model: 16 when max_batch <= 16, else 32 (lm_kernels.h)
     int NC = 0, CT = 0, max_delay = 0;
     MmiArena wts;
     // weights
@@ -63,6 +64,7 @@ struct mmi_lm {
     uint16_t *tout = nullptr, *text_logits = nullptr;
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
     float *opart = nullptr, *ml = nullptr;
+    float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
     uint16_t *dkc = nullptr, *dvc = nullptr;        // [dep_layers][B][Hd][dep_q][Dhd]
     float* noise = nullptr;                         // [B][1+dep_q][kmax]
@@ -94,8 +96,6 @@ int need(const MmiWeights& W, const std::string& name, int ndim, const mmi_tenso
     return MMI_OK;
 }
 
-int pick_tn(int n_rows) { return (n_rows / 32) >= 512 ? 32 : 16; }
-
 // nn.Linear weight [N][K] -> packed; gate_hidden > 0: [2*hidden][K] gate|value matrix
 int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g) {
     const mmi_tensor_desc* d;
@@ -103,13 +103,14 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     if (rc) return rc;
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
+    const int TN = lm->T;
     g->K = K;
     g->gate = gate_hidden > 0 ? 1 : 0;
     g->N = gate_hidden > 0 ? gate_hidden : N;
-    g->TN = pick_tn(gate_hidden > 0 ? 2 * gate_hidden : N);
-    const int rows_per_tile = gate_hidden > 0 ? g->TN / 2 : g->TN;
+    if (g->N % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "out_features must be a multiple of 8: " + name);
+    const int rows_per_tile = gate_hidden > 0 ? TN / 2 : TN;
     g->NT = mmi_cdiv(g->N, rows_per_tile);
-    g->KSTEPS = mmi_cdiv(K, g->TN == 32 ? 16 : 32);
+    g->KSTEPS = mmi_cdiv(K, mmi_kstep(TN));
     size_t n = (size_t)g->NT * g->KSTEPS * 512;
     uint16_t* p = nullptr;
     MMI_HIP_CHECK(lm->wts.alloc(&p, n));
@@ -117,7 +118,7 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     g->bytes = n * sizeof(uint16_t);
     lm->weight_bytes += g->bytes;
     MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
-               g->TN, g->NT, g->KSTEPS, gate_hidden);
+               TN, g->NT, g->KSTEPS, gate_hidden);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
@@ -137,60 +138,119 @@ int load_copy(mmi_lm* lm, const MmiWeights& W, const std::string& name, int ndim
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-template <int TN, int WAVES>
-int launch_gemm_mt(hipStream_t s, const GemmW& g, const GemmArgs& a, int mt) {
-    switch (mt) {
-        case 1: MMI_LAUNCH((k_gemm_bf16<TN, 1, WAVES>), g.NT, WAVES * 64, 0, s, a); break;
-        case 2: MMI_LAUNCH((k_gemm_bf16<TN, 2, WAVES>), g.NT, WAVES * 64, 0, s, a); break;
-        case 4:
-            if constexpr (TN == 16) { MMI_LAUNCH((k_gemm_bf16<TN, 4, WAVES>), g.NT, WAVES * 64, 0, s, a); break; }
-            return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the 32-row GEMM tile");
-        default: return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
+struct GemmPlan { int waves, ntw, ksplit; };
+
+// How a GEMM is cut into workgroups (measured on MI355X with scripts/gemm_microbench.hip): enough workgroups to
+// cover the 256 CUs, K split over the waves of a workgroup, more waves per workgroup when there are few n-tiles.
+GemmPlan plan_gemm(const GemmW& g, bool may_split) {
+    GemmPlan p;
+    p.ntw = 1;
+    p.ksplit = 1;
+    // few n-tiles (N = 4096 at the 32-row tile): split K over workgroups so that every CU streams weights
+    if (may_split && g.NT < 200 && g.KSTEPS >= 128) p.ksplit = g.NT <= 64 ? 4 : 2;
+    if (const char* ek = getenv("MMI_GEMM_KSPLIT")) {      // test hook: force the split-K path on small shapes
+        const int v = atoi(ek);
+        if (may_split && v >= 1 && v <= 4 && g.KSTEPS >= v) p.ksplit = v;
+    }
+    const int ks = g.KSTEPS / p.ksplit;
+    p.waves = ks >= 32 ? 8 : 4;
+    const char* e = getenv("MMI_GEMM_WAVES");
+    if (e && atoi(e) > 0) p.waves = atoi(e);
+    e = getenv("MMI_GEMM_NTW");
+    if (e && atoi(e) > 0) p.ntw = atoi(e);
+    return p;
+}
+
+template <int TN, int MT, int NTW>
+int launch_gemm_w(hipStream_t s, dim3 groups, int waves, const GemmArgs& a) {
+    switch (waves) {
+        case 4: MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 4>), groups, 256, 0, s, a); break;
+        case 8:
+            if constexpr (MT * NTW <= 2) { MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 4>), groups, 512, 0, s, a); break; }
+            MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 4>), groups, 256, 0, s, a); break;
+        default: return mmi_fail(MMI_ERR_UNSUPPORTED, "unsupported waves per GEMM workgroup");
     }
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
 
+template <int TN>
+int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
+    const dim3 groups(mmi_cdiv(NT, p.ntw), p.ksplit);
+    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, a);
+    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, a);
+    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, a);
+    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, a);
+    return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
+}
+
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
-    a.wp = g.wp; a.N = g.N; a.K = g.K; a.KSTEPS = g.KSTEPS;
-    const int bt = g.TN;
-    int mt = mmi_cdiv(a.B, bt);
-    if (mt == 3) mt = 4;
-    const int waves = g.KSTEPS >= 64 ? 8 : 4;
+    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    const int mt = mmi_cdiv(a.B, lm->T);
+    const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     EvPair* ev = nullptr;
     if (lm->profiling && is_dominant) {
         if (lm->ev_used == lm->ev_pool.size()) {
-            EvPair p;
-            MMI_HIP_CHECK(hipEventCreate(&p.a));
-            MMI_HIP_CHECK(hipEventCreate(&p.b));
-            lm->ev_pool.push_back(p);
+            EvPair pr;
+            MMI_HIP_CHECK(hipEventCreate(&pr.a));
+            MMI_HIP_CHECK(hipEventCreate(&pr.b));
+            lm->ev_pool.push_back(pr);
         }
         ev = &lm->ev_pool[lm->ev_used++];
         lm->prof_stream = s;
         MMI_HIP_CHECK(hipEventRecord(ev->a, s));
     }
-    int rc;
-    if (g.TN == 32) rc = waves == 8 ? launch_gemm_mt<32, 8>(s, g, a, mt) : launch_gemm_mt<32, 4>(s, g, a, mt);
-    else rc = waves == 8 ? launch_gemm_mt<16, 8>(s, g, a, mt) : launch_gemm_mt<16, 4>(s, g, a, mt);
+    int rc = lm->T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
     if (rc) return rc;
     if (ev) MMI_HIP_CHECK(hipEventRecord(ev->b, s));
     return MMI_OK;
 }
 
-void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_ld, int epi, const uint16_t* resid,
-              const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0, bool dominant = false) {
+// number of bf16 elements of a packed activation buffer with `features` columns
+size_t packed_elems(const mmi_lm* lm, int features) {
+    return (size_t)mmi_cdiv(lm->batch, lm->T) * mmi_cdiv(features, mmi_kstep(lm->T)) * 512;
+}
+int packed_ksteps(const mmi_lm* lm, int features) { return mmi_cdiv(features, mmi_kstep(lm->T)); }
+
+// x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
+void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
+              const uint16_t* resid, const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0,
+              bool dominant = false) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.out = out; a.out_ld = out_ld; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
+    a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
     a.tok_stride = tok_stride; a.B = lm->batch;
+    a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
+    a.out_ld = out_features;
+    a.out_ksteps = packed_ksteps(lm, out_features);
     GemmW gw = g;
     lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); });
 }
 
-void add_rmsnorm(mmi_lm* lm, const uint16_t* x, const uint16_t* alpha, uint16_t* y, int D) {
-    const int B = lm->batch;
+// K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
+// Returns the number of partials, 0 when the GEMM is not split (then it applied the residual itself, in place on x).
+int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features) {
+    const GemmPlan p = plan_gemm(g, true);
+    if (p.ksplit <= 1) {
+        add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x);
+        return 0;
+    }
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = reinterpret_cast<const u32x4*>(in); a.epi = MMI_EPI_PARTIAL; a.partial = lm->partial; a.B = lm->batch;
+    GemmW gw = g;
+    lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); });
+    return p.ksplit;
+}
+
+// x (+= the P pending split-K partials), y = rms_norm(x) * alpha
+void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, uint16_t* y, int D) {
+    const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, D);
+    const float* partial = lm->partial;
     lm->prog.add([=](hipStream_t s) {
-        MMI_LAUNCH(k_rmsnorm_bf16, B, 256, 0, s, x, alpha, y, D, 1e-8f);
+        int nth = mmi_cdiv(D / 8, 64) * 64;            // one 16-byte piece per thread where the row allows it
+        if (nth > 1024) nth = 1024;
+        MMI_LAUNCH(k_resid_rmsnorm, B, nth, 0, s, x, partial, P, B, alpha, y, D, T, ksteps, 1e-8f);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -209,13 +269,21 @@ void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, in
     sa.B = lm->batch;
     sa.forced = lm->forced + site; sa.forced_stride = 1 + lm->cfg.dep_q; sa.use_forced = lm->use_forced;
     const int B = lm->batch;
-    const bool big = V > 4096;
     lm->prog.add([=](hipStream_t s) {
-        if (big) MMI_LAUNCH((k_sample<1024>), B, 1024, 0, s, sa);
-        else MMI_LAUNCH((k_sample<256>), B, 256, 0, s, sa);
+        if (V <= 2048) MMI_LAUNCH((k_sample<256, 8, true>), B, 256, 0, s, sa);
+        else if (V <= 8192) MMI_LAUNCH((k_sample<1024, 8, true>), B, 1024, 0, s, sa);
+        else MMI_LAUNCH((k_sample<1024, 32, false>), B, 1024, 0, s, sa);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
+}
+
+// workgroups per (session, head) of the decode attention: 1 once B*H alone fills the chip, else split the ring
+int attn_splits(const mmi_lm_cfg& c, int B) {
+    const int chunks = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    int want = 1024 / (B * c.num_heads);
+    if (want < 1) want = 1;
+    return want < chunks ? want : chunks;
 }
 
 int launch_attn_split(hipStream_t s, const LmAttnArgs& a) {
@@ -249,65 +317,76 @@ int build_program(mmi_lm* lm) {
         TokArgs t = tok_args(lm);
         const int* user = lm->user_i32; int* tokens = lm->tokens;
         const uint16_t *emb = lm->emb, *temb = lm->text_emb; uint16_t* x = lm->x; const int NC = lm->NC, card1 = c.card + 1;
+        const int T = lm->T, xks = packed_ksteps(lm, d);
         P.add([=](hipStream_t s) {
             MMI_LAUNCH(k_lm_prepare, mmi_cdiv(B * NC, 128), 128, 0, s, t, user, n_user, tokens);
-            MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d);
+            MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d, T, xks);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
     }
     // ---- temporal transformer
-    const int NS = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    const int NS = attn_splits(c, B);
     const size_t kv_layer = (size_t)B * H * c.context * Dh;
+    int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
-        add_rmsnorm(lm, lm->x, L.n1, lm->xn, d);
-        add_gemm(lm, L.in_proj, lm->xn, lm->qkv, 3 * d, MMI_EPI_STORE, nullptr);
+        add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
         LmAttnArgs a;
-        a.qkv = lm->qkv; a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
+        a.qkv = nullptr; a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
+        a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
+        {   // in_proj with RoPE + ring-KV write in its epilogue
+            GemmArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
+            ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets; ga.H = H; ga.Dh = Dh; ga.cap = c.context;
+            ga.max_period = c.max_period;
+            GemmW gw = L.in_proj;
+            P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
+        }
         P.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_lm_rope_kv, B * H, 64, 0, s, a);
             int rc = launch_attn_split(s, a);
             if (rc) return rc;
-            MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, a);
+            if (a.NS > 1) MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, a);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
-        add_gemm(lm, L.out_proj, lm->att, lm->x, d, MMI_EPI_RESID, lm->x);
-        add_rmsnorm(lm, lm->x, L.n2, lm->xn, d);
-        add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
-        add_gemm(lm, L.ffn_out, lm->hb, lm->x, d, MMI_EPI_RESID, lm->x);
+        pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
+        add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d);
+        add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
+        pending = add_gemm_resid(lm, L.ffn_out, lm->hb, lm->x, d);
     }
-    add_rmsnorm(lm, lm->x, lm->out_norm, lm->tout, d);
-    add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, MMI_EPI_STORE, nullptr);
+    add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
+    add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr);
     add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1);
     // ---- depformer: dep_q sequential micro-steps
     const size_t dkv_layer = (size_t)B * Hd * c.dep_q * Dhd;
     for (int k = 0; k < c.dep_q; ++k) {
         const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
         const int prev_stride = k == 0 ? 1 : c.dep_q;
-        add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
+        add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
-            add_rmsnorm(lm, lm->dx, L.n1, lm->dxn, dd);
-            add_gemm(lm, L.in_proj[k], lm->dxn, lm->dqkv, 3 * dd, MMI_EPI_STORE, nullptr);
+            add_resid_rmsnorm(lm, lm->dx, 0, L.n1, lm->dxn, dd);
+            add_gemm(lm, L.in_proj[k], lm->dxn, lm->dqkv, 3 * dd, false, MMI_EPI_STORE, nullptr);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
+            da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
             P.add([=](hipStream_t s) {
                 MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
-            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, MMI_EPI_RESID, lm->dx);
-            add_rmsnorm(lm, lm->dx, L.n2, lm->dxn, dd);
-            add_gemm(lm, L.ffn_in[k], lm->dxn, lm->dhb, c.depformer_ffn_hidden, MMI_EPI_GATE, nullptr);
-            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, MMI_EPI_RESID, lm->dx);
+            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            add_resid_rmsnorm(lm, lm->dx, 0, L.n2, lm->dxn, dd);
+            add_gemm(lm, L.ffn_in[k], lm->dxn, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr);
+            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
-        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, MMI_EPI_STORE, nullptr);
+        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr);
         add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q);
     }
     // ---- token ring out
@@ -328,7 +407,11 @@ int check_cfg(const mmi_lm_cfg& c) {
     const int Dh = c.dim / c.num_heads, Dhd = c.depformer_dim / c.depformer_num_heads;
     if (Dh != 32 && Dh != 64 && Dh != 128) return mmi_fail(MMI_ERR_UNSUPPORTED, "temporal head dim must be 32/64/128");
     if (Dhd > 64 || Dhd < 1) return mmi_fail(MMI_ERR_UNSUPPORTED, "depformer head dim must be <= 64");
+    if (c.card % 8 || c.text_card_out % 8 || c.card > 32768 || c.text_card_out > 32768)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "vocabulary sizes must be multiples of 8 and at most 32768");
     if (c.dep_q < 1 || c.dep_q > 16 || c.n_q < c.dep_q || c.n_q + 1 > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "bad n_q / dep_q");
+    if (c.dim > 8 * 1024 * MMI_NORM_MAXP || c.depformer_dim > 8 * 1024 * MMI_NORM_MAXP)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "model width above the RMSNorm kernel's register budget");
     if (c.dim % 8 || c.depformer_dim % 8 || c.ffn_hidden % 8 || c.depformer_ffn_hidden % 8)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "feature sizes must be multiples of 8");
     return MMI_OK;
@@ -348,6 +431,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     mmi_lm* lm = new mmi_lm();
     lm->cfg = *cfg;
     lm->max_batch = max_batch;
+    lm->T = max_batch <= 16 ? 16 : 32;
     lm->use_graph = mmi_graphs_enabled();
     const mmi_lm_cfg& c = lm->cfg;
     lm->NC = c.n_q + 1;
@@ -437,7 +521,7 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     if (lm->kmax < 1) lm->kmax = 1;
     lm->offset_cpu = 0;
     const int B = batch, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
-    const int NS = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    const int NS = attn_splits(c, B);
     auto fail = [&](int code) { lm->streaming = true; mmi_lm_streaming_stop(lm); return code; };
     MmiArena& A = lm->st;
     const size_t kvn = (size_t)c.num_layers * B * H * c.context * Dh;
@@ -451,23 +535,23 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     ok &= hipSuccess == A.alloc(&lm->text_tok, (size_t)B);
     ok &= hipSuccess == A.alloc(&lm->audio_tok, (size_t)B * c.dep_q);
     ok &= hipSuccess == A.alloc(&lm->out_i32, (size_t)B * (c.dep_q + 1));
-    ok &= hipSuccess == A.alloc(&lm->x, (size_t)B * d);
-    ok &= hipSuccess == A.alloc(&lm->xn, (size_t)B * d);
-    ok &= hipSuccess == A.alloc(&lm->qkv, (size_t)B * 3 * d);
+    ok &= hipSuccess == A.alloc(&lm->x, packed_elems(lm, d));
+    ok &= hipSuccess == A.alloc(&lm->xn, packed_elems(lm, d));
     ok &= hipSuccess == A.alloc(&lm->qrot, (size_t)B * d);
-    ok &= hipSuccess == A.alloc(&lm->att, (size_t)B * d);
-    ok &= hipSuccess == A.alloc(&lm->hb, (size_t)B * c.ffn_hidden);
-    ok &= hipSuccess == A.alloc(&lm->tout, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->att, packed_elems(lm, d));
+    ok &= hipSuccess == A.alloc(&lm->hb, packed_elems(lm, c.ffn_hidden));
+    ok &= hipSuccess == A.alloc(&lm->tout, packed_elems(lm, d));
     ok &= hipSuccess == A.alloc(&lm->text_logits, (size_t)B * c.text_card_out);
     ok &= hipSuccess == A.alloc(&lm->kc, kvn);
     ok &= hipSuccess == A.alloc(&lm->vc, kvn);
     ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
-    ok &= hipSuccess == A.alloc(&lm->dx, (size_t)B * dd);
-    ok &= hipSuccess == A.alloc(&lm->dxn, (size_t)B * dd);
+    ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
+    ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
+    ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);
-    ok &= hipSuccess == A.alloc(&lm->datt, (size_t)B * dd);
-    ok &= hipSuccess == A.alloc(&lm->dhb, (size_t)B * c.depformer_ffn_hidden);
+    ok &= hipSuccess == A.alloc(&lm->datt, packed_elems(lm, dd));
+    ok &= hipSuccess == A.alloc(&lm->dhb, packed_elems(lm, c.depformer_ffn_hidden));
     ok &= hipSuccess == A.alloc(&lm->dlogits, (size_t)c.dep_q * B * c.card);
     ok &= hipSuccess == A.alloc(&lm->dkc, dkvn);
     ok &= hipSuccess == A.alloc(&lm->dvc, dkvn);
@@ -487,6 +571,11 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
     lm->forced_armed = false;
+    {   // packed activations: the padding rows / columns of a fragment are never written and must read as zero
+        struct { uint16_t* p; int f; } pk[] = {{lm->x, d}, {lm->xn, d}, {lm->att, d}, {lm->hb, c.ffn_hidden}, {lm->tout, d},
+                                               {lm->dx, dd}, {lm->dxn, dd}, {lm->datt, dd}, {lm->dhb, c.depformer_ffn_hidden}};
+        for (auto& e : pk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, packed_elems(lm, e.f) * sizeof(uint16_t), s));
+    }
     MMI_HIP_CHECK(hipMemsetAsync(lm->text_tok, 0, B * sizeof(int), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->audio_tok, 0, (size_t)B * c.dep_q * sizeof(int), s));
     unsigned long long r0[2] = {sampling->seed, 0ull};

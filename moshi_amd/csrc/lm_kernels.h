@@ -16,10 +16,27 @@
 #include "mmi_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// weight packing
+// fragment-packed layouts
 // ------------------------------------------------------------------------------------------------
+// Every GEMM of the step is out[b][n] = sum_k x[b][k] * W[n][k] with a handful of batch rows (B <= 64) and weights
+// that are read exactly once per step, i.e. an HBM stream.  Both operands are kept in HBM in the order the MFMA
+// wants them in registers, so that one wave instruction (16 bytes per lane) is one contiguous, fully coalesced
+// 1 KiB read that feeds one MFMA without any shuffling:
+//   T = 32 (v_mfma_f32_32x32x16_bf16, 17..64 sessions): k-step = 16; lane l holds rows/cols (l & 31), k = 8*(l>>5)+e
+//   T = 16 (v_mfma_f32_16x16x32_bf16, <= 16 sessions) : k-step = 32; lane l holds rows/cols (l & 15), k = 8*(l>>4)+e
+//   weights     Wp[nt][ks][lane][e] = W[nt*T + (l & (T-1))][ks*KS + 8*(l / T) + e]            (zero padded)
+//   activations Xp[mt][ks][lane][e] = x[mt*T + (l & (T-1))][ks*KS + 8*(l / T) + e]            (zero padded)
+// A GEMM epilogue writes its result straight into the packed layout of the GEMM that consumes it.
+MMI_HD long mmi_xp_index(int T, int b, int k, int ksteps) {
+    const int sh = T == 32 ? 4 : 5;                 // log2(k-step)
+    const int mt = b / T, bl = b - mt * T;
+    const int ks = k >> sh, kq = (k >> 3) & ((1 << (sh - 3)) - 1), e = k & 7;
+    return ((((long)mt * ksteps + ks) * 64) + kq * T + bl) * 8 + e;
+}
+static inline int mmi_kstep(int T) { return T == 32 ? 16 : 32; }
+
 // gate_hidden == 0: plain [N][K] matrix.  gate_hidden == H: rows [0,H) are gates, [H,2H) values; tile nt carries
-// gate rows nt*TN/2 .. and, in its second half, the matching value rows.
+// gate rows nt*TN/2 .. and, in its second half, the matching value rows (so the epilogue forms silu(g)*u locally).
 __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restrict__ P, int N, int K, int TN, int NT,
                               int KSTEPS, int gate_hidden) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,155 +67,310 @@ __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMM: out[b][n] = sum_k x[b][k] * W[n][k], B <= 16*MT (TN=16) or 32*MT (TN=32) rows, weights streamed once
+// weight-streaming skinny GEMM
 // ------------------------------------------------------------------------------------------------
-enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3 };
+// grid.x = groups of NTW n-tiles; the block's WAVES waves split K (contiguous slices), each wave streams its slice of
+// the NTW weight tiles with U fragments per tile in flight in each of two register buffers (explicit double
+// buffering: the loads of group g+1 are issued before the MFMAs of group g), reading the matching activation
+// fragments from L2.  The waves' partial tiles are summed through LDS in a fixed order (deterministic), and the
+// epilogue (bf16 rounding point of nn.Linear, residual add, SiLU gate, embedding add) writes 8 consecutive features
+// of one session as one 16-byte vector.
+enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5 };
+enum { MMI_OUT_ROWMAJOR = 0, MMI_OUT_PACKED = 1 };
 
 struct GemmArgs {
-    const u32x4* wp;        // packed weights
-    const uint16_t* x;      // [B][K] bf16
-    uint16_t* out;          // [B][out_ld] bf16
-    const uint16_t* resid;  // EPI_RESID: [B][out_ld]
+    const u32x4* wp;        // packed weights [NT][KSTEPS][64]
+    const u32x4* xp;        // packed activations [MT][KSTEPS][64]
+    uint16_t* out;          // row-major [B][out_ld] or packed [.][out_ksteps][64][8]
+    const uint16_t* resid;  // EPI_RESID: same geometry as out
     const uint16_t* emb;    // EPI_EMB: embedding table [rows][N]
-    const int* tok;         // EPI_EMB: token per row, tok[b * tok_stride]
+    const int* tok;         // EPI_EMB: token per session, tok[b * tok_stride]
     int tok_stride;
-    int B, N, K, KSTEPS, out_ld;
+    int B, N, KSTEPS, NT;
+    int out_mode, out_ld, out_ksteps;
     int epi;
+    float* partial;         // EPI_PARTIAL: fp32 partial sums [gridDim.y][B][N] (K split over gridDim.y workgroups so that
+                            // GEMMs with few n-tiles still cover every CU); summed by k_resid_rmsnorm
+    // EPI_ROPE_KV (temporal in_proj): features [q | k | v], each H heads x Dh.  RoPE (rope.py:11-82, interleaved, fp32) on
+    // q and k for the single new position offsets[b]; q -> qrot [B][H][Dh]; k, v -> ring slot offsets[b] % cap of
+    // [B][H][cap][Dh] (RingKVCache scatter, transformer.py:243-250: written for every row, exec mask or not)
+    uint16_t* qrot;
+    uint16_t* kc;
+    uint16_t* vc;
+    const long* offsets;
+    int H, Dh, cap;
+    float max_period;
 };
 
-template <int TN, int MT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_bf16(GemmArgs a) {
+template <int TN, int MT, int NTW, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
-    constexpr int BT = TN;                        // batch rows per MFMA tile
-    constexpr int KS = TN == 32 ? 16 : 32;        // k per MFMA
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt = blockIdx.x;
-    const int il = TN == 32 ? (lane & 31) : (lane & 15);
-    const int kq = TN == 32 ? (lane >> 5) : (lane >> 4);
+    const int nt0 = (int)blockIdx.x * NTW;
 
-    const uint16_t* xr[MT];
-    bool xv[MT];
+    // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
+    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
+    const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;
+    const int ks0 = min(kb1, kb0 + wave * kper);
+    const int nks = min(kb1, ks0 + kper) - ks0;
+
+    const u32x4* wp[NTW];
+    const u32x4* xp[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int b = mt * BT + il;
-        xv[mt] = b < a.B;
-        xr[mt] = a.x + (long)(xv[mt] ? b : 0) * a.K + 8 * kq;
+    for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * 64 + lane;
+
+    acc_t acc[NTW][MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[t][m][r] = 0.f;
+
+    u32x4 wA[U][NTW], xA[U][MT], wB[U][NTW], xB[U][MT];
+#define MMI_G_LOAD(W_, X_, base)                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) X_[u][m] = xp[m][((base) + u) * 64];  \
     }
-    const int kper = (a.KSTEPS + WAVES - 1) / WAVES;
-    const int ks0 = wave * kper;
-    const int ks1 = min(a.KSTEPS, ks0 + kper);
-
-    acc_t acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[mt][r] = 0.f;
-
-    const u32x4* wp = a.wp + ((long)nt * a.KSTEPS + ks0) * 64 + lane;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll 4
-    for (int ks = ks0; ks < ks1; ++ks) {
-        u32x4 wv = mmi_load_nt(wp);
-        wp += 64;
-        const int k = ks * KS + 8 * kq;
-        const bool kin = k < a.K;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            u32x4 xf = zero;
-            if (xv[mt] && kin) xf = *reinterpret_cast<const u32x4*>(xr[mt] + ks * KS);
-            if constexpr (TN == 32) acc[mt] = mmi_mfma_bf16_32x32x16(wv, xf, acc[mt]);
-            else acc[mt] = mmi_mfma_bf16_16x16x32(wv, xf, acc[mt]);
+#define MMI_G_MMA(W_, X_)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                       \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
+                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(W_[u][t], X_[u][m], acc[t][m]); \
+                else acc[t][m] = mmi_mfma_bf16_16x16x32(W_[u][t], X_[u][m], acc[t][m]);      \
+            }
+    const int nfull = nks / U;
+    if (nfull > 0) {
+        // steady state has no conditional loads, so that the compiler's s_waitcnt vmcnt(N) before each MFMA only waits
+        // for the older buffer and the loads of the next group stay in flight behind it
+        MMI_G_LOAD(wA, xA, 0);
+        int g = 0;
+        for (; g + 2 < nfull; g += 2) {
+            MMI_G_LOAD(wB, xB, (g + 1) * U);
+            MMI_G_MMA(wA, xA);
+            MMI_G_LOAD(wA, xA, (g + 2) * U);
+            MMI_G_MMA(wB, xB);
+        }
+        if (nfull - g == 2) {
+            MMI_G_LOAD(wB, xB, (g + 1) * U);
+            MMI_G_MMA(wA, xA);
+            MMI_G_MMA(wB, xB);
+        } else {
+            MMI_G_MMA(wA, xA);
         }
     }
+    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U k-steps)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wA[0][t] = mmi_load_nt(wp[t] + ks * 64);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xA[0][m] = xp[m][ks * 64];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(wA[0][t], xA[0][m], acc[t][m]);
+                else acc[t][m] = mmi_mfma_bf16_16x16x32(wA[0][t], xA[0][m], acc[t][m]);
+            }
+    }
+#undef MMI_G_LOAD
+#undef MMI_G_MMA
 
-    // split-K reduction across the block's waves (fixed order -> deterministic), then the epilogue
-    MMI_SHARED float red[WAVES * MT * R * 64];
+    // ---- split-K reduction across the block's waves (fixed order -> deterministic)
+    constexpr int NE = NTW * MT * R * 64;
+    MMI_SHARED float red[WAVES * NE];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-        for (int r = 0; r < R; ++r) red[((wave * MT + mt) * R + r) * 64 + lane] = acc[mt][r];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) red[wave * NE + ((t * MT + m) * R + r) * 64 + lane] = acc[t][m][r];
     __syncthreads();
-    constexpr int NE = MT * R * 64;
-    for (int e = (int)threadIdx.x; e < NE; e += WAVES * 64) {
-        const int le = e & 63;
-        const int r = (e >> 6) % R;
-        const int mt = (e >> 6) / R;
-        int i, j;
-        if (TN == 32) { i = (r & 3) + 8 * (r >> 2) + 4 * (le >> 5); j = le & 31; }
-        else { i = 4 * (le >> 4) + r; j = le & 15; }
-        const int b = mt * BT + j;
-        if (b >= a.B) continue;
-        float s = 0.f;
+
+    // ---- epilogue: one task = 8 consecutive output features of one session
+    const bool gate = a.epi == MMI_EPI_GATE;
+    const int rows_out = gate ? TN / 2 : TN;         // output features per tile
+    const int G = rows_out / 8;                      // feature groups per tile
+    const int ntasks = NTW * MT * G * TN;
+    for (int q = (int)threadIdx.x; q < ntasks; q += WAVES * 64) {
+        const int bl = q % TN;
+        int rest = q / TN;
+        const int gi = rest % G;
+        rest /= G;
+        const int m = rest % MT, t = rest / MT;
+        const int nt = nt0 + t;
+        const int b = m * TN + bl;
+        const int n0 = nt * rows_out + 8 * gi;
+        if (nt >= a.NT || b >= a.B || n0 >= a.N) continue;
+        const float* rb = red + (t * MT + m) * R * 64;
+        float s[8], s2[8];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += red[w * NE + e];
-        if (a.epi == MMI_EPI_GATE) {
-            if (i >= TN / 2) continue;
-            const int n = nt * (TN / 2) + i;
-            if (n >= a.N) continue;
-            // partner (value) element: same lane, r+8 (TN=32) or lane+32 (TN=16)
-            const int e2 = TN == 32 ? e + 8 * 64 : e + 32;
-            float u = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int i = 8 * gi + e;
+            int r, ln, r2, ln2;
+            if constexpr (TN == 32) {
+                r = (i & 3) + 4 * (i >> 3); ln = bl + 32 * ((i >> 2) & 1);
+                const int i2 = i + 16;
+                r2 = (i2 & 3) + 4 * (i2 >> 3); ln2 = bl + 32 * ((i2 >> 2) & 1);
+            } else {
+                r = i & 3; ln = bl + 16 * (i >> 2);
+                const int i2 = (i + 8) & 15;
+                r2 = i2 & 3; ln2 = bl + 16 * (i2 >> 2);
+            }
+            float v = 0.f, v2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) u += red[w * NE + e2];
-            const float g = mmi_round_bf16(s);
-            u = mmi_round_bf16(u);
-            const float act = mmi_round_bf16(g / (1.0f + expf(-g)));     // F.silu on a bf16 tensor
-            a.out[(long)b * a.out_ld + n] = mmi_f32_to_bf16(act * u);
+            for (int w = 0; w < WAVES; ++w) v += rb[w * NE + r * 64 + ln];
+            if (gate) {
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) v2 += rb[w * NE + r2 * 64 + ln2];
+            }
+            s[e] = v; s2[e] = v2;
+        }
+        if (a.epi == MMI_EPI_PARTIAL) {
+            float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
+            f32x4 lo = {s[0], s[1], s[2], s[3]}, hi = {s[4], s[5], s[6], s[7]};
+            *reinterpret_cast<f32x4*>(pd) = lo;
+            *reinterpret_cast<f32x4*>(pd + 4) = hi;
             continue;
         }
-        const int n = nt * TN + i;
-        if (n >= a.N) continue;
-        float v = mmi_round_bf16(s);                                      // nn.Linear output in bf16
-        if (a.epi == MMI_EPI_RESID) {
-            v = v + mmi_bf16_to_f32(a.resid[(long)b * a.out_ld + n]);     // x_orig + update
-        } else if (a.epi == MMI_EPI_EMB) {
-            int t = a.tok[(long)b * a.tok_stride];
-            float ev = 0.f;
-            if (t != -1) ev = mmi_bf16_to_f32(a.emb[(long)(t < 0 ? 0 : t) * a.N + n]);   // lm_utils.py:102-124
-            v = v + ev;
+        if (a.epi == MMI_EPI_ROPE_KV) {
+            const int HD = a.H * a.Dh;
+            const int sec = n0 / HD, hn = n0 - sec * HD, h = hn / a.Dh, d0 = hn - h * a.Dh;
+            const long off = a.offsets[b];
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = mmi_round_bf16(s[e]);          // in_proj output is a bf16 tensor
+            if (sec < 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float freq = expf((float)(d0 / 2 + j) * (-logf(a.max_period) * 2.0f / (float)a.Dh));
+                    const float ang = freq * (float)off;
+                    const float c = cosf(ang), sn = sinf(ang);
+                    const float re = v8[2 * j], im = v8[2 * j + 1];
+                    v8[2 * j] = re * c - im * sn;
+                    v8[2 * j + 1] = re * sn + im * c;
+                }
+            }
+            uint16_t* dst;
+            if (sec == 0) dst = a.qrot + (long)b * HD + hn;
+            else dst = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.Dh + d0;
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)mmi_f32_to_bf16(v8[2 * e]) | ((uint32_t)mmi_f32_to_bf16(v8[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(dst) = ov;
+            continue;
         }
-        a.out[(long)b * a.out_ld + n] = mmi_f32_to_bf16(v);
+        uint16_t* dst = a.out_mode == MMI_OUT_PACKED ? a.out + mmi_xp_index(TN, b, n0, a.out_ksteps)
+                                                     : a.out + (long)b * a.out_ld + n0;
+        float o[8];
+        if (gate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = mmi_round_bf16(s[e]);
+                const float u = mmi_round_bf16(s2[e]);
+                const float act = mmi_round_bf16(g / (1.0f + expf(-g)));   // F.silu on a bf16 tensor
+                o[e] = act * u;
+            }
+        } else if (a.epi == MMI_EPI_RESID) {
+            const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps)
+                                                              : a.resid + (long)b * a.out_ld + n0;
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(rs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t h = (uint16_t)((e & 1) ? (rv[e >> 1] >> 16) : (rv[e >> 1] & 0xffffu));
+                o[e] = mmi_round_bf16(s[e]) + mmi_bf16_to_f32(h);           // x_orig + update
+            }
+        } else if (a.epi == MMI_EPI_EMB) {
+            const int tk = a.tok[(long)b * a.tok_stride];
+            u32x4 ev = {0u, 0u, 0u, 0u};
+            if (tk != -1) ev = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint16_t h = (uint16_t)((e & 1) ? (ev[e >> 1] >> 16) : (ev[e >> 1] & 0xffffu));
+                o[e] = mmi_round_bf16(s[e]) + mmi_bf16_to_f32(h);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = s[e];                         // nn.Linear output in bf16
+        }
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)mmi_f32_to_bf16(o[2 * e]) | ((uint32_t)mmi_f32_to_bf16(o[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4*>(dst) = ov;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // RMSNorm (rms_norm_f32, eps 1e-8): y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rmsnorm_bf16(const uint16_t* __restrict__ x, const uint16_t* __restrict__ alpha,
-                                                      uint16_t* __restrict__ y, int D, float eps) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const uint16_t* xr = x + (long)b * D;
+// One block per session row b; thread t owns the 16-byte piece (8 features) t, t + blockDim, ... of the packed row
+// (launch with blockDim = D/8 up to 1024 so that a row is a single round of loads held in registers).
+// P > 0: first finish the preceding split-K GEMM (out_proj / linear_out) and its residual connection,
+//        x <- x + bf16(sum_p partial[p][b][:])      (transformer.py:739-741,772-776: x_orig + update, bf16 tensors)
+// then   y <- rms_norm_f32(x) * alpha               (transformer.py:45-58)
+#define MMI_NORM_MAXP 4      // pieces per thread kept in registers (D <= 8 * 1024 * MMI_NORM_MAXP)
+__global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x, const float* __restrict__ partial, int P,
+                                                        int B, const uint16_t* __restrict__ alpha, uint16_t* __restrict__ y,
+                                                        int D, int T, int ksteps, float eps) {
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    float f[MMI_NORM_MAXP][8];
+    u32x4 al[MMI_NORM_MAXP];
     float ss = 0.f;
-    for (int i = tid * 8; i < D; i += 256 * 8) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        const long at = mmi_xp_index(T, b, i, ksteps);
+        u32x4 v = *reinterpret_cast<const u32x4*>(x + at);
+        al[j] = *reinterpret_cast<const u32x4*>(alpha + i);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float lo = mmi_bf16_to_f32((uint16_t)(v[q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(v[q] >> 16));
-            ss += lo * lo;
-            ss += hi * hi;
+            f[j][2 * q] = mmi_bf16_to_f32((uint16_t)(v[q] & 0xffffu));
+            f[j][2 * q + 1] = mmi_bf16_to_f32((uint16_t)(v[q] >> 16));
         }
+        if (P > 0) {
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float* pp = partial + ((long)p * B + b) * D + i;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u[e] += lo[e]; u[4 + e] += hi[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[j][e] = mmi_round_bf16(mmi_round_bf16(u[e]) + f[j][e]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (uint32_t)mmi_f32_to_bf16(f[j][2 * q]) | ((uint32_t)mmi_f32_to_bf16(f[j][2 * q + 1]) << 16);
+            *reinterpret_cast<u32x4*>(x + at) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += f[j][e] * f[j][e];
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) ss += mmi_shfl_xor(ss, m);
-    MMI_SHARED float red[4];
+    MMI_SHARED float red[16];
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    float tot = 0.f;
+    for (int w = 0; w < (nth + 63) / 64; ++w) tot += red[w];
     const float rs = mmi_rsqrtf(eps + tot / (float)D);
-    uint16_t* yr = y + (long)b * D;
-    for (int i = tid * 8; i < D; i += 256 * 8) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
-        u32x4 al = *reinterpret_cast<const u32x4*>(alpha + i);
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float lo = mmi_bf16_to_f32((uint16_t)(v[q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(v[q] >> 16));
-            float alo = mmi_bf16_to_f32((uint16_t)(al[q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[q] >> 16));
-            uint32_t olo = mmi_f32_to_bf16(lo * (alo * rs)), ohi = mmi_f32_to_bf16(hi * (ahi * rs));
+            float alo = mmi_bf16_to_f32((uint16_t)(al[j][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[j][q] >> 16));
+            uint32_t olo = mmi_f32_to_bf16(f[j][2 * q] * (alo * rs)), ohi = mmi_f32_to_bf16(f[j][2 * q + 1] * (ahi * rs));
             o[q] = olo | (ohi << 16);
         }
-        *reinterpret_cast<u32x4*>(yr + i) = o;
+        *reinterpret_cast<u32x4*>(y + mmi_xp_index(T, b, i, ksteps)) = o;
     }
 }
 
@@ -206,7 +378,8 @@ __global__ __launch_bounds__(256) void k_rmsnorm_bf16(const uint16_t* __restrict
 // input embedding sum (lm.py:388-397): ((emb0[t1] + emb1[t2]) + ...) + text_emb[t0], each add rounded to bf16
 // ------------------------------------------------------------------------------------------------
 __global__ void k_lm_embed(const int* __restrict__ tokens, int n_codebooks, const uint16_t* __restrict__ emb,
-                           int card1, const uint16_t* __restrict__ text_emb, uint16_t* __restrict__ x, int D) {
+                           int card1, const uint16_t* __restrict__ text_emb, uint16_t* __restrict__ x, int D, int T,
+                           int ksteps) {
     const int b = blockIdx.y;
     const int d = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (d >= D) return;
@@ -222,7 +395,7 @@ __global__ void k_lm_embed(const int* __restrict__ tokens, int n_codebooks, cons
     float tv = 0.f;
     if (t0 != -1) tv = mmi_bf16_to_f32(text_emb[(long)(t0 < 0 ? 0 : t0) * D + d]);
     acc = n_codebooks > 1 ? mmi_round_bf16(acc + tv) : tv;
-    x[(long)b * D + d] = mmi_f32_to_bf16(acc);
+    x[mmi_xp_index(T, b, d, ksteps)] = mmi_f32_to_bf16(acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,57 +409,29 @@ struct LmAttnArgs {
     const long* offsets;   // [B]
     float* opart;          // [B][H][NS][Dh]
     float* ml;             // [B][H][NS][2]
-    uint16_t* out;         // [B][H*Dh]
+    uint16_t* out;         // packed (T, out_ksteps) activations of out_proj, feature = h*Dh + d
     int B, H, Dh, cap, context, NS;
+    int T, out_ksteps;
     float max_period;
 };
 
-// rope.py:11-82 (interleaved, fp32) for the single new position, then RingKVCache scatter (transformer.py:243-250)
-__global__ void k_lm_rope_kv(LmAttnArgs a) {
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int Dh = a.Dh, HD = a.H * Dh;
-    const long off = a.offsets[b];
-    const int slot = (int)(off % a.cap);
-    const uint16_t* row = a.qkv + (long)b * 3 * HD;
-    uint16_t* kdst = a.kc + (((long)b * a.H + h) * a.cap + slot) * Dh;
-    uint16_t* vdst = a.vc + (((long)b * a.H + h) * a.cap + slot) * Dh;
-    uint16_t* qdst = a.qrot + ((long)b * a.H + h) * Dh;
-    for (int j = threadIdx.x; j < Dh / 2; j += blockDim.x) {
-        float freq = expf((float)j * (-logf(a.max_period) * 2.0f / (float)Dh));
-        float ang = freq * (float)off;
-        float c = cosf(ang), s = sinf(ang);
-        float qr = mmi_bf16_to_f32(row[h * Dh + 2 * j]), qi = mmi_bf16_to_f32(row[h * Dh + 2 * j + 1]);
-        float kr = mmi_bf16_to_f32(row[HD + h * Dh + 2 * j]), ki = mmi_bf16_to_f32(row[HD + h * Dh + 2 * j + 1]);
-        qdst[2 * j] = mmi_f32_to_bf16(qr * c - qi * s);
-        qdst[2 * j + 1] = mmi_f32_to_bf16(qr * s + qi * c);
-        kdst[2 * j] = mmi_f32_to_bf16(kr * c - ki * s);
-        kdst[2 * j + 1] = mmi_f32_to_bf16(kr * s + ki * c);
-        vdst[2 * j] = row[2 * HD + h * Dh + 2 * j];
-        vdst[2 * j + 1] = row[2 * HD + h * Dh + 2 * j + 1];
-    }
-}
-
 #define MMI_ATTN_CHUNK 256
-// grid (B*H, NS); 256 threads.  Chunk c covers ring slots [c*256, c*256+256).  Each 16-byte load covers 8 dims of one
-// key row; DH/8 lanes share a row, so one wave instruction reads 64/(DH/8) consecutive rows = 1 KiB contiguous.
+// Decode attention of the one new query per (session, head) over the VALID part of the ring only (the reference reads
+// all `cap` slots through a mask, transformer.py:574-585).  grid (B*H, NS); 256 threads.  Block y walks the 256-slot
+// chunks y, y+NS, ... of the ring with an online softmax; each 16-byte load covers 8 dims of one key row, DH/8 lanes share
+// a row, so one wave instruction reads 64/(DH/8) consecutive rows = 1 KiB contiguous.  NS == 1 (enough (b,h) pairs to
+// fill the chip): the normalised output goes straight to out_proj's packed input; otherwise partials for the combine.
 template <int DH>
 __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     constexpr int LPR = DH / 8;        // lanes per row
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
     constexpr int CH = MMI_ATTN_CHUNK;
     const int bh = blockIdx.x, b = bh / a.H;
-    const int chunk = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long off = a.offsets[b];
     const long end_new = off + 1;
     const int end_index = (int)(off % a.cap);
     const int L = (int)(end_new < (long)a.cap ? end_new : (long)a.cap);
-    const int c0 = chunk * CH;
-    float* mlp = a.ml + ((long)bh * a.NS + chunk) * 2;
-    if (c0 >= L) {                      // nothing valid in this chunk (block-uniform)
-        if (tid == 0) { mlp[0] = -INFINITY; mlp[1] = 0.f; }
-        return;
-    }
     MMI_SHARED float sc[CH];
     MMI_SHARED float wred[8];
     MMI_SHARED float ored[4 * DH];
@@ -304,63 +449,73 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     const uint16_t* vbase = a.vc + (long)bh * a.cap * DH;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr int PER_WAVE = CH / 4;
-    // ---- scores
-    for (int it = 0; it < PER_WAVE / RPW; ++it) {
-        const int rl = wave * PER_WAVE + it * RPW + rsub;
-        const int slot = c0 + rl;
-        bool valid = slot < L;
-        if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
-            int delta = slot - end_index;
-            long pos = delta <= 0 ? off + delta : off + delta - a.cap;
-            long dq = off - pos;
-            valid = pos >= 0 && dq >= 0 && dq < a.context;
-        }
-        float dot = 0.f;
-        if (valid) {
-            u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + (long)slot * DH + seg * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dot += qv[2 * q] * mmi_bf16_to_f32((uint16_t)(kk[q] & 0xffffu));
-                dot += qv[2 * q + 1] * mmi_bf16_to_f32((uint16_t)(kk[q] >> 16));
-            }
-        }
-#pragma unroll
-        for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
-        if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
-    }
-    __syncthreads();
-    // ---- chunk softmax statistics
-    float s = sc[tid];
-    float mx = s;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, mmi_shfl_xor(mx, m));
-    if (lane == 0) wred[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    float p = (mx == -INFINITY) ? 0.f : expf(s - mx);
-    float sum = p;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) sum += mmi_shfl_xor(sum, m);
-    if (lane == 0) wred[4 + wave] = sum;
-    sc[tid] = p;
-    __syncthreads();
-    sum = (wred[4] + wred[5]) + (wred[6] + wred[7]);
-    // ---- P.V
+    float m_run = -INFINITY, l_run = 0.f;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int it = 0; it < PER_WAVE / RPW; ++it) {
-        const int rl = wave * PER_WAVE + it * RPW + rsub;
-        const int slot = c0 + rl;
-        const float pr = sc[rl];
-        if (pr != 0.f && slot < L) {
-            u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (long)slot * DH + seg * 8);
+    for (int c0 = (int)blockIdx.y * CH; c0 < L; c0 += (int)gridDim.y * CH) {     // block-uniform trip count
+        // ---- scores of this chunk
+        for (int it = 0; it < PER_WAVE / RPW; ++it) {
+            const int rl = wave * PER_WAVE + it * RPW + rsub;
+            const int slot = c0 + rl;
+            bool valid = slot < L;
+            if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
+                int delta = slot - end_index;
+                long pos = delta <= 0 ? off + delta : off + delta - a.cap;
+                long dq = off - pos;
+                valid = pos >= 0 && dq >= 0 && dq < a.context;
+            }
+            float dot = 0.f;
+            if (valid) {
+                u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + (long)slot * DH + seg * 8);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[2 * q] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] & 0xffffu));
-                acc[2 * q + 1] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] >> 16));
+                for (int q = 0; q < 4; ++q) {
+                    dot += qv[2 * q] * mmi_bf16_to_f32((uint16_t)(kk[q] & 0xffffu));
+                    dot += qv[2 * q + 1] * mmi_bf16_to_f32((uint16_t)(kk[q] >> 16));
+                }
+            }
+#pragma unroll
+            for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
+            if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
+        }
+        __syncthreads();
+        // ---- online softmax update
+        const float sv = sc[tid];
+        float mx = sv;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, mmi_shfl_xor(mx, m));
+        if (lane == 0) wred[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        const float m_new = fmaxf(m_run, mx);
+        const float p = (m_new == -INFINITY) ? 0.f : expf(sv - m_new);
+        float sum = p;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sum += mmi_shfl_xor(sum, m);
+        if (lane == 0) wred[4 + wave] = sum;
+        sc[tid] = p;
+        __syncthreads();
+        sum = (wred[4] + wred[5]) + (wred[6] + wred[7]);
+        const float resc = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        l_run = l_run * resc + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= resc;
+        // ---- P.V
+        for (int it = 0; it < PER_WAVE / RPW; ++it) {
+            const int rl = wave * PER_WAVE + it * RPW + rsub;
+            const int slot = c0 + rl;
+            const float pr = sc[rl];
+            if (pr != 0.f && slot < L) {
+                u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (long)slot * DH + seg * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] & 0xffffu));
+                    acc[2 * q + 1] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] >> 16));
+                }
             }
         }
+        __syncthreads();     // sc / wred are rewritten by the next chunk
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -372,10 +527,18 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     }
     __syncthreads();
     if (tid < DH) {
-        float o = (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]);
-        a.opart[((long)bh * a.NS + chunk) * DH + tid] = o;
+        const float o = (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]);
+        if (gridDim.y == 1) {
+            a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(o / l_run);
+        } else {
+            a.opart[((long)bh * gridDim.y + blockIdx.y) * DH + tid] = o;
+        }
     }
-    if (tid == 0) { mlp[0] = mx; mlp[1] = sum; }
+    if (gridDim.y > 1 && tid == 0) {
+        float* mlp = a.ml + ((long)bh * gridDim.y + blockIdx.y) * 2;
+        mlp[0] = m_run;
+        mlp[1] = l_run;
+    }
 }
 
 // merge the chunk partials: out = sum_c e^{m_c-M} O_c / sum_c e^{m_c-M} l_c  -> bf16 [B][H*Dh]
@@ -394,7 +557,7 @@ __global__ void k_lm_attn_combine(LmAttnArgs a) {
             num += w * a.opart[((long)bh * a.NS + c) * Dh + d];
             den += w * ml[2 * c + 1];
         }
-        a.out[(long)bh * Dh + d] = mmi_f32_to_bf16(num / den);
+        a.out[mmi_xp_index(a.T, bh / a.H, (bh % a.H) * Dh + d, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
     }
 }
 
@@ -407,8 +570,9 @@ struct DepAttnArgs {
     const uint16_t* qkv;   // [B][3*H*Dh]
     uint16_t* kc;          // [B][H][steps][Dh]
     uint16_t* vc;
-    uint16_t* out;         // [B][H*Dh]
+    uint16_t* out;         // packed (T, out_ksteps), feature = h*Dh + lane
     int B, H, Dh, steps, k;
+    int T, out_ksteps;
 };
 
 __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
@@ -447,7 +611,7 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
         if (on) vv = (j == a.k) ? mmi_bf16_to_f32(vn) : mmi_bf16_to_f32(vcb[(long)j * Dh + lane]);
         o += p * vv;
     }
-    if (on) a.out[(long)b * HD + h * Dh + lane] = mmi_f32_to_bf16(o / den);
+    if (on) a.out[mmi_xp_index(a.T, b, h * Dh + lane, a.out_ksteps)] = mmi_f32_to_bf16(o / den);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -522,29 +686,68 @@ __device__ __forceinline__ int mmi_block_excl_scan(int v, int* wsum /* [NT/64 + 
     return base + inc - v;
 }
 
-template <int NT>
+// One block per session; thread t owns the E consecutive vocabulary entries [t*E, t*E+E) (NT*E >= V; V and the row
+// stride multiples of 8), held packed in registers when CACHE (small vocabularies: the 8 depformer heads) or re-read
+// from L2 in every pass (the 32000-entry text head).  The logits are bf16, so the top-k threshold is a 16-bit radix
+// select (two 256-bin passes) on the order-preserving key of the logit - softmax is monotone in the logit - with ties
+// at the threshold resolved towards the lower index; the probabilities p = softmax(logits/temp) are NOT renormalised
+// over the top-k set (sampling.py:59-63,95-105), and the token is argmax_i p_i / q_rank(i), q ~ Exp(1) indexed by the
+// rank of i in the descending top-k order, exactly the reference's `multinomial` trick (sampling.py:32-46).
+__device__ __forceinline__ unsigned mmi_bf16_key(uint16_t h) {       // order-preserving: larger logit <-> larger key
+    return (h & 0x8000u) ? (unsigned)(uint16_t)~h : (unsigned)(h | 0x8000u);
+}
+
+template <int NT, int E, bool CACHE>
 __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint16_t* lg = a.logits + (long)b * a.ld;
     const int V = a.V;
     MMI_SHARED float redf[NT / 64];
     MMI_SHARED int redi[NT / 64];
+    MMI_SHARED int redr[NT / 64];
     MMI_SHARED int hist[256];
     MMI_SHARED int wsum[NT / 64 + 1];
     MMI_SHARED float sel_val[256];
+    MMI_SHARED __attribute__((aligned(16))) unsigned sel_cmp[256];   // (key << 16) | (0xffff - index): larger = earlier rank
     MMI_SHARED int sel_idx[256];
-    MMI_SHARED unsigned s_prefix;
+    MMI_SHARED int s_bin;
     MMI_SHARED int s_want;
     const int lane = tid & 63, wave = tid >> 6;
+    const int i0 = tid * E;
+    constexpr int NV = E / 8;
+
+    u32x4 cache[CACHE ? NV : 1];
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            cache[v] = u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};      // bf16 -inf
+            if (i0 + v * 8 < V) cache[v] = *reinterpret_cast<const u32x4*>(lg + i0 + v * 8);
+        }
+    }
+    // visit the thread's entries: BODY sees `i` (vocabulary index, < V) and `bits` (the bf16 logit)
+#define MMI_S_FOREACH(BODY)                                                                        \
+    {                                                                                              \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) {                                        \
+            if (i0 + v_ * 8 >= V) break;                                                           \
+            u32x4 r4_;                                                                             \
+            if constexpr (CACHE) r4_ = cache[v_];                                                  \
+            else r4_ = *reinterpret_cast<const u32x4*>(lg + i0 + v_ * 8);                          \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                     \
+                const int i = i0 + v_ * 8 + e_;                                                    \
+                const uint16_t bits = (uint16_t)((e_ & 1) ? (r4_[e_ >> 1] >> 16) : (r4_[e_ >> 1] & 0xffffu)); \
+                BODY                                                                               \
+            }                                                                                      \
+        }                                                                                          \
+    }
 
     if (!a.use_sampling || !(a.temp > 0.f)) {
         // torch.argmax(logits): first maximum
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int i = tid; i < V; i += NT) {
-            float v = mmi_bf16_to_f32(lg[i]);
-            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-        }
+        MMI_S_FOREACH({
+            const float v = mmi_bf16_to_f32(bits);
+            if (v > best || bi == 0x7fffffff) { best = v; bi = i; }
+        })
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             float ov = mmi_shfl_xor(best, m);
@@ -563,15 +766,16 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
 
     // ---- softmax statistics of logits / temp (fp32)
     float mx = -INFINITY;
-    for (int i = tid; i < V; i += NT) mx = fmaxf(mx, mmi_bf16_to_f32(lg[i]) / a.temp);
+    MMI_S_FOREACH({ mx = fmaxf(mx, mmi_bf16_to_f32(bits) / a.temp); })
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, mmi_shfl_xor(mx, m));
     if (lane == 0) redf[wave] = mx;
     __syncthreads();
-    for (int w = 0; w < NT / 64; ++w) mx = fmaxf(mx, redf[w]);
+    mx = redf[0];
+    for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, redf[w]);
     __syncthreads();
     float sum = 0.f;
-    for (int i = tid; i < V; i += NT) sum += expf(mmi_bf16_to_f32(lg[i]) / a.temp - mx);
+    MMI_S_FOREACH({ sum += expf(mmi_bf16_to_f32(bits) / a.temp - mx); })
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sum += mmi_shfl_xor(sum, m);
     if (lane == 0) redf[wave] = sum;
@@ -579,64 +783,75 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     sum = 0.f;
     for (int w = 0; w < NT / 64; ++w) sum += redf[w];
     __syncthreads();
-#define MMI_PROB(i) (expf(mmi_bf16_to_f32(lg[i]) / a.temp - mx) / sum)
 
-    // ---- radix select of the k-th largest probability (bit pattern of a non-negative float is monotonic)
+    // ---- radix select of the k-th largest key: high byte, then low byte
     const int k = a.k < V ? a.k : V;
-    if (tid == 0) { s_prefix = 0u; s_want = k; }
-    __syncthreads();
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 256; i += NT) hist[i] = 0;
+    int want = k;
+    unsigned Tkey = 0u;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = tid; j < 256; j += NT) hist[j] = 0;
         __syncthreads();
-        const unsigned prefix = s_prefix;
-        for (int i = tid; i < V; i += NT) {
-            unsigned bits = __builtin_bit_cast(unsigned, MMI_PROB(i));
-            bool match = shift == 24 ? true : ((bits >> (shift + 8)) == (prefix >> (shift + 8)));
-            if (match) mmi_atomic_add(reinterpret_cast<unsigned*>(&hist[(bits >> shift) & 255u]), 1u);
+        MMI_S_FOREACH({
+            const unsigned ky = mmi_bf16_key(bits);
+            if (pass == 0 || (ky >> 8) == (Tkey >> 8))
+                mmi_atomic_add(reinterpret_cast<unsigned*>(&hist[pass == 0 ? (ky >> 8) : (ky & 255u)]), 1u);
+        })
+        __syncthreads();
+        {   // bin holding the want-th largest key: thread t looks at bin 255-t; `above` = entries in higher bins
+            const int bin = 255 - tid;
+            const int cnt = tid < 256 ? hist[bin] : 0;
+            int total;
+            const int above = mmi_block_excl_scan<NT>(cnt, wsum, &total);
+            if (tid < 256 && above < want && want <= above + cnt) { s_bin = bin; s_want = want - above; }
         }
         __syncthreads();
-        if (tid == 0) {
-            int want = s_want, bin = 255, cum = 0;
-            for (; bin > 0; --bin) {
-                if (cum + hist[bin] >= want) break;
-                cum += hist[bin];
-            }
-            s_want = want - cum;
-            s_prefix = prefix | ((unsigned)bin << shift);
-        }
+        Tkey |= (unsigned)s_bin << (pass == 0 ? 8 : 0);
+        want = s_want;
         __syncthreads();
     }
-    const unsigned Tbits = s_prefix;   // bits of the k-th largest value
-    const int want_eq = s_want;        // how many elements equal to it belong to the top-k (lowest indices first)
+    const int want_eq = want;          // how many entries equal to the threshold belong to the set (lowest indices first)
 
-    // ---- ordered compaction of the top-k set (index order; ties at the threshold resolved by index)
-    int n_sel = 0, n_eq = 0;
-    for (int base = 0; base < V; base += NT) {
-        const int i = base + tid;
-        unsigned bits = 0;
-        float pv = 0.f;
-        if (i < V) { pv = MMI_PROB(i); bits = __builtin_bit_cast(unsigned, pv); }
-        const int is_eq = (i < V && bits == Tbits) ? 1 : 0;
-        int tot_eq;
-        const int eq_pos = n_eq + mmi_block_excl_scan<NT>(is_eq, wsum, &tot_eq);
-        const int take = (i < V && (bits > Tbits || (is_eq && eq_pos < want_eq))) ? 1 : 0;
-        int tot_take;
-        const int pos = n_sel + mmi_block_excl_scan<NT>(take, wsum, &tot_take);
-        if (take && pos < 256) { sel_val[pos] = pv; sel_idx[pos] = i; }
-        n_eq += tot_eq;
-        n_sel += tot_take;
-    }
+    // ---- ordered compaction of the top-k set (index order)
+    int n_gt = 0, n_eq = 0;
+    MMI_S_FOREACH({
+        const unsigned ky = mmi_bf16_key(bits);
+        n_gt += ky > Tkey ? 1 : 0;
+        n_eq += ky == Tkey ? 1 : 0;
+    })
+    int tot;
+    const int eq_base = mmi_block_excl_scan<NT>(n_eq, wsum, &tot);
+    int eq_take = want_eq - eq_base;
+    eq_take = eq_take < 0 ? 0 : (eq_take > n_eq ? n_eq : eq_take);
+    int pos = mmi_block_excl_scan<NT>(n_gt + eq_take, wsum, &tot);
+    int eq_seen = 0;
+    MMI_S_FOREACH({
+        const unsigned ky = mmi_bf16_key(bits);
+        bool take = ky > Tkey;
+        if (ky == Tkey) { take = eq_seen < eq_take; ++eq_seen; }
+        if (take) {
+            if (pos < 256) {
+                sel_val[pos] = expf(mmi_bf16_to_f32(bits) / a.temp - mx) / sum;
+                sel_cmp[pos] = (ky << 16) | (unsigned)(0xffff - i);
+                sel_idx[pos] = i;
+            }
+            ++pos;
+        }
+    })
+#undef MMI_S_FOREACH
     __syncthreads();
-    // ---- rank inside the set (descending value, then index) and the noisy argmax
+    // ---- rank inside the set (descending logit, then index) and the noisy argmax
     float score = -INFINITY;
     int rank = 0x7fffffff, tok = 0;
+    for (int j = k + tid; j < 256; j += NT) sel_cmp[j] = 0u;      // entries past the set never outrank anything
+    __syncthreads();
     if (tid < k && tid < 256) {
         const float v = sel_val[tid];
+        const unsigned mine = sel_cmp[tid];
         const int id = sel_idx[tid];
         int r = 0;
-        for (int m = 0; m < k; ++m) {
-            float ov = sel_val[m];
-            r += (ov > v || (ov == v && sel_idx[m] < id)) ? 1 : 0;
+        for (int m = 0; m < k; m += 4) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(&sel_cmp[m]);
+            r += (o[0] > mine ? 1 : 0) + (o[1] > mine ? 1 : 0) + (o[2] > mine ? 1 : 0) + (o[3] > mine ? 1 : 0);
         }
         float q;
         if (*a.use_noise) q = a.noise[(long)b * a.noise_ld + r];
@@ -651,7 +866,6 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         int orank = mmi_shfl_xor(rank, m), otok = mmi_shfl_xor(tok, m);
         if (os > score || (os == score && orank < rank)) { score = os; rank = orank; tok = otok; }
     }
-    MMI_SHARED int redr[NT / 64];
     if (lane == 0) { redf[wave] = score; redi[wave] = tok; redr[wave] = rank; }
     __syncthreads();
     if (tid == 0) {
@@ -659,7 +873,6 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
             if (redf[w] > score || (redf[w] == score && redr[w] < rank)) { score = redf[w]; rank = redr[w]; tok = redi[w]; }
         a.out[(long)b * a.out_stride] = mmi_apply_forced(a, b, tok);
     }
-#undef MMI_PROB
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,116 @@
+// Microbenchmark of the weight-streaming skinny GEMM (moshi_amd/csrc/lm_kernels.h: k_gemm_xp) on the Moshi-7B
+// layer shapes: sweeps workgroup shapes (waves per workgroup, n-tiles per wave, fragments in flight) and prints the
+// achieved weight-streaming rate.  Weights cycle through enough distinct buffers (> 1 GiB) that the 256 MiB
+// Infinity Cache cannot serve them.  Measurement tool only - the product picks its plan in lm_engine.hip:plan_gemm.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Imoshi_amd/csrc scripts/gemm_microbench.hip \
+//         moshi_amd/csrc/api_common.hip -o gpurun_out/gemm_microbench && gpurun_out/gemm_microbench [B]
+#include "lm_kernels.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } \
+    } while (0)
+
+__global__ void k_fill_rand_bf16(uint16_t* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        float f = ((float)(h & 0xffff) / 65536.0f - 0.5f) * 0.05f;
+        p[i] = mmi_f32_to_bf16(f);
+    }
+}
+
+struct Shape { const char* name; int N, K, gate; };
+
+typedef void (*launch_fn)(dim3 groups, hipStream_t s, const GemmArgs& a);
+struct Variant { const char* name; int TN, MT, NTW, WAVES, U; launch_fn fn; };
+
+template <int TN, int MT, int NTW, int WAVES, int U>
+void launch_v(dim3 groups, hipStream_t s, const GemmArgs& a) {
+    hipLaunchKernelGGL((k_gemm_xp<TN, MT, NTW, WAVES, U>), groups, dim3(WAVES * 64), 0, s, a);
+}
+#define V(TN, MT, NTW, WAVES, U) {#TN "x" #MT " ntw" #NTW " w" #WAVES " u" #U, TN, MT, NTW, WAVES, U, launch_v<TN, MT, NTW, WAVES, U>}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 32;
+    const int ksplit = argc > 2 ? atoi(argv[2]) : 1;   // > 1: the residual GEMMs run split-K with fp32 partial output
+    const int T = B <= 16 ? 16 : 32;
+    const int MT = (B + T - 1) / T;
+    const Shape shapes[] = {
+        {"ffn_in  22528x4096 (gate)", 11264, 4096, 1}, {"in_proj 12288x4096", 12288, 4096, 0},
+        {"ffn_out 4096x11264", 4096, 11264, 0},        {"out_proj 4096x4096", 4096, 4096, 0},
+        {"text_linear 32000x4096", 32000, 4096, 0},    {"dep ffn_in 5632x1024 (gate)", 2816, 1024, 1},
+        {"dep in_proj 3072x1024", 3072, 1024, 0},      {"dep ffn_out 1024x2816", 1024, 2816, 0},
+        {"dep out_proj 1024x1024", 1024, 1024, 0},
+    };
+    const Variant variants[] = {
+        V(32, 1, 1, 4, 4), V(32, 1, 1, 8, 4), V(32, 1, 1, 16, 4), V(32, 1, 2, 4, 4), V(32, 1, 2, 8, 4),
+        V(32, 1, 1, 4, 8), V(32, 1, 1, 8, 8), V(32, 1, 2, 4, 2), V(32, 1, 2, 8, 2), V(32, 1, 1, 8, 2), V(32, 1, 1, 16, 2),
+        V(32, 2, 1, 4, 4), V(32, 2, 1, 8, 4), V(32, 2, 2, 4, 4), V(32, 2, 2, 4, 2), V(32, 2, 1, 8, 2),
+        V(16, 1, 1, 4, 4), V(16, 1, 1, 8, 4), V(16, 1, 1, 16, 4), V(16, 1, 2, 4, 4), V(16, 1, 2, 8, 4),
+        V(16, 1, 1, 4, 8), V(16, 1, 1, 8, 8), V(16, 1, 4, 4, 2), V(16, 1, 4, 8, 2),
+    };
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    printf("B=%d  tile T=%d  MT=%d  ksplit=%d\n", B, T, MT, ksplit);
+    for (const Shape& sh : shapes) {
+        const int rows_per_tile = sh.gate ? T / 2 : T;
+        const int NT = (sh.N + rows_per_tile - 1) / rows_per_tile;
+        const int KS = (sh.K + mmi_kstep(T) - 1) / mmi_kstep(T);
+        const size_t welems = (size_t)NT * KS * 512;
+        const size_t wbytes = welems * 2;
+        int nbuf = (int)((size_t)1400 * 1024 * 1024 / wbytes) + 1;
+        if (nbuf > 64) nbuf = 64;
+        if (nbuf < 4) nbuf = 4;
+        uint16_t* w;
+        CK(hipMalloc(&w, wbytes * nbuf));
+        k_fill_rand_bf16<<<2048, 256, 0, s>>>(w, welems * nbuf, 12345u);
+        uint16_t *x, *out;
+        const size_t xelems = (size_t)MT * KS * 512;
+        const int out_ks = (sh.N + mmi_kstep(T) - 1) / mmi_kstep(T);
+        const size_t oelems = (size_t)MT * out_ks * 512;
+        float* partial;
+        CK(hipMalloc(&partial, (size_t)4 * 64 * sh.N * sizeof(float)));
+        CK(hipMalloc(&x, xelems * 2));
+        CK(hipMalloc(&out, oelems * 2));
+        k_fill_rand_bf16<<<256, 256, 0, s>>>(x, xelems, 777u);
+        CK(hipMemsetAsync(out, 0, oelems * 2, s));
+        CK(hipStreamSynchronize(s));
+        printf("== %s  (%.1f MB, %d n-tiles x %d k-steps, %d buffers)\n", sh.name, wbytes / 1e6, NT, KS, nbuf);
+        for (const Variant& v : variants) {
+            if (v.TN != T || v.MT != MT) continue;
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = (const u32x4*)x; a.out = out; a.resid = out; a.B = B; a.N = sh.N; a.KSTEPS = KS; a.NT = NT;
+            a.out_mode = MMI_OUT_PACKED; a.out_ld = sh.N; a.out_ksteps = out_ks;
+            a.epi = sh.gate ? MMI_EPI_GATE : (ksplit > 1 ? MMI_EPI_PARTIAL : MMI_EPI_RESID);
+            a.partial = partial;
+            const dim3 groups((NT + v.NTW - 1) / v.NTW, sh.gate ? 1 : ksplit);
+            const int reps = wbytes > 50e6 ? 3 : 10;
+            for (int i = 0; i < nbuf; ++i) { a.wp = (const u32x4*)(w + welems * i); v.fn(groups, s, a); }   // warm-up
+            CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r)
+                for (int i = 0; i < nbuf; ++i) { a.wp = (const u32x4*)(w + welems * i); v.fn(groups, s, a); }
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / (reps * nbuf);
+            printf("   %-22s groups %5d x %d  %8.2f us  %7.0f GB/s\n", v.name, groups.x, groups.y, us, wbytes / us / 1e3);
+        }
+        CK(hipFree(w)); CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(partial));
+    }
+    return 0;
+}

@@ -101,25 +101,25 @@ def check_golden_sampled(device, lib):
     assert same >= 0.9 * total, f"sampled-token agreement given the reference's noise: {same}/{total}"
 
 
-def engine_sampling_matches_oracle_rule(device, lib):
+def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_text=10, B=4, steps=4):
     """The engine's in-kernel sampler (softmax -> top-k -> argmax(p/q)) against the oracle's restatement of
     sampling.py:86-106 on the engine's OWN logits with supplied noise: must be identical token for token."""
     from oracle.lm_oracle import sample_token
-    cfg = tiny_lm_config()
+    cfg = cfg or tiny_lm_config()
     sd = random_lm_state_dict(cfg, seed=5)
-    B = 4
-    gen = make_engine(cfg, sd, device, lib, B, use_sampling=True, temp=0.8, temp_text=0.7, top_k=20, top_k_text=10,
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=True, temp=0.8, temp_text=0.7, top_k=top_k, top_k_text=top_k_text,
                       support_out_of_sync=True)
     rng = np.random.default_rng(1)
+    kmax = max(top_k, top_k_text)
     with gen.streaming(B):
-        for s in range(4):
+        for s in range(steps):
             codes = rng.integers(0, cfg.card, (B, 8, 1))
-            noise = rng.exponential(1.0, (B, 1 + cfg.dep_q, 20)).astype(np.float32)
+            noise = rng.exponential(1.0, (B, 1 + cfg.dep_q, kmax)).astype(np.float32)
             out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), noise=torch.from_numpy(noise).to(device))
             tl, al = tl.cpu().numpy(), al.cpu().numpy()
             # the step output holds text of this step (delay 0) only after the ring delay; re-derive from taps instead
-            tt = sample_token(tl, True, 0.7, 10, noise[:, 0])
-            toks = [sample_token(al[:, k], True, 0.8, 20, noise[:, 1 + k]) for k in range(cfg.dep_q)]
+            tt = sample_token(tl, True, 0.7, top_k_text, noise[:, 0])
+            toks = [sample_token(al[:, k], True, 0.8, top_k, noise[:, 1 + k]) for k in range(cfg.dep_q)]
             if s >= 1:
                 o = out.cpu().numpy()[:, :, 0]
                 # channels with delay 1 (acoustic codebooks 1..) are emitted in the step they are sampled

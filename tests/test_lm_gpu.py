@@ -25,6 +25,12 @@ def test_in_kernel_sampler_follows_the_reference_rule(gpu_lib):
     lm_cases.engine_sampling_matches_oracle_rule(DEV, None)
 
 
+def test_full_size_sampler_follows_the_reference_rule(gpu_lib):
+    """Moshi-7B vocabularies (32000 text / 2048 audio) and LMGen's default top-k 25 / 250 on the GPU."""
+    cfg = LMConfig(num_layers=1, context=16)
+    lm_cases.engine_sampling_matches_oracle_rule(DEV, None, cfg, top_k=250, top_k_text=25, B=5, steps=3)
+
+
 @pytest.mark.parametrize("B", [1, 5])
 def test_tiny_matches_oracle_with_masks_and_reset(gpu_lib, B):
     lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=50 + B, B=B, S=16)   # S > context=12: the ring wraps
@@ -51,15 +57,19 @@ def _greedy_run(cfg, sd, B, codes, steps, graph=True, monkeypatch=None):
 
 def test_batch_rows_independent_and_graph_equals_eager(gpu_lib, monkeypatch):
     """Size-independent properties at the benchmark batch (B=32, 7B layer shapes, 2 layers): a session's tokens and
-    logits do not depend on its neighbours (row b of B=32 == the same stream alone), and hipGraph replay == eager."""
+    logits do not depend on its neighbours (row 0 is bit-identical when the other 31 sessions carry different audio),
+    and hipGraph replay == eager launches."""
     cfg = LMConfig(num_layers=2, context=64)
     sd = random_lm_state_dict(cfg, seed=11, device=DEV)
     g = torch.Generator().manual_seed(2)
     steps = 4
     codes = torch.randint(0, cfg.card, (steps, 32, 8, 1), generator=g).to(DEV)
+    other = codes.clone()
+    other[:, 1:] = torch.randint(0, cfg.card, (steps, 31, 8, 1), generator=g).to(DEV)
     o32, t32 = _greedy_run(cfg, sd, 32, codes, steps)
-    o1, t1 = _greedy_run(cfg, sd, 1, codes, steps)
-    assert torch.equal(o32[:, :1], o1) and torch.equal(t32[:, :1], t1)
+    o2, t2 = _greedy_run(cfg, sd, 32, other, steps)
+    assert torch.equal(o32[:, :1], o2[:, :1]) and torch.equal(t32[:, :1], t2[:, :1])
+    assert not torch.equal(t32[:, 1:], t2[:, 1:])
     monkeypatch.setenv("MMI_NO_GRAPH", "1")
     oe, te = _greedy_run(cfg, sd, 32, codes, steps)
     assert torch.equal(oe, o32) and torch.equal(te, t32)

@@ -20,9 +20,31 @@ def test_in_kernel_sampler_follows_the_reference_rule(sim_lib):
     lm_cases.engine_sampling_matches_oracle_rule("cpu", sim_lib)
 
 
+def test_sampler_large_vocabulary_variants(sim_lib):
+    """Vocabularies above 2048 / 8192 entries take the wider / uncached sampler kernels (lm_kernels.h k_sample)."""
+    from dataclasses import replace
+    cfg = replace(tiny_lm_config(), text_card=8200, card=2056)
+    lm_cases.engine_sampling_matches_oracle_rule("cpu", sim_lib, cfg, top_k=30, top_k_text=25, B=2, steps=2)
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_matches_oracle_with_masks_and_reset(sim_lib, B):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=40 + B, B=B, S=5)
+
+
+@pytest.mark.parametrize("B", [18, 34])
+def test_wide_batch_tiles_match_oracle(sim_lib, B):
+    """17..32 sessions use the 32x32x16 MFMA tile, 33..64 two batch tiles per weight fragment (lm_kernels.h)."""
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=60 + B, B=B, S=3)
+
+
+def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
+    """The K-split GEMM path (fp32 partials folded into the residual stream by k_resid_rmsnorm) that the 4096-wide
+    layers take at 17..64 sessions, forced onto the tiny shapes."""
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=77, B=18, S=3)
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "4")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=78, B=3, S=3)
 
 
 def test_none_during_delay_and_errors(sim_lib):
