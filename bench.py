@@ -38,7 +38,9 @@ def parse():
     return ap.parse_args()
 
 
-def dist_setup(n):
+def dist_setup(n, backend="nccl"):
+    """One process per GPU (launched by torch.distributed.run): sessions shard data-parallel, no data-path collective.
+    `backend="gloo"` is the CPU stand-in used by tests/test_bench_dist.py."""
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,11 +48,27 @@ def dist_setup(n):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         return rank, local, world, dist
-    torch.cuda.set_device(0)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
     return 0, 0, 1, None
+
+
+def job_time(dt_local, dist, dev):
+    """Whole-job time of the timed region = MAX over ranks (the only collective of the benchmark besides barriers)."""
+    if dist is None:
+        return dt_local
+    t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(world, sessions_per_gpu, steps, dt):
+    """frames/s of the whole job: every rank advances `sessions_per_gpu` sessions by `steps` frames (weak scaling)."""
+    return world * sessions_per_gpu * steps / dt
 
 
 def mimi_algorithmic_bytes(cfg, B, frames_so_far):
@@ -146,16 +164,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt = job_time(time.perf_counter() - t0, dist, dev)
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
-        dt = float(t.item())
     torch.cuda.synchronize(dev)
 
     ms = 1e3 * dt / args.steps
-    value = world * B * args.steps / dt
+    value = job_value(world, B, args.steps, dt)
     out = {
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -256,6 +256,34 @@ void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, ui
     });
 }
 
+// RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
+// registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
+void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
+                   int out_features, bool out_packed, int epi) {
+    const bool fuse = g.KSTEPS <= 64 && !getenv("MMI_NO_NORM_FUSION");
+    if (!fuse) {
+        add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
+        add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr);
+        return;
+    }
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.B = lm->batch;
+    a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
+    a.out_ld = out_features;
+    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.alpha = alpha; a.D = D; a.eps = 1e-8f;
+    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT;
+    lm->prog.add([=](hipStream_t s) {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+}
+
 void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride) {
     SampleArgs sa;
     sa.logits = logits; sa.ld = ld; sa.V = V;
@@ -369,8 +397,7 @@ int build_program(mmi_lm* lm) {
         add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
-            add_resid_rmsnorm(lm, lm->dx, 0, L.n1, lm->dxn, dd);
-            add_gemm(lm, L.in_proj[k], lm->dxn, lm->dqkv, 3 * dd, false, MMI_EPI_STORE, nullptr);
+            add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
@@ -381,8 +408,7 @@ int build_program(mmi_lm* lm) {
                 return (int)MMI_OK;
             });
             add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
-            add_resid_rmsnorm(lm, lm->dx, 0, L.n2, lm->dxn, dd);
-            add_gemm(lm, L.ffn_in[k], lm->dxn, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr);
+            add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE);
             add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
@@ -695,7 +721,7 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
         // algorithmic bytes of one FFN linear_in launch: packed weights + activations in + gated activations out
         *bytes_per_launch = (int64_t)2 * c.ffn_hidden * c.dim * 2 + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
     }
-    if (kernel_name) *kernel_name = "k_gemm_bf16 (temporal FFN linear_in + SiLU gate)";
+    if (kernel_name) *kernel_name = "k_gemm_xp<32,1,1,8,4> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;
 }

@@ -100,86 +100,18 @@ struct GemmArgs {
     const long* offsets;
     int H, Dh, cap;
     float max_period;
+    // k_gemm_xp_norm: RMSNorm of the input rows fused in front of the GEMM (xp holds the un-normalised rows)
+    const uint16_t* alpha;  // [D]
+    int D;                  // features of a row (the mean is over D, not the padded K)
+    float eps;
 };
 
-template <int TN, int MT, int NTW, int WAVES, int U>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
-    constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
-    typedef float acc_t __attribute__((ext_vector_type(R)));
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = (int)blockIdx.x * NTW;
-
-    // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
-    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
-    const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;
-    const int ks0 = min(kb1, kb0 + wave * kper);
-    const int nks = min(kb1, ks0 + kper) - ks0;
-
-    const u32x4* wp[NTW];
-    const u32x4* xp[MT];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * 64 + lane;
-
-    acc_t acc[NTW][MT];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[t][m][r] = 0.f;
-
-    u32x4 wA[U][NTW], xA[U][MT], wB[U][NTW], xB[U][MT];
-#define MMI_G_LOAD(W_, X_, base)                                                              \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
-        _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) X_[u][m] = xp[m][((base) + u) * 64];  \
-    }
-#define MMI_G_MMA(W_, X_)                                                                     \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
-        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                       \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
-                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(W_[u][t], X_[u][m], acc[t][m]); \
-                else acc[t][m] = mmi_mfma_bf16_16x16x32(W_[u][t], X_[u][m], acc[t][m]);      \
-            }
-    const int nfull = nks / U;
-    if (nfull > 0) {
-        // steady state has no conditional loads, so that the compiler's s_waitcnt vmcnt(N) before each MFMA only waits
-        // for the older buffer and the loads of the next group stay in flight behind it
-        MMI_G_LOAD(wA, xA, 0);
-        int g = 0;
-        for (; g + 2 < nfull; g += 2) {
-            MMI_G_LOAD(wB, xB, (g + 1) * U);
-            MMI_G_MMA(wA, xA);
-            MMI_G_LOAD(wA, xA, (g + 2) * U);
-            MMI_G_MMA(wB, xB);
-        }
-        if (nfull - g == 2) {
-            MMI_G_LOAD(wB, xB, (g + 1) * U);
-            MMI_G_MMA(wA, xA);
-            MMI_G_MMA(wB, xB);
-        } else {
-            MMI_G_MMA(wA, xA);
-        }
-    }
-    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U k-steps)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) wA[0][t] = mmi_load_nt(wp[t] + ks * 64);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xA[0][m] = xp[m][ks * 64];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(wA[0][t], xA[0][m], acc[t][m]);
-                else acc[t][m] = mmi_mfma_bf16_16x16x32(wA[0][t], xA[0][m], acc[t][m]);
-            }
-    }
-#undef MMI_G_LOAD
-#undef MMI_G_MMA
-
+// Split-K reduction across the workgroup's waves (fixed order -> deterministic) and the epilogue shared by the GEMM
+// kernels: one task = 8 consecutive output features of one session, written as one 16-byte vector.
+template <int TN, int MT, int NTW, int WAVES>
+__device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
+                                                  int nt0) {
+    constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic)
     constexpr int NE = NTW * MT * R * 64;
     MMI_SHARED float red[WAVES * NE];
@@ -188,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < R; ++r) red[wave * NE + ((t * MT + m) * R + r) * 64 + lane] = acc[t][m][r];
+            for (int r = 0; r < R; ++r) red[wave * NE + ((t * MT + m) * R + r) * 64 + lane] = accv[t][m][r];
     __syncthreads();
 
     // ---- epilogue: one task = 8 consecutive output features of one session
@@ -302,6 +234,176 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
         for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)mmi_f32_to_bf16(o[2 * e]) | ((uint32_t)mmi_f32_to_bf16(o[2 * e + 1]) << 16);
         *reinterpret_cast<u32x4*>(dst) = ov;
     }
+}
+
+template <int TN, int MT, int NTW, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
+    constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
+    typedef float acc_t __attribute__((ext_vector_type(R)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int nt0 = (int)blockIdx.x * NTW;
+
+    // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
+    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
+    const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;
+    const int ks0 = min(kb1, kb0 + wave * kper);
+    const int nks = min(kb1, ks0 + kper) - ks0;
+
+    const u32x4* wp[NTW];
+    const u32x4* xp[MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * 64 + lane;
+
+    acc_t acc[NTW][MT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[t][m][r] = 0.f;
+
+    u32x4 wA[U][NTW], xA[U][MT], wB[U][NTW], xB[U][MT];
+#define MMI_G_LOAD(W_, X_, base)                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) X_[u][m] = xp[m][((base) + u) * 64];  \
+    }
+#define MMI_G_MMA(W_, X_)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                       \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
+                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(W_[u][t], X_[u][m], acc[t][m]); \
+                else acc[t][m] = mmi_mfma_bf16_16x16x32(W_[u][t], X_[u][m], acc[t][m]);      \
+            }
+    const int nfull = nks / U;
+    if (nfull > 0) {
+        // steady state has no conditional loads, so that the compiler's s_waitcnt vmcnt(N) before each MFMA only waits
+        // for the older buffer and the loads of the next group stay in flight behind it
+        MMI_G_LOAD(wA, xA, 0);
+        int g = 0;
+        for (; g + 2 < nfull; g += 2) {
+            MMI_G_LOAD(wB, xB, (g + 1) * U);
+            MMI_G_MMA(wA, xA);
+            MMI_G_LOAD(wA, xA, (g + 2) * U);
+            MMI_G_MMA(wB, xB);
+        }
+        if (nfull - g == 2) {
+            MMI_G_LOAD(wB, xB, (g + 1) * U);
+            MMI_G_MMA(wA, xA);
+            MMI_G_MMA(wB, xB);
+        } else {
+            MMI_G_MMA(wA, xA);
+        }
+    }
+    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U k-steps)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wA[0][t] = mmi_load_nt(wp[t] + ks * 64);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xA[0][m] = xp[m][ks * 64];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(wA[0][t], xA[0][m], acc[t][m]);
+                else acc[t][m] = mmi_mfma_bf16_16x16x32(wA[0][t], xA[0][m], acc[t][m]);
+            }
+    }
+#undef MMI_G_LOAD
+#undef MMI_G_MMA
+    float accv[NTW][MT][R];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) accv[t][m][r] = acc[t][m][r];
+    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0);
+}
+
+// RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
+// 1024 features): y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16) (transformer.py:45-58), then
+// out = y @ W^T.  A wave's whole K-slice of activation and weight fragments (<= KMAX k-steps) is loaded in one go -
+// everything in flight at once, these GEMMs are latency bound - the waves combine their sums of squares through
+// LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
+template <int TN, int MT, int WAVES, int KMAX>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
+    constexpr int R = TN == 32 ? 16 : 4;
+    constexpr int KS = TN == 32 ? 16 : 32;
+    typedef float acc_t __attribute__((ext_vector_type(R)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int nt0 = (int)blockIdx.x;
+    const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
+    const int ks0 = min(a.KSTEPS, wave * kper);
+    const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
+    const int kq = TN == 32 ? (lane >> 5) : (lane >> 4);
+
+    const u32x4* wp = a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
+    u32x4 wv[KMAX], xv[MT][KMAX], al[KMAX];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        const bool on = u < nks;
+        const int k = (ks0 + u) * KS + 8 * kq;
+        wv[u] = on ? mmi_load_nt(wp + u * 64) : zero;
+        al[u] = (on && k < a.D) ? *reinterpret_cast<const u32x4*>(a.alpha + k) : zero;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xv[m][u] = on ? a.xp[((long)m * a.KSTEPS + ks0 + u) * 64 + lane] : zero;
+    }
+    // sum of squares of this lane's row over the wave's slice (the kq lane groups hold different k of the same row)
+    MMI_SHARED float ssum[WAVES][MT][TN];
+    float rs[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] >> 16));
+                ss += lo * lo;
+                ss += hi * hi;
+            }
+        if constexpr (TN == 32) ss += mmi_shfl_xor(ss, 32);
+        else { ss += mmi_shfl_xor(ss, 16); ss += mmi_shfl_xor(ss, 32); }
+        if (lane < TN) ssum[wave][m][lane] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) tot += ssum[w][m][lane & (TN - 1)];
+        rs[m] = mmi_rsqrtf(a.eps + tot / (float)a.D);
+    }
+    acc_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            u32x4 xn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] >> 16));
+                const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
+                xn[q] = (uint32_t)mmi_f32_to_bf16(lo * (alo * rs[m])) | ((uint32_t)mmi_f32_to_bf16(hi * (ahi * rs[m])) << 16);
+            }
+            if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wv[u], xn, acc[m]);
+            else acc[m] = mmi_mfma_bf16_16x16x32(wv[u], xn, acc[m]);
+        }
+    }
+    float accv[1][MT][R];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0);
 }
 
 // ------------------------------------------------------------------------------------------------

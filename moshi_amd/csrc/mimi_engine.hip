@@ -47,6 +47,7 @@ struct mmi_mimi {
     int* codes_i32 = nullptr;                  // [maxB][n_q]
     float* q2 = nullptr;                       // [maxB][2*Dq]
     float* lat_tmp = nullptr;                  // [maxB][dimension]
+    float *qin_bp = nullptr, *qin_part = nullptr, *qout_bp = nullptr, *qout_part = nullptr;   // projection scratch (max_batch)
     int nchunk = 0;
     // streaming state
     bool streaming = false;
@@ -227,26 +228,124 @@ int load_rvq(mmi_mimi* m, const MmiWeights& W) {
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-int launch_conv(hipStream_t s, const ConvGemmArgs& a) {
-    const int Mt = a.Mt;
-    int NT = 4;
-    auto tiles = [&](int nt) { return Mt * mmi_cdiv(a.Ntot, 32 * nt); };
-    while (NT > 1 && tiles(NT) < 1024) NT >>= 1;
-    int KS = 1;
-    while (KS < 4 && tiles(NT) * KS < 1024 && a.Q / (KS * 2) >= 8) KS <<= 1;
-    if (KS > 1 && NT > 2) NT = 2;
-    const int nt_tiles = tiles(NT);
-    const int grid = mmi_cdiv(nt_tiles, 4 / KS);
-#define MMI_CG(NT_, KS_) MMI_LAUNCH((k_conv_gemm<NT_, KS_>), grid, 256, 0, s, a)
-    if (KS == 1) {
-        if (NT == 4) MMI_CG(4, 1); else if (NT == 2) MMI_CG(2, 1); else MMI_CG(1, 1);
-    } else if (KS == 2) {
-        if (NT == 2) MMI_CG(2, 2); else MMI_CG(1, 2);
-    } else {
-        if (NT == 2) MMI_CG(2, 4); else MMI_CG(1, 4);
+// A conv / linear becomes one of two launch sequences, chosen when the frame program is built (mimi_kernels.h):
+//   N = B*T_out > 128 columns : k_conv_wide
+//   N <= 128                  : [k_pack_b_f32] -> k_gemm_f32 [-> k_conv_finish when K is split over workgroups]
+struct ConvPlan {
+    bool wide = false;
+    int MTB = 1, W = 1, U = 1;        // wide
+    int NSUB = 1, waves = 4, ksplit = 1;
+    bool pack = false;
+};
+
+template <int MTB, int U>
+void launch_wide_w(hipStream_t s, const ConvGemmArgs& a, int W, dim3 grid) {
+    const size_t smem = (size_t)W * MTB * 16 * 64 * sizeof(float);
+    switch (W) {
+        case 1: MMI_LAUNCH((k_conv_wide<MTB, 1, U>), grid, 64, 0, s, a); break;
+        case 2: MMI_LAUNCH((k_conv_wide<MTB, 2, U>), grid, 128, smem, s, a); break;
+        case 4: MMI_LAUNCH((k_conv_wide<MTB, 4, U>), grid, 256, smem, s, a); break;
+        default: MMI_LAUNCH((k_conv_wide<MTB, 8, U>), grid, 512, smem, s, a); break;
     }
-#undef MMI_CG
+}
+
+int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
+    if (p.wide) {
+        const dim3 grid(mmi_cdiv(a.Ntot, 32), mmi_cdiv(a.Mt, p.MTB));
+        switch (p.MTB) {
+            case 1: launch_wide_w<1, 4>(s, a, p.W, grid); break;
+            case 2: launch_wide_w<2, 4>(s, a, p.W, grid); break;
+            case 4: launch_wide_w<4, 2>(s, a, p.W, grid); break;
+            default: launch_wide_w<8, 1>(s, a, p.W, grid); break;
+        }
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
+    if (p.pack) {
+        const long n = (long)mmi_cdiv(a.Ntot, 32) * a.Q * 64;
+        MMI_LAUNCH(k_pack_b_f32, (int)mmi_cdiv64(n, 256), 256, 0, s, a, const_cast<float*>(a.bp));
+    }
+    ConvGemmArgs g = a;
+    if (p.ksplit > 1) g.out_mode = MMI_GOUT_PARTIAL;
+    const dim3 grid(a.Mt, p.ksplit);
+    if (p.NSUB == 1) {
+        if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<1, 8, 2>), grid, 512, 0, s, g);
+        else MMI_LAUNCH((k_gemm_f32<1, 4, 2>), grid, 256, 0, s, g);
+    } else if (p.NSUB == 2) {
+        if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<2, 8, 2>), grid, 512, 0, s, g);
+        else MMI_LAUNCH((k_gemm_f32<2, 4, 2>), grid, 256, 0, s, g);
+    } else {
+        MMI_LAUNCH((k_gemm_f32<4, 4, 2>), grid, 256, 0, s, g);
+    }
+    if (p.ksplit > 1) MMI_LAUNCH(k_conv_finish, (int)mmi_cdiv64((int64_t)a.Cout * a.Ntot, 256), 256, 0, s, a, p.ksplit);
     MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+// Decide the launch sequence of one conv and allocate its scratch (offset table / packed operand / partials) from
+// `arena`.  `a.x_packed`: the producer writes a.bp itself.  `a.out_mode` PACKED: the result feeds a linear directly.
+int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
+    const int N = a.Ntot;
+    if (N > 128) {
+        if (a.first || a.x_packed || a.out_mode != MMI_GOUT_NATURAL)
+            return mmi_fail(MMI_ERR_UNSUPPORTED, "wide conv path does not take replicate padding / packed operands");
+        p->wide = true;
+        const int nsub = mmi_cdiv(N, 32);
+        // m-tiles per wave (each gathered + ELU'd operand element is reused MTB times) vs. waves in flight:
+        // aim for >= 1024 waves, taking the parallelism from split-K waves (W) before shrinking MTB
+        int MTB = 8;
+        while (MTB > a.Mt) MTB >>= 1;
+        int W = 1;
+        auto waves = [&](int mtb, int w) { return nsub * mmi_cdiv(a.Mt, mtb) * w; };
+        auto wmax = [&](int mtb) { int w = 1; while (w < 8 && w * 2 * mtb <= 16 && a.Q / (w * 2) >= 4) w <<= 1; return w; };
+        while (MTB > 1 && waves(MTB, wmax(MTB)) < 1024) MTB >>= 1;
+        while (W < wmax(MTB) && waves(MTB, W) < 1024) W <<= 1;
+        if (const char* e = getenv("MMI_CONV_MTB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) MTB = v; }   // test hooks
+        if (const char* e = getenv("MMI_CONV_W")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) W = v; }
+        while (W * MTB > 16) W >>= 1;          // split-K reduction buffer: W * MTB * 4 KiB of LDS, keep it within 64 KiB
+        p->MTB = MTB; p->W = W;
+        std::vector<int> tab((size_t)a.Q * 8);
+        for (int q = 0; q < a.Q; ++q)
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 4; ++e) {
+                    const int kd = (q * 4 + e) * 2 + h;
+                    tab[((size_t)q * 2 + h) * 4 + e] = kd < a.Cin * a.K ? (kd / a.K) * a.x_ld + kd % a.K : -1;
+                }
+        int* dev = nullptr;
+        MMI_HIP_CHECK(arena.alloc(&dev, tab.size()));
+        MMI_HIP_CHECK(hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        a.koff = dev;
+        return MMI_OK;
+    }
+    p->wide = false;
+    const int nsub = mmi_cdiv(N, 32);
+    p->NSUB = nsub <= 1 ? 1 : (nsub == 2 ? 2 : 4);
+    a.Npad = p->NSUB * 32;
+    if (!a.x_packed) {
+        if (!a.bp) {
+            float* bp = nullptr;
+            MMI_HIP_CHECK(arena.alloc(&bp, (size_t)nsub * a.Q * 256));
+            a.bp = bp;
+        }
+        p->pack = true;
+    }
+    int ks = 1;
+    if (a.out_mode == MMI_GOUT_NATURAL) {
+        // only the large strided convs (>= 2048-deep reductions, tens of MB of weights) are worth a finishing launch
+        while (a.Q >= 256 && ks < 8 && a.Mt * ks * 2 <= 256 && a.Q / (ks * 2) >= 32) ks <<= 1;
+    }
+    if (const char* e = getenv("MMI_CONV_KSPLIT")) {   // test hook
+        const int v = atoi(e);
+        if (a.out_mode == MMI_GOUT_NATURAL && v >= 1 && v <= 8 && a.Q >= v) ks = v;
+    }
+    p->ksplit = ks;
+    if (ks > 1 && !a.partial) {
+        float* part = nullptr;
+        MMI_HIP_CHECK(arena.alloc(&part, (size_t)ks * a.Mt * 32 * a.Npad));
+        a.partial = part;
+    }
+    const int qblk = a.Q / ks;
+    p->waves = (p->NSUB <= 2 && qblk >= 32) ? 8 : 4;
     return MMI_OK;
 }
 
@@ -261,6 +360,7 @@ ConvGemmArgs conv_args(const ConvW& w, const Buf& in, int x_off, int T_out, cons
     a.Mt = w.Mt; a.Q = w.Q; a.Ntot = B * T_out;
     a.elu_in = elu_in ? 1 : 0;
     a.act_out = MMI_ACT_NONE;
+    a.out_mode = MMI_GOUT_NATURAL;
     return a;
 }
 
@@ -272,20 +372,29 @@ int alloc_buf(mmi_mimi* m, int B, int C, int H, int T, Buf* b, hipStream_t s) {
     return MMI_OK;
 }
 
-void add_conv(MmiProgram& prog, ConvGemmArgs a) {
-    prog.add([a](hipStream_t s) { return launch_conv(s, a); });
+int add_conv(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a, MmiArena* arena = nullptr) {
+    ConvPlan p;
+    int rc = plan_conv(arena ? *arena : m->st, a, &p);
+    if (rc) return rc;
+    prog.add([a, p](hipStream_t s) { return launch_conv_plan(s, a, p); });
+    return MMI_OK;
 }
 
 // residual vector quantiser: latent [B][dim] (column `lat_off` of rows of length lat_ld) -> codes_i32 [B][n_q]
-void add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B) {
+int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B) {
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins;
     Buf in; in.p = const_cast<float*>(latent); in.C = c.dimension; in.ld = lat_ld; in.H = lat_off;
     Buf out; out.p = m->xq; out.C = 2 * D; out.ld = 1; out.H = 0;
-    add_conv(prog, conv_args(m->q_in, in, lat_off, 1, out, 0, B, false));
+    {
+        ConvGemmArgs a = conv_args(m->q_in, in, lat_off, 1, out, 0, B, false);
+        a.bp = m->qin_bp; a.partial = m->qin_part;
+        int rc = add_conv(m, prog, a);
+        if (rc) return rc;
+    }
     const int K = m->n_codebooks;
     const int nchunk = m->nchunk;
-    const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 1) + (size_t)B * D) * sizeof(float);
+    const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 1) + (size_t)8 * D) * sizeof(float);
     for (int k = 0; k < K; ++k) {
         const bool sem = k < c.q_n_q_semantic;
         float* x = m->xq + (sem ? 0 : D);
@@ -293,16 +402,17 @@ void add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int la
         const double* e2 = m->e2_all + (size_t)k * bins;
         double* bd = m->best_d; int* bi = m->best_i; int* codes = m->codes_i32; const int nq = c.q_n_q;
         prog.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_rvq_dist, nchunk, 256, smem, s, (const float*)x, 2 * D, E, e2, bd, bi, B, D, bins);
+            MMI_LAUNCH(k_rvq_dist, dim3(nchunk, mmi_cdiv(B, 8)), 256, smem, s, (const float*)x, 2 * D, E, e2, bd, bi, B, D, bins);
             MMI_LAUNCH(k_rvq_select, B, 256, 0, s, (const double*)bd, (const int*)bi, nchunk, x, 2 * D, E, codes, nq, k, B, D);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
     }
+    return MMI_OK;
 }
 
 // codes_i32 [B][n_q] (first K used) -> latent written to out buffer column out_off
-void add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B) {
+int add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B) {
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins, nq = c.q_n_q, nsem = c.q_n_q_semantic;
     float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all;
@@ -312,7 +422,9 @@ void add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int o
         return (int)MMI_OK;
     });
     Buf in; in.p = m->q2; in.C = 2 * D; in.ld = 1; in.H = 0;
-    add_conv(prog, conv_args(m->q_out, in, 0, 1, out, out_off, B, false));
+    ConvGemmArgs a = conv_args(m->q_out, in, 0, 1, out, out_off, B, false);
+    a.bp = m->qout_bp; a.partial = m->qout_part;
+    return add_conv(m, prog, a);
 }
 
 // one streaming transformer (ProjectedTransformer with conv_layout, transformer.py:932-983) working in place
@@ -321,28 +433,49 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
                     float* kv, const long* offsets, int B, hipStream_t init_stream) {
     const mmi_mimi_cfg& c = m->cfg;
     const int d = c.tr_d_model, H = c.tr_num_heads, Dh = d / H, ff = c.tr_dim_feedforward, cap = c.tr_context;
+    const int N = B * T;
+    // At <= 128 columns (every real configuration: T = 2 per session) the linears run on k_gemm_f32 and the producers
+    // (LayerNorm, attention, linear1+GELU) write its packed operand directly; otherwise plain [B][C][T] buffers.
+    const bool packed = N <= 128;
     Buf y, qkv, att, hb;
     int rc;
     if ((rc = alloc_buf(m, B, d, 0, T, &y, init_stream))) return rc;
     if ((rc = alloc_buf(m, B, 3 * d, 0, T, &qkv, init_stream))) return rc;
     if ((rc = alloc_buf(m, B, d, 0, T, &att, init_stream))) return rc;
     if ((rc = alloc_buf(m, B, ff, 0, T, &hb, init_stream))) return rc;
+    float *yp = nullptr, *attp = nullptr, *hbp = nullptr;
+    const int nsub = mmi_cdiv(N, 32), Qd = mmi_cdiv(d, 8), Qff = mmi_cdiv(ff, 8);
+    if (packed) {
+        MMI_HIP_CHECK(m->st.alloc(&yp, (size_t)nsub * Qd * 256));
+        MMI_HIP_CHECK(m->st.alloc(&attp, (size_t)nsub * Qd * 256));
+        MMI_HIP_CHECK(m->st.alloc(&hbp, (size_t)nsub * Qff * 256));
+        MMI_HIP_CHECK(hipMemsetAsync(yp, 0, (size_t)nsub * Qd * 256 * sizeof(float), init_stream));
+        MMI_HIP_CHECK(hipMemsetAsync(attp, 0, (size_t)nsub * Qd * 256 * sizeof(float), init_stream));
+        MMI_HIP_CHECK(hipMemsetAsync(hbp, 0, (size_t)nsub * Qff * 256 * sizeof(float), init_stream));
+    }
     const size_t kv_layer = (size_t)B * H * cap * Dh;
-    const size_t attn_smem = ((size_t)T * Dh + (size_t)T * cap + 256) * sizeof(float);
+    if (T > 4) return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi attention kernel handles at most 4 transformer steps per frame");
+    const size_t attn_smem = ((size_t)T * Dh + (size_t)T * cap + (size_t)(256 / (Dh / 4)) * T * Dh + 8) * sizeof(float);
+    auto add_norm = [&](const float* w, const float* bb) {
+        const float* xp = xb.p; int xld = xb.ld; float* yn = y.p;
+        prog.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_layernorm_ct, B * T, 64, 0, s, xp, xld, off, w, bb, yn, T, 0, d, T, 1e-5f, yp, Qd);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    };
     for (size_t l = 0; l < layers.size(); ++l) {
         const TrLayerW& L = layers[l];
         {   // x = x + ls1 * out_proj(attn(norm1(x)))
-            const float* xp = xb.p; int xld = xb.ld; float* yp = y.p; const float *w = L.n1w, *bb = L.n1b;
-            prog.add([=](hipStream_t s) {
-                MMI_LAUNCH(k_layernorm_ct, B * T, 64, 0, s, xp, xld, off, w, bb, yp, T, 0, d, T, 1e-5f);
-                MMI_CHECK_LAUNCH();
-                return (int)MMI_OK;
-            });
-            add_conv(prog, conv_args(L.in_proj, y, 0, T, qkv, 0, B, false));
+            add_norm(L.n1w, L.n1b);
+            ConvGemmArgs ai = conv_args(L.in_proj, y, 0, T, qkv, 0, B, false);
+            if (packed) { ai.x_packed = 1; ai.bp = yp; }
+            if ((rc = add_conv(m, prog, ai))) return rc;
             MimiAttnArgs aa;
             aa.qkv = qkv.p; aa.kc = kv + (2 * l) * kv_layer; aa.vc = kv + (2 * l + 1) * kv_layer;
             aa.offsets = offsets; aa.out = att.p; aa.B = B; aa.H = H; aa.D = Dh; aa.T = T; aa.cap = cap;
             aa.context = c.tr_context; aa.max_period = c.tr_max_period;
+            aa.outp = attp; aa.outQ = Qd;
             prog.add([=](hipStream_t s) {
                 MMI_LAUNCH(k_mimi_attn, B * H, 256, attn_smem, s, aa);
                 MMI_CHECK_LAUNCH();
@@ -350,21 +483,19 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
             });
             ConvGemmArgs a = conv_args(L.out_proj, att, 0, T, xb, off, B, false);
             a.res = xb.p; a.res_ld = xb.ld; a.res_off = off; a.scale = L.ls1;
-            add_conv(prog, a);
+            if (packed) { a.x_packed = 1; a.bp = attp; }
+            if ((rc = add_conv(m, prog, a))) return rc;
         }
         {   // x = x + ls2 * linear2(gelu(linear1(norm2(x))))
-            const float* xp = xb.p; int xld = xb.ld; float* yp = y.p; const float *w = L.n2w, *bb = L.n2b;
-            prog.add([=](hipStream_t s) {
-                MMI_LAUNCH(k_layernorm_ct, B * T, 64, 0, s, xp, xld, off, w, bb, yp, T, 0, d, T, 1e-5f);
-                MMI_CHECK_LAUNCH();
-                return (int)MMI_OK;
-            });
+            add_norm(L.n2w, L.n2b);
             ConvGemmArgs a1 = conv_args(L.lin1, y, 0, T, hb, 0, B, false);
             a1.act_out = MMI_ACT_GELU;
-            add_conv(prog, a1);
+            if (packed) { a1.x_packed = 1; a1.bp = yp; a1.out_mode = MMI_GOUT_PACKED; a1.outp = hbp; a1.outQ = Qff; }
+            if ((rc = add_conv(m, prog, a1))) return rc;
             ConvGemmArgs a2 = conv_args(L.lin2, hb, 0, T, xb, off, B, false);
             a2.res = xb.p; a2.res_ld = xb.ld; a2.res_off = off; a2.scale = L.ls2;
-            add_conv(prog, a2);
+            if (packed) { a2.x_packed = 1; a2.bp = hbp; }
+            if ((rc = add_conv(m, prog, a2))) return rc;
         }
     }
     return MMI_OK;
@@ -408,7 +539,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     {   // conv0: channels -> n_filters, K = kernel_size; consumer = resblock conv (K = residual_kernel_size)
         Buf nxt;
         if ((rc = alloc_buf(m, B, c.n_filters, c.residual_kernel_size - 1, T, &nxt, s0))) return rc;
-        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false));
+        if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false)))) return rc;
         hist.push_back(hist_of(nxt, T));
         cur = nxt;
     }
@@ -419,10 +550,10 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         Buf hid, nxt;
         if ((rc = alloc_buf(m, B, ch / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
-        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true));
+        if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->enc_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
         a.res = cur.p; a.res_ld = cur.ld; a.res_off = cur.H;
-        add_conv(prog, a);
+        if ((rc = add_conv(m, prog, a))) return rc;
         hist.push_back(hist_of(nxt, T));
         cur = nxt;
         // strided conv: ch -> 2ch ; consumer = next resblock conv (K3) or the final conv (last_kernel_size)
@@ -430,7 +561,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? c.residual_kernel_size - 1 : c.last_kernel_size - 1;
         Buf nx2;
         if ((rc = alloc_buf(m, B, 2 * ch, Hn, Tn, &nx2, s0))) return rc;
-        add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true));
+        if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true)))) return rc;
         hist.push_back(hist_of(nx2, Tn));
         cur = nx2;
         T = Tn;
@@ -440,7 +571,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     const int stride = c.resample_stride;
     Buf dsin;
     if ((rc = alloc_buf(m, B, c.dimension, 2 * stride - stride, T, &dsin, s0))) return rc;
-    add_conv(prog, conv_args(m->enc_convs[ci++], cur, 0, T, dsin, dsin.H, B, true));
+    if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, dsin, dsin.H, B, true)))) return rc;
     hist.push_back(hist_of(dsin, T));
     // encoder transformer, in place on dsin[:, :, H:H+T]
     {
@@ -458,9 +589,9 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     {
         ConvGemmArgs a = conv_args(m->downsample, dsin, 0, 1, m->latent, 0, B, false);
         a.first = m->first; a.exec = m->exec;
-        add_conv(prog, a);
+        if ((rc = add_conv(m, prog, a))) return rc;
     }
-    add_quantize_ops(m, prog, m->latent.p, 1, 0, B);
+    if ((rc = add_quantize_ops(m, prog, m->latent.p, 1, 0, B))) return rc;
     // commit
     if ((rc = upload_hist(m, hist, B, &m->enc_hist, &m->enc_nhist, &m->enc_hist_rows))) return rc;
     {
@@ -484,7 +615,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     const int stride = c.resample_stride;
     // dequantised latent [B][dim][1]
     if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->dec_codes_lat, s0))) return rc;
-    add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B);
+    if ((rc = add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B))) return rc;
     // upsample (depthwise transposed conv) into the decoder transformer buffer = input of decoder conv0
     int T = stride;
     Buf din;
@@ -518,7 +649,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     Buf cur;
     {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
         if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
-        add_conv(prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false));
+        if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false)))) return rc;
     }
     for (int i = 0; i < c.n_ratios; ++i) {
         const int ratio = c.ratios[i];
@@ -532,7 +663,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         {
             ConvGemmArgs a = conv_args(wtr, cur, 0, T, tmp, 0, B, true);
             a.bias = nullptr;  // bias is added once, in the combine step
-            add_conv(prog, a);
+            if ((rc = add_conv(m, prog, a))) return rc;
         }
         {
             float* part = nullptr;
@@ -556,17 +687,17 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? 0 : c.last_kernel_size - 1;
         if ((rc = alloc_buf(m, B, cout / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
-        add_conv(prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true));
+        if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->dec_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
         a.res = up.p; a.res_ld = up.ld; a.res_off = up.H;
-        add_conv(prog, a);
+        if ((rc = add_conv(m, prog, a))) return rc;
         if (Hn > 0) hist.push_back(hist_of(nxt, T));
         cur = nxt;
         mult /= 2;
     }
     if (T != c.frame_size) return mmi_fail(MMI_ERR_UNSUPPORTED, "decoder does not reproduce frame_size samples");
     if ((rc = alloc_buf(m, B, c.channels, 0, T, &m->dec_out, s0))) return rc;
-    add_conv(prog, conv_args(m->dec_convs[ci++], cur, 0, T, m->dec_out, 0, B, true));
+    if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], cur, 0, T, m->dec_out, 0, B, true)))) return rc;
     if ((rc = upload_hist(m, hist, B, &m->dec_hist, &m->dec_nhist, &m->dec_hist_rows))) return rc;
     {
         HistDesc* hd = m->dec_hist; int nh = m->dec_nhist, rows = m->dec_hist_rows;
@@ -588,8 +719,8 @@ int check_cfg(const mmi_mimi_cfg& c) {
     if (hop * c.resample_stride != c.frame_size) return mmi_fail(MMI_ERR_UNSUPPORTED, "frame_size != hop*stride");
     if (c.tr_d_model != c.dimension) return mmi_fail(MMI_ERR_UNSUPPORTED, "projected transformer (d_model != dimension)");
     const int Dh = c.tr_d_model / c.tr_num_heads;
-    if (Dh * c.tr_num_heads != c.tr_d_model || (Dh & 1) || 256 % Dh != 0)
-        return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be even and divide 256");
+    if (Dh * c.tr_num_heads != c.tr_d_model || (Dh & 3) || 256 % Dh != 0)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be a multiple of 4 and divide 256");
     if (c.compress < 1 || c.q_n_q_semantic < 1 || c.q_n_q < c.q_n_q_semantic)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "bad quantizer/compress config");
     return MMI_OK;
@@ -692,7 +823,11 @@ extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* w
         hipSuccess != m->wts.alloc(&m->best_i, (size_t)m->nchunk * max_batch) ||
         hipSuccess != m->wts.alloc(&m->codes_i32, (size_t)max_batch * c.q_n_q) ||
         hipSuccess != m->wts.alloc(&m->q2, (size_t)max_batch * 2 * c.q_dimension) ||
-        hipSuccess != m->wts.alloc(&m->lat_tmp, (size_t)max_batch * c.dimension))
+        hipSuccess != m->wts.alloc(&m->lat_tmp, (size_t)max_batch * c.dimension) ||
+        hipSuccess != m->wts.alloc(&m->qin_bp, (size_t)mmi_cdiv(max_batch, 32) * m->q_in.Q * 256) ||
+        hipSuccess != m->wts.alloc(&m->qout_bp, (size_t)mmi_cdiv(max_batch, 32) * m->q_out.Q * 256) ||
+        hipSuccess != m->wts.alloc(&m->qin_part, (size_t)8 * m->q_in.Mt * 32 * 128) ||
+        hipSuccess != m->wts.alloc(&m->qout_part, (size_t)8 * m->q_out.Mt * 32 * 128))
         return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (RVQ scratch)"));
     if (hipDeviceSynchronize() != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "weight packing failed"));
     if (m->use_graph && hipStreamCreate(&m->cap_stream) != hipSuccess)
@@ -820,8 +955,9 @@ extern "C" int mmi_mimi_quantize(mmi_mimi* m, const float* latent, int64_t* code
     const mmi_mimi_cfg& c = m->cfg;
     for (int f = 0; f < n_frames; ++f) {
         MmiProgram prog;
-        add_quantize_ops(m, prog, latent, n_frames, f, batch);
-        int rc = prog.run_eager(s);
+        int rc = add_quantize_ops(m, prog, latent, n_frames, f, batch);
+        if (rc) return rc;
+        rc = prog.run_eager(s);
         if (rc) return rc;
         MMI_LAUNCH(k_codes_out, mmi_cdiv(batch * m->n_codebooks, 256), 256, 0, s, (const int*)m->codes_i32, c.q_n_q, (long*)codes, batch,
                    m->n_codebooks, n_frames, f);
@@ -841,8 +977,9 @@ extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* 
     for (int f = 0; f < n_frames; ++f) {
         MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
         MmiProgram prog;
-        add_dequant_ops(m, prog, n_codebooks, out, f, batch);
-        int rc = prog.run_eager(s);
+        int rc = add_dequant_ops(m, prog, n_codebooks, out, f, batch);
+        if (rc) return rc;
+        rc = prog.run_eager(s);
         if (rc) return rc;
     }
     return MMI_OK;

@@ -13,9 +13,11 @@
 //   KV ring       [layer][2][B][H][cap][D] fp32 (transformer.py:196-288).
 //
 // Every conv / linear of the codec (SEANet convs, the GEMM half of the transposed convs, the 1x1
-// RVQ projections, the transformer's linears) runs through ONE implicit-GEMM kernel, k_conv_gemm:
+// RVQ projections, the transformer's linears) is the implicit GEMM
 //   out[co][n=(b,t)] = sum_{kd=(ci,k)} W[co][kd] * act(in[b][ci][t*S + k])
-// with the fp32 MFMA (an exact fma chain, so results track the fp32 reference to rounding order).
+// on the fp32 MFMA (an exact fma chain, so results track the fp32 reference to rounding order); see k_conv_wide /
+// k_gemm_f32 below.  Activations that feed k_gemm_f32 are additionally kept as a packed B operand:
+//   Bp[nt][q][lane][e] = act(in)[kd = (q*4+e)*2 + (lane>>5)][n = nt*32 + (lane&31)]
 #pragma once
 #include "mmi_common.h"
 
@@ -75,7 +77,18 @@ __global__ void k_codebook_prepare(const float* __restrict__ esum, const float* 
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM conv / linear
 // ------------------------------------------------------------------------------------------------
-enum { MMI_ACT_NONE = 0, MMI_ACT_GELU = 1 };
+// out[co][n=(b,t)] = sum_{kd=(ci,k)} W[co][kd] * act(in[b][ci][t*S + k]), fp32 MFMA 32x32x2 (exact fma chain).
+// Two kernels cover the codec:
+//   k_conv_wide  (N = B*T_out > 128 columns: SEANet layers at audio rate).  A wave owns 32 columns x MTB m-tiles x a
+//                K-slice; lane (j, h) gathers exactly the B-operand elements its own MFMA lane consumes
+//                (column j, reduction index kd = 2q+h), applies ELU once, and reuses them for the MTB m-tiles.
+//                The reduction index -> input offset map (ci*x_ld + k) is a per-layer table, 16 bytes per k-quad.
+//   k_gemm_f32   (N <= 128: the 12.5/25 Hz layers - transformer linears, last strided convs, resampling, RVQ
+//                projections; weights dominate).  Same shape as the LM's weight-streaming GEMM: one m-tile per
+//                workgroup, K split over waves (+ workgroups), activations pre-packed into B-fragment order by
+//                k_pack_b_f32 (im2col + ELU + replicate padding) or by the producing kernel.
+enum { MMI_ACT_NONE = 0, MMI_ACT_GELU = 1, MMI_ACT_ELU = 2 };
+enum { MMI_GOUT_NATURAL = 0, MMI_GOUT_PACKED = 1, MMI_GOUT_PARTIAL = 2 };
 
 struct ConvGemmArgs {
     const float* x;       // input [B][Cin][x_ld]; position p of a row = history (p < H) then the T new columns
@@ -97,108 +110,265 @@ struct ConvGemmArgs {
     int Ntot;             // B * T_out
     int elu_in;           // apply ELU(alpha=1) to every loaded input (seanet.py:63,205,222)
     int act_out;          // MMI_ACT_*
+    // --- filled in by the engine's planner
+    const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h, or -1 past Cin*K
+    const float* bp;      // k_gemm_f32: packed activations [ceil(N/32)][Q][64][4]
+    int x_packed;         // the producer already wrote `bp` (no k_pack_b_f32 launch)
+    int out_mode;         // MMI_GOUT_*
+    float* outp;          // GOUT_PACKED: packed B operand of the consuming linear, [ceil(N/32)][outQ][64][4]
+    int outQ;
+    float* partial;       // GOUT_PARTIAL: [gridDim.y][Mt*32][Npad] raw sums, finished by k_conv_finish
+    int Npad;
 };
 
 __device__ __forceinline__ float mmi_elu(float v) { return v > 0.f ? v : expm1f(v); }
 __device__ __forceinline__ float mmi_gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int NT, int KSPLIT>
-__global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
-    constexpr int TPB = 4 / KSPLIT;
+// index of element (kd, n) in a packed B operand with Q k-quads
+__device__ __forceinline__ long mmi_bp_index(int kd, int n, int Q) {
+    return ((((long)(n >> 5) * Q + (kd >> 3)) * 64) + (kd & 1) * 32 + (n & 31)) * 4 + ((kd & 7) >> 1);
+}
+
+// bias / activation / LayerScale / residual, then the store to [B][Cout][out_ld] - shared by the three epilogues
+__device__ __forceinline__ void mmi_conv_store(const ConvGemmArgs& a, int co, int b, int t, float v) {
+    if (a.bias) v += a.bias[co];
+    if (a.act_out == MMI_ACT_GELU) v = mmi_gelu_erf(v);
+    else if (a.act_out == MMI_ACT_ELU) v = mmi_elu(v);
+    if (a.scale) v *= a.scale[co];
+    const long row = (long)b * a.Cout + co;
+    if (a.res) v = a.res[row * a.res_ld + a.res_off + t] + v;
+    a.out[row * a.out_ld + a.out_off + t] = v;
+}
+
+template <int MTB, int W, int U>
+__global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int jl = lane & 31, kh = lane >> 5;
-    const int Ntiles = (a.Ntot + 32 * NT - 1) / (32 * NT);
-    int tile = (int)blockIdx.x * TPB + wave / KSPLIT;
-    const bool tile_ok = tile < a.Mt * Ntiles;
-    if (!tile_ok) tile = 0;  // keep every lane alive for the MFMAs / barriers; results are discarded
-    const int ks = wave % KSPLIT;
-    const int mt = tile % a.Mt, nt = tile / a.Mt;
+    const int n = (int)blockIdx.x * 32 + jl;
+    const int mt0 = (int)blockIdx.y * MTB;
+    const bool nvalid = n < a.Ntot;
+    const int nn = nvalid ? n : 0;
+    const int b = nn / a.T_out, t = nn - b * a.T_out;
+    const float* xb = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
+    const int qper = (a.Q + W - 1) / W;
+    const int q0 = min(a.Q, wave * qper), q1 = min(a.Q, q0 + qper);
 
-    const float* xb[NT];
-    bool nvalid[NT], rep[NT];
-    int ob[NT], ot[NT];
+    f32x16 acc[MTB];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-        int n = (nt * NT + s) * 32 + jl;
-        nvalid[s] = tile_ok && n < a.Ntot;
-        int nn = nvalid[s] ? n : 0;
-        int b = nn / a.T_out, t = nn - b * a.T_out;
-        ob[s] = b; ot[s] = t;
-        xb[s] = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
-        rep[s] = a.first != nullptr && a.first[b] != 0 && a.exec[b] != 0;
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const f32x4* wp[MTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m) wp[m] = reinterpret_cast<const f32x4*>(a.wpk) + (long)min(mt0 + m, a.Mt - 1) * a.Q * 64 + lane;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* ko = reinterpret_cast<const i32x4*>(a.koff) + kh;
+
+    // groups of U k-quads, double buffered: the gathers / weight fragments of group g+1 are in flight while group g
+    // runs on the matrix core.  Loads past the slice are clamped to its last quad and their MFMAs skipped.
+    f32x4 avA[U][MTB], avB[U][MTB];
+    float bvA[U][4], bvB[U][4];
+#define MMI_W_LOAD(AV, BV, qb)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
+        const int qq = min((qb) + u, q1 - 1);                                                       \
+        const i32x4 o = ko[qq * 2];                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) BV[u][e] = (nvalid && o[e] >= 0) ? xb[o[e]] : 0.f; \
+        _Pragma("unroll") for (int m = 0; m < MTB; ++m) AV[u][m] = wp[m][(long)qq * 64];           \
     }
-    const int qper = (a.Q + KSPLIT - 1) / KSPLIT;
-    const int q0 = ks * qper;
-    const int q1 = min(a.Q, q0 + qper);
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-
-    // (ci, k) of this lane's reduction index kd = q*8 + 2*e + kh, advanced incrementally
-    int kd = q0 * 8 + kh;
-    int ci = kd / a.K, k = kd - ci * a.K;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpk) + ((long)mt * a.Q + q0) * 64 + lane;
-    const int hist = a.H - a.x_off;  // columns (relative to x_off) that belong to the history
-    for (int q = q0; q < q1; ++q) {
-        f32x4 av = mmi_load_nt(wp);
-        wp += 64;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float bv[NT];
-#pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                float v = 0.f;
-                if (nvalid[s] && ci < a.Cin) {
-                    int p = k;                         // column relative to xb (= x_off + t*S)
-                    if (rep[s] && (ot[s] * a.S + p) < hist) p = hist - ot[s] * a.S;  // replicate x[..., :1]
-                    v = xb[s][(long)ci * a.x_ld + p];
-                    if (a.elu_in) v = mmi_elu(v);
-                }
-                bv[s] = v;
-            }
-#pragma unroll
-            for (int s = 0; s < NT; ++s) acc[s] = mmi_mfma_f32_32x32x2(av[e], bv[s], acc[s]);
-            k += 2;
-            while (k >= a.K) { k -= a.K; ++ci; }
+#define MMI_W_MMA(AV, BV, qb)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
+        if ((qb) + u < q1) {                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+                const float v = a.elu_in ? mmi_elu(BV[u][e]) : BV[u][e];                            \
+                _Pragma("unroll") for (int m = 0; m < MTB; ++m) acc[m] = mmi_mfma_f32_32x32x2(AV[u][m][e], v, acc[m]); \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    const int G = (q1 - q0 + U - 1) / U;
+    if (G > 0) {
+        MMI_W_LOAD(avA, bvA, q0);
+        int g = 0;
+        for (; g + 2 < G; g += 2) {
+            MMI_W_LOAD(avB, bvB, q0 + (g + 1) * U);
+            MMI_W_MMA(avA, bvA, q0 + g * U);
+            MMI_W_LOAD(avA, bvA, q0 + (g + 2) * U);
+            MMI_W_MMA(avB, bvB, q0 + (g + 1) * U);
+        }
+        if (G - g == 2) {
+            MMI_W_LOAD(avB, bvB, q0 + (g + 1) * U);
+            MMI_W_MMA(avA, bvA, q0 + g * U);
+            MMI_W_MMA(avB, bvB, q0 + (g + 1) * U);
+        } else {
+            MMI_W_MMA(avA, bvA, q0 + g * U);
         }
     }
+#undef MMI_W_LOAD
+#undef MMI_W_MMA
 
-    if (KSPLIT > 1) {
-        MMI_SHARED float red[4 * NT * 16 * 64];
-        if (ks > 0) {
+    if (W > 1) {   // split-K reduction across the waves, fixed order
+        MMI_DYN_SHARED(float, red);
+        const int NE = MTB * 16 * 64;
 #pragma unroll
-            for (int s = 0; s < NT; ++s)
+        for (int m = 0; m < MTB; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((wave * NT + s) * 16 + r) * 64 + lane] = acc[s][r];
-        }
+            for (int r = 0; r < 16; ++r) red[wave * NE + (m * 16 + r) * 64 + lane] = acc[m][r];
         __syncthreads();
-        if (ks > 0) return;
-        for (int w2 = 1; w2 < KSPLIT; ++w2)
-#pragma unroll
-            for (int s = 0; s < NT; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[s][r] += red[(((wave + w2) * NT + s) * 16 + r) * 64 + lane];
+        for (int e = (int)threadIdx.x; e < NE; e += W * 64) {
+            const int le = e & 63, r = (e >> 6) & 15, m = e >> 10;
+            const int nn2 = (int)blockIdx.x * 32 + (le & 31);
+            const int co = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+            if (nn2 >= a.Ntot || co >= a.Cout) continue;
+            float s = 0.f;
+            for (int w = 0; w < W; ++w) s += red[w * NE + e];
+            const int b2 = nn2 / a.T_out;
+            mmi_conv_store(a, co, b2, nn2 - b2 * a.T_out, s);
+        }
+        return;
     }
-
+    if (!nvalid) return;
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-        if (!nvalid[s]) continue;
+    for (int m = 0; m < MTB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co >= a.Cout) continue;
-            float v = acc[s][r];
-            if (a.bias) v += a.bias[co];
-            if (a.act_out == MMI_ACT_GELU) v = mmi_gelu_erf(v);
-            if (a.scale) v *= a.scale[co];
-            long row = (long)ob[s] * a.Cout + co;
-            if (a.res) v = a.res[row * a.res_ld + a.res_off + ot[s]] + v;
-            a.out[row * a.out_ld + a.out_off + ot[s]] = v;
+            const int co = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < a.Cout) mmi_conv_store(a, co, b, t, acc[m][r]);
+        }
+}
+
+// natural [B][Cin][x_ld] -> packed B operand: im2col (K, S), ELU, replicate padding of the first frame.
+// One thread per (n-subtile, k-quad, lane): 4 elements kd = (q*4+e)*2 + (lane>>5), column n = nt*32 + (lane&31).
+__global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ntn = (a.Ntot + 31) / 32;
+    if (idx >= (long)ntn * a.Q * 64) return;
+    const int lane = (int)(idx & 63);
+    const int q = (int)((idx >> 6) % a.Q);
+    const int nt = (int)((idx >> 6) / a.Q);
+    const int n = nt * 32 + (lane & 31), kh = lane >> 5;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (n < a.Ntot) {
+        const int b = n / a.T_out, t = n - b * a.T_out;
+        const float* xb = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
+        const bool rep = a.first != nullptr && a.first[b] != 0 && a.exec[b] != 0;
+        const int hist = a.H - a.x_off;  // columns (relative to x_off) that belong to the history
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kd = (q * 4 + e) * 2 + kh;
+            const int ci = kd / a.K, k = kd - ci * a.K;
+            if (ci < a.Cin) {
+                int p = k;
+                if (rep && (t * a.S + p) < hist) p = hist - t * a.S;  // replicate x[..., :1]
+                float v = xb[(long)ci * a.x_ld + p];
+                if (a.elu_in) v = mmi_elu(v);
+                o[e] = v;
+            }
         }
     }
+    reinterpret_cast<f32x4*>(bp)[idx] = o;
+}
+
+// grid (Mt, ksplit); NSUB n-subtiles of 32 columns (N <= 32*NSUB); the block's WAVES waves split the workgroup's k-quads.
+template <int NSUB, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int mt = blockIdx.x;
+    const int qb_per = (a.Q + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int qb0 = min(a.Q, (int)blockIdx.y * qb_per), qb1 = min(a.Q, qb0 + qb_per);
+    const int qper = (qb1 - qb0 + WAVES - 1) / WAVES;
+    const int q0 = min(qb1, qb0 + wave * qper);
+    const int nq = min(qb1, q0 + qper) - q0;
+    const int ntn = (a.Ntot + 31) / 32;
+
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpk) + ((long)mt * a.Q + q0) * 64 + lane;
+    const f32x4* bp[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) bp[s] = reinterpret_cast<const f32x4*>(a.bp) + ((long)min(s, ntn - 1) * a.Q + q0) * 64 + lane;
+
+    f32x4 wA[U], bA[U][NSUB], wB[U], bB[U][NSUB];
+#define MMI_F_LOAD(W_, B_, base)                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
+        W_[u] = mmi_load_nt(wp + ((base) + u) * 64);                                          \
+        _Pragma("unroll") for (int s = 0; s < NSUB; ++s) B_[u][s] = bp[s][((base) + u) * 64]; \
+    }
+#define MMI_F_MMA(W_, B_)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                         \
+            _Pragma("unroll") for (int s = 0; s < NSUB; ++s) acc[s] = mmi_mfma_f32_32x32x2(W_[u][e], B_[u][s][e], acc[s]);
+    const int nfull = nq / U;
+    if (nfull > 0) {
+        MMI_F_LOAD(wA, bA, 0);
+        int g = 0;
+        for (; g + 2 < nfull; g += 2) {
+            MMI_F_LOAD(wB, bB, (g + 1) * U);
+            MMI_F_MMA(wA, bA);
+            MMI_F_LOAD(wA, bA, (g + 2) * U);
+            MMI_F_MMA(wB, bB);
+        }
+        if (nfull - g == 2) {
+            MMI_F_LOAD(wB, bB, (g + 1) * U);
+            MMI_F_MMA(wA, bA);
+            MMI_F_MMA(wB, bB);
+        } else {
+            MMI_F_MMA(wA, bA);
+        }
+    }
+    for (int q = nfull * U; q < nq; ++q) {
+        wA[0] = mmi_load_nt(wp + q * 64);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) bA[0][s] = bp[s][q * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) acc[s] = mmi_mfma_f32_32x32x2(wA[0][e], bA[0][s][e], acc[s]);
+    }
+#undef MMI_F_LOAD
+#undef MMI_F_MMA
+
+    constexpr int NE = NSUB * 16 * 64;
+    MMI_SHARED float red[WAVES * NE];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * NE + (s * 16 + r) * 64 + lane] = acc[s][r];
+    __syncthreads();
+    for (int e = (int)threadIdx.x; e < NE; e += WAVES * 64) {
+        const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
+        const int n = s * 32 + (le & 31);
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += red[w * NE + e];
+        if (a.out_mode == MMI_GOUT_PARTIAL) {
+            a.partial[((long)blockIdx.y * a.Mt * 32 + co) * a.Npad + n] = v;     // padded rows / columns included
+            continue;
+        }
+        if (n >= a.Ntot || co >= a.Cout) continue;
+        if (a.out_mode == MMI_GOUT_PACKED) {
+            if (a.bias) v += a.bias[co];
+            if (a.act_out == MMI_ACT_GELU) v = mmi_gelu_erf(v);
+            else if (a.act_out == MMI_ACT_ELU) v = mmi_elu(v);
+            a.outp[mmi_bp_index(co, n, a.outQ)] = v;
+            continue;
+        }
+        const int b = n / a.T_out;
+        mmi_conv_store(a, co, b, n - b * a.T_out, v);
+    }
+}
+
+// sum of the split-K partials + epilogue -> [B][Cout][out_ld]
+__global__ void k_conv_finish(ConvGemmArgs a, int ksplit) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.Cout * a.Ntot) return;
+    const int n = (int)(idx % a.Ntot), co = (int)(idx / a.Ntot);
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += a.partial[((long)s * a.Mt * 32 + co) * a.Npad + n];
+    const int b = n / a.T_out;
+    mmi_conv_store(a, co, b, n - b * a.T_out, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,7 +501,7 @@ __global__ void k_set_mask(uint8_t* __restrict__ dst, const uint8_t* __restrict_
 __global__ __launch_bounds__(64) void k_layernorm_ct(const float* __restrict__ x, int x_ld, int x_off,
                                                      const float* __restrict__ w, const float* __restrict__ bvec,
                                                      float* __restrict__ y, int y_ld, int y_off, int C, int T,
-                                                     float eps) {
+                                                     float eps, float* __restrict__ yp, int yQ) {
     const int b = blockIdx.x / T, t = blockIdx.x % T;
     const int lane = threadIdx.x;
     const float* xc = x + (long)b * C * x_ld + x_off + t;
@@ -349,6 +519,10 @@ __global__ __launch_bounds__(64) void k_layernorm_ct(const float* __restrict__ x
     for (int m = 32; m >= 1; m >>= 1) v += mmi_shfl_xor(v, m);
     const float rstd = mmi_rsqrtf(v / (float)C + eps);
     float* yc = y + (long)b * C * y_ld + y_off + t;
+    if (yp) {   // straight into the packed B operand of the linear that consumes it (column n = b*T + t)
+        for (int c = lane; c < C; c += 64) yp[mmi_bp_index(c, blockIdx.x, yQ)] = (xc[(long)c * x_ld] - mean) * rstd * w[c] + bvec[c];
+        return;
+    }
     for (int c = lane; c < C; c += 64) yc[(long)c * y_ld] = (xc[(long)c * x_ld] - mean) * rstd * w[c] + bvec[c];
 }
 
@@ -363,18 +537,25 @@ struct MimiAttnArgs {
     float* vc;
     const long* offsets;
     float* out;
+    float* outp;   // when set: packed B operand of out_proj (feature h*D+d, column b*T+t) instead of `out`
+    int outQ;
     int B, H, D, T, cap, context;
     float max_period;
 };
 
+// 256 threads; D/4 lanes share a ring row (one 16-byte load each), so a wave instruction reads 64/(D/4) consecutive
+// rows.  Only the min(offset + T, cap) valid slots are visited (the reference masks all `cap`).  T <= 4, D % 4 == 0,
+// 256 % (D/4) == 0.  Dynamic LDS: qs[T][D] | sc[T][cap] | red[(256/(D/4)) * T * D] (also the block-reduction scratch).
 __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, T = a.T, cap = a.cap;
+    const int LPR = D / 4;             // lanes per row
+    const int RPB = 256 / LPR;         // rows per block pass
     MMI_DYN_SHARED(float, sm);
     float* qs = sm;               // [T][D] roped queries
     float* sc = qs + T * D;       // [T][cap] scores / probabilities
-    float* red = sc + T * cap;    // [T][256] reduction scratch... sized [max(T,1)*256]
+    float* red = sc + T * cap;    // [RPB][T][D] partial outputs; first 8 floats double as reduction scratch
     const long off = a.offsets[b];
     const int HD = a.H * D;
     const float* qrow = a.qkv + (long)b * 3 * HD * T;
@@ -382,7 +563,7 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     float* vcb = a.vc + ((long)b * a.H + h) * cap * D;
 
     // phase 1: rope(q), rope(k) -> ring, v -> ring (written unconditionally, transformer.py:243-250)
-    for (int i = tid; i < T * (D / 2); i += nth) {
+    for (int i = tid; i < T * (D / 2); i += 256) {
         int t = i / (D / 2), j = i % (D / 2);
         float freq = expf((float)j * (-logf(a.max_period) * 2.0f / (float)D));
         float ts = (float)(off + t);
@@ -396,82 +577,87 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
         kcb[(long)slot * D + 2 * j] = kr * c - ki * s;
         kcb[(long)slot * D + 2 * j + 1] = kr * s + ki * c;
     }
-    for (int i = tid; i < T * D; i += nth) {
+    for (int i = tid; i < T * D; i += 256) {
         int t = i / D, d = i % D;
         int slot = (int)((off + t) % cap);
         vcb[(long)slot * D + d] = qrow[(long)(2 * HD + h * D + d) * T + t];
     }
     __syncthreads();
 
-    // phase 2: scores.  positions of ring slots after this call's write (transformer.py:258-286)
+    // phase 2: scores over the valid slots.  positions of ring slots after this call's write (transformer.py:258-286)
     const long last = off + T - 1;
     const int end_index = (int)(last % cap);
     const long end_new = off + T;
+    const int L = (int)(end_new < (long)cap ? end_new : (long)cap);
     const float scale = 1.0f / sqrtf((float)D);
-    for (int slot = tid; slot < cap; slot += nth) {
-        int delta = slot - end_index;
-        long pos = delta <= 0 ? last + delta : last + delta - cap;
-        if ((long)slot >= end_new) pos = -1;
-        const float* kr = kcb + (long)slot * D;
-        for (int t = 0; t < T; ++t) {
-            long dq = (off + t) - pos;
-            bool ok = pos >= 0 && dq >= 0 && dq < a.context;
-            float s = -INFINITY;
-            if (ok) {
-                float acc = 0.f;
-                for (int d = 0; d < D; ++d) acc += qs[t * D + d] * kr[d];
-                s = acc * scale;
+    const int seg = tid % LPR, rsub = tid / LPR;
+    for (int s0 = 0; s0 < L; s0 += RPB) {            // block-uniform trip count
+        const int slot = s0 + rsub;
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        long pos = -1;
+        if (slot < L) {
+            int delta = slot - end_index;
+            pos = delta <= 0 ? last + delta : last + delta - cap;
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(kcb + (long)slot * D + seg * 4);
+            for (int t = 0; t < T; ++t) {
+                const float* q = qs + t * D + seg * 4;
+                dot[t] = (q[0] * kk[0] + q[1] * kk[1]) + (q[2] * kk[2] + q[3] * kk[3]);
             }
-            sc[t * cap + slot] = s;
+        }
+        for (int t = 0; t < T; ++t) {
+            float dv = dot[t];
+            for (int m = LPR / 2; m >= 1; m >>= 1) dv += mmi_shfl_xor(dv, m);
+            if (seg == 0 && slot < L) {
+                const long dq = (off + t) - pos;
+                const bool ok = pos >= 0 && dq >= 0 && dq < a.context;
+                sc[t * cap + slot] = ok ? dv * scale : -INFINITY;
+            }
         }
     }
     __syncthreads();
 
-    // phase 3: softmax per query (block reductions through `red`)
+    // phase 3: softmax per query over [0, L)
     for (int t = 0; t < T; ++t) {
         float m = -INFINITY;
-        for (int slot = tid; slot < cap; slot += nth) m = fmaxf(m, sc[t * cap + slot]);
-        red[tid] = m;
+        for (int slot = tid; slot < L; slot += 256) m = fmaxf(m, sc[t * cap + slot]);
+        for (int x = 32; x >= 1; x >>= 1) m = fmaxf(m, mmi_shfl_xor(m, x));
+        if (lane == 0) red[wave] = m;
         __syncthreads();
-        for (int s2 = nth / 2; s2 > 0; s2 >>= 1) {
-            if (tid < s2) red[tid] = fmaxf(red[tid], red[tid + s2]);
-            __syncthreads();
-        }
-        m = red[0];
-        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         float sum = 0.f;
-        for (int slot = tid; slot < cap; slot += nth) {
+        for (int slot = tid; slot < L; slot += 256) {
             float e = expf(sc[t * cap + slot] - m);
             sc[t * cap + slot] = e;
             sum += e;
         }
-        red[tid] = sum;
+        for (int x = 32; x >= 1; x >>= 1) sum += mmi_shfl_xor(sum, x);
+        if (lane == 0) red[4 + wave] = sum;
         __syncthreads();
-        for (int s2 = nth / 2; s2 > 0; s2 >>= 1) {
-            if (tid < s2) red[tid] += red[tid + s2];
-            __syncthreads();
-        }
-        float inv = 1.0f / red[0];
+        const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+        for (int slot = tid; slot < L; slot += 256) sc[t * cap + slot] *= inv;
         __syncthreads();
-        for (int slot = tid; slot < cap; slot += nth) sc[t * cap + slot] *= inv;
     }
-    __syncthreads();
 
-    // phase 4: out[t][d] = sum_slot p[t][slot] * V[slot][d]; thread groups split the slots, then reduce
-    const int groups = nth / D > 0 ? nth / D : 1;   // nth is a multiple of D for the configs we run
-    const int d = tid % D, g = tid / D;
-    for (int t = 0; t < T; ++t) {
-        float acc = 0.f;
-        if (g < groups)
-            for (int slot = g; slot < cap; slot += groups) acc += sc[t * cap + slot] * vcb[(long)slot * D + d];
-        red[tid] = acc;
-        __syncthreads();
-        if (g == 0) {
-            float s = red[d];
-            for (int g2 = 1; g2 < groups; ++g2) s += red[g2 * D + d];
-            a.out[((long)b * HD + h * D + d) * T + t] = s;
+    // phase 4: out[t][d] = sum_slot p[t][slot] * V[slot][d]
+    float acc[4][4];
+    for (int t = 0; t < 4; ++t)
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    for (int slot = rsub; slot < L; slot += RPB) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vcb + (long)slot * D + seg * 4);
+        for (int t = 0; t < T; ++t) {
+            const float pr = sc[t * cap + slot];
+            for (int e = 0; e < 4; ++e) acc[t][e] += pr * vv[e];
         }
-        __syncthreads();
+    }
+    for (int t = 0; t < T; ++t)
+        for (int e = 0; e < 4; ++e) red[(rsub * T + t) * D + seg * 4 + e] = acc[t][e];
+    __syncthreads();
+    for (int i = tid; i < T * D; i += 256) {
+        const int t = i / D, d = i % D;
+        float s = 0.f;
+        for (int r = 0; r < RPB; ++r) s += red[(r * T + t) * D + d];
+        if (a.outp) a.outp[mmi_bp_index(h * D + d, b * T + t, a.outQ)] = s;
+        else a.out[((long)b * HD + h * D + d) * T + t] = s;
     }
 }
 
@@ -497,20 +683,21 @@ __global__ __launch_bounds__(256) void k_rvq_dist(const float* __restrict__ x, i
         int c = i / D, d = i % D;
         Es[c * ldE + d] = (c0 + c) < bins ? E[(long)(c0 + c) * D + d] : 0.f;
     }
-    for (int i = tid; i < Bn * D; i += 256) {
+    const int rg0 = (int)blockIdx.y * 8;   // this block's 8 rows (grid.y = ceil(Bn / 8))
+    for (int i = tid; i < 8 * D; i += 256) {
         int r = i / D, d = i % D;
-        xs[r * D + d] = x[(long)r * x_rstride + d];
+        xs[r * D + d] = (rg0 + r) < Bn ? x[(long)(rg0 + r) * x_rstride + d] : 0.f;
     }
     __syncthreads();
-    const int c = tid & 31, g = tid >> 5;  // 8 row groups, 32 codes
+    const int c = tid & 31, g = tid >> 5;  // 8 rows, 32 codes
     const bool cvalid = (c0 + c) < bins;
     const double en = cvalid ? e2[c0 + c] : 0.0;
-    for (int r0 = 0; r0 < Bn; r0 += 8) {   // uniform trip count: both half-waves take part in the shuffles
-        const int r = r0 + g;
+    {
+        const int r = rg0 + g;
         const bool rvalid = r < Bn;
         double acc = 0.0;
         if (rvalid)
-            for (int d = 0; d < D; ++d) acc += (double)Es[c * ldE + d] * (double)xs[r * D + d];
+            for (int d = 0; d < D; ++d) acc += (double)Es[c * ldE + d] * (double)xs[g * D + d];
         double dist = (cvalid && rvalid) ? en - 2.0 * acc : INFINITY;
         int idx = c0 + c;
         // argmin over the 32 codes held by this half-wave (xor masks < 32 stay inside it)
@@ -531,16 +718,24 @@ __global__ __launch_bounds__(256) void k_rvq_select(const double* __restrict__ b
                                                     int codes_rstride, int level, int Bn, int D) {
     const int r = blockIdx.x;
     MMI_SHARED int widx;
-    if (threadIdx.x == 0) {
-        double bd = best_d[r];
-        int bi = best_i[r];
-        for (int ch = 1; ch < nchunk; ++ch) {
+    if (threadIdx.x < 64) {   // first wave: strided scan of the chunk winners, then a wave argmin (lowest index on ties)
+        double bd = INFINITY;
+        int bi = 0x7fffffff;
+        for (int ch = threadIdx.x; ch < nchunk; ch += 64) {
             double d = best_d[(long)ch * Bn + r];
             int i = best_i[(long)ch * Bn + r];
             if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
         }
-        widx = bi;
-        codes[(long)r * codes_rstride + level] = bi;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            double od = mmi_shfl_xor(bd, m);
+            int oi = mmi_shfl_xor(bi, m);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
+        if (threadIdx.x == 0) {
+            widx = bi;
+            codes[(long)r * codes_rstride + level] = bi;
+        }
     }
     __syncthreads();
     const int idx = widx;

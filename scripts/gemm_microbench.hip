@@ -27,6 +27,19 @@ __global__ void k_fill_rand_bf16(uint16_t* p, size_t n, unsigned seed) {
     }
 }
 
+// speed-of-light reference: stream the same bytes with 16-byte non-temporal loads and nothing else
+__global__ __launch_bounds__(256) void k_stream_read(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 a = mmi_load_nt(p + i), b = mmi_load_nt(p + i + stride), c = mmi_load_nt(p + i + 2 * stride), d = mmi_load_nt(p + i + 3 * stride);
+        acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    for (; i < n16; i += stride) acc ^= mmi_load_nt(p + i)[0];
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 struct Shape { const char* name; int N, K, gate; };
 
 typedef void (*launch_fn)(dim3 groups, hipStream_t s, const GemmArgs& a);
@@ -87,6 +100,21 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(out, 0, oelems * 2, s));
         CK(hipStreamSynchronize(s));
         printf("== %s  (%.1f MB, %d n-tiles x %d k-steps, %d buffers)\n", sh.name, wbytes / 1e6, NT, KS, nbuf);
+        for (int blocks : {1024, 2048, 4096}) {      // pure read of the same buffers
+            unsigned* sink = (unsigned*)out;
+            const int reps = wbytes > 50e6 ? 3 : 10;
+            for (int i = 0; i < nbuf; ++i) k_stream_read<<<blocks, 256, 0, s>>>((const u32x4*)(w + welems * i), wbytes / 16, sink);
+            CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r)
+                for (int i = 0; i < nbuf; ++i) k_stream_read<<<blocks, 256, 0, s>>>((const u32x4*)(w + welems * i), wbytes / 16, sink);
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / (reps * nbuf);
+            printf("   pure nt read, %4d blocks                 %8.2f us  %7.0f GB/s\n", blocks, us, wbytes / us / 1e3);
+        }
         for (const Variant& v : variants) {
             if (v.TN != T || v.MT != MT) continue;
             GemmArgs a;

@@ -1,0 +1,14 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+timeout 300 python bench.py --workload mimi --batch 32 --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/bench_mimi_b32.log 2>&1
+timeout 300 python bench.py --workload mimi --batch 8 --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/bench_mimi_b8.log 2>&1
+timeout 300 python bench.py --workload mimi --batch 1 --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/bench_mimi_b1.log 2>&1
+timeout 300 python bench.py --workload lm --batch 32 --steps 60 --warmup 12 --no-cpu-baseline > gpurun_out/bench_lm_b32.log 2>&1
+timeout 400 python bench.py --no-cpu-baseline > gpurun_out/bench_duplex_b32.log 2>&1
+cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_mimi_b32 -o mimi -- python $GRAFT_REPO_ROOT/bench.py --workload mimi --batch 32 --steps 30 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof_mimi.log 2>&1
+cd $GRAFT_REPO_ROOT
+tail -n 3 gpurun_out/smoke.log; tail -n 5 gpurun_out/pytest_gpu.log; for f in bench_mimi_b32 bench_mimi_b8 bench_mimi_b1 bench_lm_b32 bench_duplex_b32; do tail -n 1 gpurun_out/$f.log | cut -c1-250; done
