@@ -138,7 +138,7 @@ int load_copy(mmi_lm* lm, const MmiWeights& W, const std::string& name, int ndim
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-struct GemmPlan { int waves, ntw, ksplit; };
+struct GemmPlan { int waves, ntw, ksplit, u; };
 
 // How a GEMM is cut into workgroups (measured on MI355X with scripts/gemm_microbench.hip): enough workgroups to
 // cover the 256 CUs, K split over the waves of a workgroup, more waves per workgroup when there are few n-tiles.
@@ -154,6 +154,9 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     }
     const int ks = g.KSTEPS / p.ksplit;
     p.waves = ks >= 32 ? 8 : 4;
+    // fragments in flight per register buffer: 2 for the widest GEMM (the temporal FFN linear_in, 704 n-tiles: fewer
+    // registers -> 3 workgroups per CU -> all 704 resident at once; 36.8 vs 39.3 us in the microbenchmark), else 4
+    p.u = (g.gate && g.NT >= 512 && p.waves == 8) ? 2 : 4;
     const char* e = getenv("MMI_GEMM_WAVES");
     if (e && atoi(e) > 0) p.waves = atoi(e);
     e = getenv("MMI_GEMM_NTW");
@@ -162,7 +165,12 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
 }
 
 template <int TN, int MT, int NTW>
-int launch_gemm_w(hipStream_t s, dim3 groups, int waves, const GemmArgs& a) {
+int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, const GemmArgs& a) {
+    if (waves == 8 && u == 2 && MT * NTW == 1) {
+        if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
     switch (waves) {
         case 4: MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 4>), groups, 256, 0, s, a); break;
         case 8:
@@ -177,10 +185,10 @@ int launch_gemm_w(hipStream_t s, dim3 groups, int waves, const GemmArgs& a) {
 template <int TN>
 int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
     const dim3 groups(mmi_cdiv(NT, p.ntw), p.ksplit);
-    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, a);
-    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, a);
-    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, a);
-    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, a);
+    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, a);
+    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, a);
+    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, a);
+    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, p.u, a);
     return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
 }
 
@@ -721,7 +729,7 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
         // algorithmic bytes of one FFN linear_in launch: packed weights + activations in + gated activations out
         *bytes_per_launch = (int64_t)2 * c.ffn_hidden * c.dim * 2 + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
     }
-    if (kernel_name) *kernel_name = "k_gemm_xp<32,1,1,8,4> (temporal FFN linear_in + SiLU gate)";
+    if (kernel_name) *kernel_name = "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;
 }

@@ -106,11 +106,37 @@ struct GemmArgs {
     float eps;
 };
 
+// The residual (or embedding) vector the thread's FIRST epilogue task will add, requested before the weight stream starts
+// so that its latency is hidden behind the main loop instead of extending the epilogue.
+template <int TN, int MT, int NTW>
+__device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int nt0) {
+    u32x4 pre = {0u, 0u, 0u, 0u};
+    if (a.epi != MMI_EPI_RESID && a.epi != MMI_EPI_EMB) return pre;
+    const int G = TN / 8;
+    const int q = (int)threadIdx.x;
+    if (q >= NTW * MT * G * TN) return pre;
+    const int bl = q % TN;
+    int rest = q / TN;
+    const int gi = rest % G;
+    rest /= G;
+    const int m = rest % MT, t = rest / MT;
+    const int nt = nt0 + t, b = m * TN + bl, n0 = nt * TN + 8 * gi;
+    if (nt >= a.NT || b >= a.B || n0 >= a.N) return pre;
+    if (a.epi == MMI_EPI_RESID) {
+        const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.resid + (long)b * a.out_ld + n0;
+        pre = *reinterpret_cast<const u32x4*>(rs);
+    } else {
+        const int tk = a.tok[(long)b * a.tok_stride];
+        if (tk != -1) pre = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
+    }
+    return pre;
+}
+
 // Split-K reduction across the workgroup's waves (fixed order -> deterministic) and the epilogue shared by the GEMM
 // kernels: one task = 8 consecutive output features of one session, written as one 16-byte vector.
 template <int TN, int MT, int NTW, int WAVES>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
-                                                  int nt0) {
+                                                  int nt0, u32x4 pre) {
     constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic)
     constexpr int NE = NTW * MT * R * 64;
@@ -210,16 +236,19 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         } else if (a.epi == MMI_EPI_RESID) {
             const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps)
                                                               : a.resid + (long)b * a.out_ld + n0;
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(rs);
+            const u32x4 rv = q == (int)threadIdx.x ? pre : *reinterpret_cast<const u32x4*>(rs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint16_t h = (uint16_t)((e & 1) ? (rv[e >> 1] >> 16) : (rv[e >> 1] & 0xffffu));
                 o[e] = mmi_round_bf16(s[e]) + mmi_bf16_to_f32(h);           // x_orig + update
             }
         } else if (a.epi == MMI_EPI_EMB) {
-            const int tk = a.tok[(long)b * a.tok_stride];
-            u32x4 ev = {0u, 0u, 0u, 0u};
-            if (tk != -1) ev = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
+            u32x4 ev = pre;
+            if (q != (int)threadIdx.x) {
+                const int tk = a.tok[(long)b * a.tok_stride];
+                ev = u32x4{0u, 0u, 0u, 0u};
+                if (tk != -1) ev = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint16_t h = (uint16_t)((e & 1) ? (ev[e >> 1] >> 16) : (ev[e >> 1] & 0xffffu));
@@ -242,6 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int nt0 = (int)blockIdx.x * NTW;
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW>(a, nt0);
 
     // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
     const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < R; ++r) accv[t][m][r] = acc[t][m][r];
-    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0);
+    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre);
 }
 
 // RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
@@ -340,17 +370,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
     const int kq = TN == 32 ? (lane >> 5) : (lane >> 4);
 
-    const u32x4* wp = a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
     u32x4 wv[KMAX], xv[MT][KMAX], al[KMAX];
     const u32x4 zero = {0u, 0u, 0u, 0u};
+    // every load is unconditional from a clamped (valid) address and masked afterwards: conditional loads would be
+    // serialised behind s_waitcnt vmcnt(0) by the compiler, and these GEMMs live on having the whole slice in flight
+    const int ksl = min(ks0, a.KSTEPS - 1);
+    const int dmax = (a.D - 8) > 0 ? (a.D - 8) : 0;
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        const int uu = min(u, nks > 0 ? nks - 1 : 0);
+        const int k = (ksl + uu) * KS + 8 * kq;
+        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + lane);
+        al[u] = *reinterpret_cast<const u32x4*>(a.alpha + min(k, dmax));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xv[m][u] = a.xp[((long)m * a.KSTEPS + ksl + uu) * 64 + lane];
+    }
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         const bool on = u < nks;
         const int k = (ks0 + u) * KS + 8 * kq;
-        wv[u] = on ? mmi_load_nt(wp + u * 64) : zero;
-        al[u] = (on && k < a.D) ? *reinterpret_cast<const u32x4*>(a.alpha + k) : zero;
+        if (!on) wv[u] = zero;
+        if (!on || k >= a.D) al[u] = zero;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xv[m][u] = on ? a.xp[((long)m * a.KSTEPS + ks0 + u) * 64 + lane] : zero;
+        for (int m = 0; m < MT; ++m) if (!on) xv[m][u] = zero;
     }
     // sum of squares of this lane's row over the wave's slice (the kq lane groups hold different k of the same row)
     MMI_SHARED float ssum[WAVES][MT][TN];
@@ -403,7 +445,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
-    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0);
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,11 +480,18 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
             float u[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = 0.f;
-            for (int p = 0; p < P; ++p) {
-                const float* pp = partial + ((long)p * B + b) * D + i;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+            f32x4 plo[4], phi[4];                                  // P <= 4; unconditional (clamped) loads, all in flight
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { u[e] += lo[e]; u[4 + e] += hi[e]; }
+            for (int p = 0; p < 4; ++p) {
+                const float* pp = partial + ((long)min(p, P - 1) * B + b) * D + i;
+                plo[p] = *reinterpret_cast<const f32x4*>(pp);
+                phi[p] = *reinterpret_cast<const f32x4*>(pp + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float on = p < P ? 1.f : 0.f;                // exact: x*1 = x, finite x*0 = 0
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u[e] += plo[p][e] * on; u[4 + e] += phi[p][e] * on; }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[j][e] = mmi_round_bf16(mmi_round_bf16(u[e]) + f[j][e]);
@@ -556,29 +605,39 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int c0 = (int)blockIdx.y * CH; c0 < L; c0 += (int)gridDim.y * CH) {     // block-uniform trip count
-        // ---- scores of this chunk
-        for (int it = 0; it < PER_WAVE / RPW; ++it) {
-            const int rl = wave * PER_WAVE + it * RPW + rsub;
-            const int slot = c0 + rl;
-            bool valid = slot < L;
-            if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
-                int delta = slot - end_index;
-                long pos = delta <= 0 ? off + delta : off + delta - a.cap;
-                long dq = off - pos;
-                valid = pos >= 0 && dq >= 0 && dq < a.context;
+        // ---- scores of this chunk: all of the wave's key rows are requested up front (unconditional loads from a clamped
+        // slot; a load under `if (valid)` would be serialised behind s_waitcnt vmcnt(0)), then reduced
+        constexpr int NIT = PER_WAVE / RPW;
+        constexpr int NB = NIT < 8 ? NIT : 8;             // rows in flight per lane: 8 x 16 bytes keeps the kernel at <= 96 VGPRs
+#pragma unroll 1
+        for (int h0 = 0; h0 < NIT; h0 += NB) {
+            u32x4 kk[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
+                kk[i] = *reinterpret_cast<const u32x4*>(kbase + (long)slot * DH + seg * 8);
             }
-            float dot = 0.f;
-            if (valid) {
-                u32x4 kk = *reinterpret_cast<const u32x4*>(kbase + (long)slot * DH + seg * 8);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
+                const int slot = c0 + rl;
+                bool valid = slot < L;
+                if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
+                    int delta = slot - end_index;
+                    long pos = delta <= 0 ? off + delta : off + delta - a.cap;
+                    long dq = off - pos;
+                    valid = pos >= 0 && dq >= 0 && dq < a.context;
+                }
+                float dot = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    dot += qv[2 * q] * mmi_bf16_to_f32((uint16_t)(kk[q] & 0xffffu));
-                    dot += qv[2 * q + 1] * mmi_bf16_to_f32((uint16_t)(kk[q] >> 16));
+                    dot += qv[2 * q] * mmi_bf16_to_f32((uint16_t)(kk[i][q] & 0xffffu));
+                    dot += qv[2 * q + 1] * mmi_bf16_to_f32((uint16_t)(kk[i][q] >> 16));
                 }
-            }
 #pragma unroll
-            for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
-            if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
+                for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
+                if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
+            }
         }
         __syncthreads();
         // ---- online softmax update
@@ -603,17 +662,23 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] *= resc;
-        // ---- P.V
-        for (int it = 0; it < PER_WAVE / RPW; ++it) {
-            const int rl = wave * PER_WAVE + it * RPW + rsub;
-            const int slot = c0 + rl;
-            const float pr = sc[rl];
-            if (pr != 0.f && slot < L) {
-                u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (long)slot * DH + seg * 8);
+        // ---- P.V (value rows requested up front as well; rows past L carry p = 0 and finite ring contents)
+#pragma unroll 1
+        for (int h0 = 0; h0 < NIT; h0 += NB) {
+            u32x4 vv[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
+                vv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)slot * DH + seg * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
+                const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[2 * q] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] & 0xffffu));
-                    acc[2 * q + 1] += pr * mmi_bf16_to_f32((uint16_t)(vv[q] >> 16));
+                    acc[2 * q] += pr * mmi_bf16_to_f32((uint16_t)(vv[i][q] & 0xffffu));
+                    acc[2 * q + 1] += pr * mmi_bf16_to_f32((uint16_t)(vv[i][q] >> 16));
                 }
             }
         }
@@ -694,24 +759,39 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
         vcb[(long)a.k * Dh + lane] = vn;
     }
     const float scale = 1.0f / sqrtf((float)Dh);
+    // rows 0..k-1 of this frame's cache, all requested up front (unconditional loads from a clamped row); steps <= 16
+    float kr[16], vr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int jc = j < a.k ? j : (a.k > 0 ? a.k - 1 : 0);
+        const int lc = on ? lane : 0;
+        kr[j] = mmi_bf16_to_f32(kcb[(long)jc * Dh + lc]);
+        vr[j] = mmi_bf16_to_f32(vcb[(long)jc * Dh + lc]);
+    }
     float sc[16];
     float mx = -INFINITY;
-    for (int j = 0; j <= a.k; ++j) {
-        float kv = 0.f;
-        if (on) kv = (j == a.k) ? mmi_bf16_to_f32(kn) : mmi_bf16_to_f32(kcb[(long)j * Dh + lane]);
-        float d = q * kv;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) d += mmi_shfl_xor(d, m);
-        sc[j] = d * scale;
-        mx = fmaxf(mx, sc[j]);
+    for (int j = 0; j < 16; ++j) {
+        if (j <= a.k) {
+            float kv = 0.f;
+            if (on) kv = (j == a.k) ? mmi_bf16_to_f32(kn) : kr[j];
+            float d = q * kv;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) d += mmi_shfl_xor(d, m);
+            sc[j] = d * scale;
+            mx = fmaxf(mx, sc[j]);
+        }
     }
     float den = 0.f, o = 0.f;
-    for (int j = 0; j <= a.k; ++j) {
-        float p = expf(sc[j] - mx);
-        den += p;
-        float vv = 0.f;
-        if (on) vv = (j == a.k) ? mmi_bf16_to_f32(vn) : mmi_bf16_to_f32(vcb[(long)j * Dh + lane]);
-        o += p * vv;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j <= a.k) {
+            float p = expf(sc[j] - mx);
+            den += p;
+            float vv = 0.f;
+            if (on) vv = (j == a.k) ? mmi_bf16_to_f32(vn) : vr[j];
+            o += p * vv;
+        }
     }
     if (on) a.out[mmi_xp_index(a.T, b, h * Dh + lane, a.out_ksteps)] = mmi_f32_to_bf16(o / den);
 }

@@ -255,8 +255,7 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
         switch (p.MTB) {
             case 1: launch_wide_w<1, 4>(s, a, p.W, grid); break;
             case 2: launch_wide_w<2, 4>(s, a, p.W, grid); break;
-            case 4: launch_wide_w<4, 2>(s, a, p.W, grid); break;
-            default: launch_wide_w<8, 1>(s, a, p.W, grid); break;
+            default: launch_wide_w<4, 2>(s, a, p.W, grid); break;
         }
         MMI_CHECK_LAUNCH();
         return MMI_OK;
@@ -293,14 +292,14 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         const int nsub = mmi_cdiv(N, 32);
         // m-tiles per wave (each gathered + ELU'd operand element is reused MTB times) vs. waves in flight:
         // aim for >= 1024 waves, taking the parallelism from split-K waves (W) before shrinking MTB
-        int MTB = 8;
+        int MTB = 4;                         // 8 m-tiles per wave needs > 256 registers per lane: one wave per SIMD, slower
         while (MTB > a.Mt) MTB >>= 1;
         int W = 1;
         auto waves = [&](int mtb, int w) { return nsub * mmi_cdiv(a.Mt, mtb) * w; };
         auto wmax = [&](int mtb) { int w = 1; while (w < 8 && w * 2 * mtb <= 16 && a.Q / (w * 2) >= 4) w <<= 1; return w; };
         while (MTB > 1 && waves(MTB, wmax(MTB)) < 1024) MTB >>= 1;
         while (W < wmax(MTB) && waves(MTB, W) < 1024) W <<= 1;
-        if (const char* e = getenv("MMI_CONV_MTB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) MTB = v; }   // test hooks
+        if (const char* e = getenv("MMI_CONV_MTB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) MTB = v; }   // test hooks
         if (const char* e = getenv("MMI_CONV_W")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) W = v; }
         while (W * MTB > 16) W >>= 1;          // split-K reduction buffer: W * MTB * 4 KiB of LDS, keep it within 64 KiB
         p->MTB = MTB; p->W = W;
@@ -309,7 +308,7 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
             for (int h = 0; h < 2; ++h)
                 for (int e = 0; e < 4; ++e) {
                     const int kd = (q * 4 + e) * 2 + h;
-                    tab[((size_t)q * 2 + h) * 4 + e] = kd < a.Cin * a.K ? (kd / a.K) * a.x_ld + kd % a.K : -1;
+                    tab[((size_t)q * 2 + h) * 4 + e] = kd < a.Cin * a.K ? (kd / a.K) * a.x_ld + kd % a.K : 0;
                 }
         int* dev = nullptr;
         MMI_HIP_CHECK(arena.alloc(&dev, tab.size()));
@@ -721,6 +720,7 @@ int check_cfg(const mmi_mimi_cfg& c) {
     const int Dh = c.tr_d_model / c.tr_num_heads;
     if (Dh * c.tr_num_heads != c.tr_d_model || (Dh & 3) || 256 % Dh != 0)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be a multiple of 4 and divide 256");
+    if (c.tr_d_model > 1024) return mmi_fail(MMI_ERR_UNSUPPORTED, "transformer width above the LayerNorm kernel's register budget");
     if (c.compress < 1 || c.q_n_q_semantic < 1 || c.q_n_q < c.q_n_q_semantic)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "bad quantizer/compress config");
     return MMI_OK;

@@ -111,7 +111,7 @@ struct ConvGemmArgs {
     int elu_in;           // apply ELU(alpha=1) to every loaded input (seanet.py:63,205,222)
     int act_out;          // MMI_ACT_*
     // --- filled in by the engine's planner
-    const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h, or -1 past Cin*K
+    const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h; 0 past Cin*K (the weights there are 0)
     const float* bp;      // k_gemm_f32: packed activations [ceil(N/32)][Q][64][4]
     int x_packed;         // the producer already wrote `bp` (no k_pack_b_f32 launch)
     int out_mode;         // MMI_GOUT_*
@@ -129,15 +129,42 @@ __device__ __forceinline__ long mmi_bp_index(int kd, int n, int Q) {
     return ((((long)(n >> 5) * Q + (kd >> 3)) * 64) + (kd & 1) * 32 + (n & 31)) * 4 + ((kd & 7) >> 1);
 }
 
-// bias / activation / LayerScale / residual, then the store to [B][Cout][out_ld] - shared by the three epilogues
-__device__ __forceinline__ void mmi_conv_store(const ConvGemmArgs& a, int co, int b, int t, float v) {
-    if (a.bias) v += a.bias[co];
-    if (a.act_out == MMI_ACT_GELU) v = mmi_gelu_erf(v);
-    else if (a.act_out == MMI_ACT_ELU) v = mmi_elu(v);
-    if (a.scale) v *= a.scale[co];
-    const long row = (long)b * a.Cout + co;
-    if (a.res) v = a.res[row * a.res_ld + a.res_off + t] + v;
-    a.out[row * a.out_ld + a.out_off + t] = v;
+// bias / activation / LayerScale / residual, then the store to [B][Cout][out_ld] - shared by the epilogues.
+// NV results of one thread are finished together: all bias / scale / residual loads are issued first (under branches
+// that are uniform for the launch), so that the epilogue costs one memory round trip instead of NV of them.
+template <int NV>
+__device__ __forceinline__ void mmi_conv_store_n(const ConvGemmArgs& a, const int (&co)[NV], const int (&b)[NV], const int (&t)[NV],
+                                                 const bool (&ok)[NV], float (&v)[NV]) {
+    float bia[NV], scl[NV], rsv[NV];
+    long row[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = ok[i] ? co[i] : 0;
+        row[i] = (long)(ok[i] ? b[i] : 0) * a.Cout + cc;
+        bia[i] = 0.f; scl[i] = 1.f; rsv[i] = 0.f;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bia[i] = a.bias[ok[i] ? co[i] : 0];
+    }
+    if (a.scale) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scl[i] = a.scale[ok[i] ? co[i] : 0];
+    }
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rsv[i] = a.res[row[i] * a.res_ld + a.res_off + (ok[i] ? t[i] : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float x = v[i];
+        if (a.bias) x += bia[i];
+        if (a.act_out == MMI_ACT_GELU) x = mmi_gelu_erf(x);
+        else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
+        if (a.scale) x *= scl[i];
+        if (a.res) x = rsv[i] + x;
+        if (ok[i]) a.out[row[i] * a.out_ld + a.out_off + t[i]] = x;
+    }
 }
 
 template <int MTB, int W, int U>
@@ -172,7 +199,9 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
         const int qq = min((qb) + u, q1 - 1);                                                       \
         const i32x4 o = ko[qq * 2];                                                                 \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) BV[u][e] = (nvalid && o[e] >= 0) ? xb[o[e]] : 0.f; \
+        /* plain unconditional gathers (a conditional load would be serialised behind s_waitcnt vmcnt(0)): reduction   \
+           indices past Cin*K point at offset 0 and meet zero weights; columns past Ntot are computed and discarded */  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) BV[u][e] = xb[o[e]];                          \
         _Pragma("unroll") for (int m = 0; m < MTB; ++m) AV[u][m] = wp[m][(long)qq * 64];           \
     }
 #define MMI_W_MMA(AV, BV, qb)                                                                       \
@@ -213,26 +242,49 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[wave * NE + (m * 16 + r) * 64 + lane] = acc[m][r];
         __syncthreads();
-        for (int e = (int)threadIdx.x; e < NE; e += W * 64) {
-            const int le = e & 63, r = (e >> 6) & 15, m = e >> 10;
-            const int nn2 = (int)blockIdx.x * 32 + (le & 31);
-            const int co = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
-            if (nn2 >= a.Ntot || co >= a.Cout) continue;
-            float s = 0.f;
-            for (int w = 0; w < W; ++w) s += red[w * NE + e];
-            const int b2 = nn2 / a.T_out;
-            mmi_conv_store(a, co, b2, nn2 - b2 * a.T_out, s);
+        constexpr int NVT = MTB * 16 / W;                      // results per thread (W divides 16)
+        constexpr int NV = NVT < 8 ? NVT : 8;                  // finished 8 at a time (register budget)
+#pragma unroll 1
+        for (int i0 = 0; i0 < NVT; i0 += NV) {
+            int co[NV], bb[NV], tt[NV];
+            bool ok[NV];
+            float v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = (int)threadIdx.x + (i0 + i) * W * 64;
+                const int le = e & 63, r = (e >> 6) & 15, m = e >> 10;
+                const int nn2 = (int)blockIdx.x * 32 + (le & 31);
+                co[i] = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+                ok[i] = nn2 < a.Ntot && co[i] < a.Cout;
+                const int n3 = ok[i] ? nn2 : 0;
+                bb[i] = n3 / a.T_out;
+                tt[i] = n3 - bb[i] * a.T_out;
+                float s = 0.f;
+                for (int w = 0; w < W; ++w) s += red[w * NE + e];
+                v[i] = s;
+            }
+            mmi_conv_store_n<NV>(a, co, bb, tt, ok, v);
         }
         return;
     }
-    if (!nvalid) return;
 #pragma unroll
-    for (int m = 0; m < MTB; ++m)
+    for (int m = 0; m < MTB; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co < a.Cout) mmi_conv_store(a, co, b, t, acc[m][r]);
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            int co[8], bb[8], tt[8];
+            bool ok[8];
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + i;
+                co[i] = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                ok[i] = nvalid && co[i] < a.Cout;
+                bb[i] = b; tt[i] = t;
+                v[i] = acc[m][r];
+            }
+            mmi_conv_store_n<8>(a, co, bb, tt, ok, v);
         }
+    }
 }
 
 // natural [B][Cin][x_ld] -> packed B operand: im2col (K, S), ELU, replicate padding of the first frame.
@@ -246,22 +298,23 @@ __global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {
     const int nt = (int)((idx >> 6) / a.Q);
     const int n = nt * 32 + (lane & 31), kh = lane >> 5;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (n < a.Ntot) {
-        const int b = n / a.T_out, t = n - b * a.T_out;
+    {   // columns past Ntot / reduction indices past Cin*K read a clamped (valid) element: they meet zero weights or are
+        // discarded, and unconditional loads are not serialised by the compiler
+        const int nc = n < a.Ntot ? n : 0;
+        const int b = nc / a.T_out, t = nc - b * a.T_out;
         const float* xb = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
         const bool rep = a.first != nullptr && a.first[b] != 0 && a.exec[b] != 0;
         const int hist = a.H - a.x_off;  // columns (relative to x_off) that belong to the history
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int kd = (q * 4 + e) * 2 + kh;
-            const int ci = kd / a.K, k = kd - ci * a.K;
-            if (ci < a.Cin) {
-                int p = k;
-                if (rep && (t * a.S + p) < hist) p = hist - t * a.S;  // replicate x[..., :1]
-                float v = xb[(long)ci * a.x_ld + p];
-                if (a.elu_in) v = mmi_elu(v);
-                o[e] = v;
-            }
+            const int ci0 = kd / a.K, k = kd - ci0 * a.K;
+            const int ci = ci0 < a.Cin ? ci0 : a.Cin - 1;
+            int p = k;
+            if (rep && (t * a.S + p) < hist) p = hist - t * a.S;  // replicate x[..., :1]
+            float v = xb[(long)ci * a.x_ld + p];
+            if (a.elu_in) v = mmi_elu(v);
+            o[e] = v;
         }
     }
     reinterpret_cast<f32x4*>(bp)[idx] = o;
@@ -336,28 +389,50 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave * NE + (s * 16 + r) * 64 + lane] = acc[s][r];
     __syncthreads();
-    for (int e = (int)threadIdx.x; e < NE; e += WAVES * 64) {
-        const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
-        const int n = s * 32 + (le & 31);
-        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
-        float v = 0.f;
+    constexpr int NV = NE / (WAVES * 64);
+    int co[NV], nn[NV];
+    float v[NV];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) v += red[w * NE + e];
-        if (a.out_mode == MMI_GOUT_PARTIAL) {
-            a.partial[((long)blockIdx.y * a.Mt * 32 + co) * a.Npad + n] = v;     // padded rows / columns included
-            continue;
-        }
-        if (n >= a.Ntot || co >= a.Cout) continue;
-        if (a.out_mode == MMI_GOUT_PACKED) {
-            if (a.bias) v += a.bias[co];
-            if (a.act_out == MMI_ACT_GELU) v = mmi_gelu_erf(v);
-            else if (a.act_out == MMI_ACT_ELU) v = mmi_elu(v);
-            a.outp[mmi_bp_index(co, n, a.outQ)] = v;
-            continue;
-        }
-        const int b = n / a.T_out;
-        mmi_conv_store(a, co, b, n - b * a.T_out, v);
+    for (int i = 0; i < NV; ++i) {
+        const int e = (int)threadIdx.x + i * WAVES * 64;
+        const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
+        nn[i] = s * 32 + (le & 31);
+        co[i] = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) x += red[w * NE + e];
+        v[i] = x;
     }
+    if (a.out_mode == MMI_GOUT_PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a.partial[((long)blockIdx.y * a.Mt * 32 + co[i]) * a.Npad + nn[i]] = v[i];   // padded rows / columns included
+        return;
+    }
+    if (a.out_mode == MMI_GOUT_PACKED) {
+        float bia[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bia[i] = a.bias ? a.bias[co[i] < a.Cout ? co[i] : 0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (nn[i] >= a.Ntot || co[i] >= a.Cout) continue;
+            float x = v[i];
+            if (a.bias) x += bia[i];
+            if (a.act_out == MMI_ACT_GELU) x = mmi_gelu_erf(x);
+            else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
+            a.outp[mmi_bp_index(co[i], nn[i], a.outQ)] = x;
+        }
+        return;
+    }
+    int bb[NV], tt[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ok[i] = nn[i] < a.Ntot && co[i] < a.Cout;
+        const int n3 = ok[i] ? nn[i] : 0;
+        bb[i] = n3 / a.T_out;
+        tt[i] = n3 - bb[i] * a.T_out;
+    }
+    mmi_conv_store_n<NV>(a, co, bb, tt, ok, v);
 }
 
 // sum of the split-K partials + epilogue -> [B][Cout][out_ld]
@@ -365,10 +440,17 @@ __global__ void k_conv_finish(ConvGemmArgs a, int ksplit) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)a.Cout * a.Ntot) return;
     const int n = (int)(idx % a.Ntot), co = (int)(idx / a.Ntot);
-    float v = 0.f;
-    for (int s = 0; s < ksplit; ++s) v += a.partial[((long)s * a.Mt * 32 + co) * a.Npad + n];
-    const int b = n / a.T_out;
-    mmi_conv_store(a, co, b, n - b * a.T_out, v);
+    float pv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) pv[s] = a.partial[((long)min(s, ksplit - 1) * a.Mt * 32 + co) * a.Npad + n];   // ksplit <= 8, all in flight
+    float x = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x += s < ksplit ? pv[s] : 0.f;
+    const int bq = n / a.T_out;
+    int co1[1] = {co}, b1[1] = {bq}, t1[1] = {n - bq * a.T_out};
+    bool ok1[1] = {true};
+    float v1[1] = {x};
+    mmi_conv_store_n<1>(a, co1, b1, t1, ok1, v1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,25 +587,37 @@ __global__ __launch_bounds__(64) void k_layernorm_ct(const float* __restrict__ x
     const int b = blockIdx.x / T, t = blockIdx.x % T;
     const int lane = threadIdx.x;
     const float* xc = x + (long)b * C * x_ld + x_off + t;
+    constexpr int NR = 16;                 // channels per lane held in registers (C <= 1024), one round of loads
+    float xv[NR];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xc[(long)c * x_ld];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = lane + i * 64;
+        xv[i] = xc[(long)(c < C ? c : 0) * x_ld];
+        s += c < C ? xv[i] : 0.f;
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += mmi_shfl_xor(s, m);
     const float mean = s / (float)C;
     float v = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        float d = xc[(long)c * x_ld] - mean;
-        v += d * d;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const float d = xv[i] - mean;
+        v += (lane + i * 64) < C ? d * d : 0.f;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += mmi_shfl_xor(v, m);
     const float rstd = mmi_rsqrtf(v / (float)C + eps);
     float* yc = y + (long)b * C * y_ld + y_off + t;
-    if (yp) {   // straight into the packed B operand of the linear that consumes it (column n = b*T + t)
-        for (int c = lane; c < C; c += 64) yp[mmi_bp_index(c, blockIdx.x, yQ)] = (xc[(long)c * x_ld] - mean) * rstd * w[c] + bvec[c];
-        return;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = lane + i * 64;
+        if (c < C) {
+            const float o = (xv[i] - mean) * rstd * w[c] + bvec[c];
+            if (yp) yp[mmi_bp_index(c, blockIdx.x, yQ)] = o;   // packed B operand of the consuming linear (column n = b*T + t)
+            else yc[(long)c * y_ld] = o;
+        }
     }
-    for (int c = lane; c < C; c += 64) yc[(long)c * y_ld] = (xc[(long)c * x_ld] - mean) * rstd * w[c] + bvec[c];
 }
 
 // RoPE (rope.py:11-82, interleaved) on q,k + ring-KV write (transformer.py:236-253) + masked attention over the
@@ -591,26 +685,25 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     const int L = (int)(end_new < (long)cap ? end_new : (long)cap);
     const float scale = 1.0f / sqrtf((float)D);
     const int seg = tid % LPR, rsub = tid / LPR;
-    for (int s0 = 0; s0 < L; s0 += RPB) {            // block-uniform trip count
-        const int slot = s0 + rsub;
-        float dot[4] = {0.f, 0.f, 0.f, 0.f};
-        long pos = -1;
-        if (slot < L) {
+    constexpr int NP = 8;                             // ring rows in flight per thread (unconditional, clamped loads)
+    for (int s0 = 0; s0 < L; s0 += NP * RPB) {        // block-uniform trip count
+        f32x4 kk[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) kk[i] = *reinterpret_cast<const f32x4*>(kcb + (long)min(s0 + i * RPB + rsub, L - 1) * D + seg * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int slot = s0 + i * RPB + rsub;
             int delta = slot - end_index;
-            pos = delta <= 0 ? last + delta : last + delta - cap;
-            const f32x4 kk = *reinterpret_cast<const f32x4*>(kcb + (long)slot * D + seg * 4);
+            const long pos = delta <= 0 ? last + delta : last + delta - cap;
             for (int t = 0; t < T; ++t) {
                 const float* q = qs + t * D + seg * 4;
-                dot[t] = (q[0] * kk[0] + q[1] * kk[1]) + (q[2] * kk[2] + q[3] * kk[3]);
-            }
-        }
-        for (int t = 0; t < T; ++t) {
-            float dv = dot[t];
-            for (int m = LPR / 2; m >= 1; m >>= 1) dv += mmi_shfl_xor(dv, m);
-            if (seg == 0 && slot < L) {
-                const long dq = (off + t) - pos;
-                const bool ok = pos >= 0 && dq >= 0 && dq < a.context;
-                sc[t * cap + slot] = ok ? dv * scale : -INFINITY;
+                float dv = (q[0] * kk[i][0] + q[1] * kk[i][1]) + (q[2] * kk[i][2] + q[3] * kk[i][3]);
+                for (int m = LPR / 2; m >= 1; m >>= 1) dv += mmi_shfl_xor(dv, m);
+                if (seg == 0 && slot < L) {
+                    const long dq = (off + t) - pos;
+                    const bool ok = pos >= 0 && dq >= 0 && dq < a.context;
+                    sc[t * cap + slot] = ok ? dv * scale : -INFINITY;
+                }
             }
         }
     }
@@ -642,11 +735,17 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     float acc[4][4];
     for (int t = 0; t < 4; ++t)
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
-    for (int slot = rsub; slot < L; slot += RPB) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vcb + (long)slot * D + seg * 4);
-        for (int t = 0; t < T; ++t) {
-            const float pr = sc[t * cap + slot];
-            for (int e = 0; e < 4; ++e) acc[t][e] += pr * vv[e];
+    for (int s0 = 0; s0 < L; s0 += NP * RPB) {
+        f32x4 vv[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) vv[i] = *reinterpret_cast<const f32x4*>(vcb + (long)min(s0 + i * RPB + rsub, L - 1) * D + seg * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int slot = s0 + i * RPB + rsub;
+            for (int t = 0; t < T; ++t) {
+                const float pr = slot < L ? sc[t * cap + slot] : 0.f;
+                for (int e = 0; e < 4; ++e) acc[t][e] += pr * vv[i][e];
+            }
         }
     }
     for (int t = 0; t < T; ++t)

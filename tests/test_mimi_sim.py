@@ -26,7 +26,7 @@ def test_tiny_matches_oracle_with_masks_and_reset(factory, B):
     mimi_cases.oracle_vs_engine(factory, "cpu", tiny_mimi_config(), seed=21 + B, B=B, F=6, K=5)
 
 
-@pytest.mark.parametrize("mtb,w,ks", [(1, 2, 2), (2, 4, 3), (4, 8, 8), (8, 1, 1)])
+@pytest.mark.parametrize("mtb,w,ks", [(1, 2, 2), (2, 4, 3), (4, 8, 8), (4, 1, 1)])
 def test_conv_kernel_variants(factory, monkeypatch, mtb, w, ks):
     """Every tiling the planner can pick at full size (m-tiles per wave, split-K over waves / workgroups), forced onto
     the tiny codec: B=6 puts the audio-rate layers on k_conv_wide and the rest on k_pack_b_f32 + k_gemm_f32."""
