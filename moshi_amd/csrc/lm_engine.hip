@@ -65,6 +65,7 @@ struct mmi_lm {
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
     float *opart = nullptr, *ml = nullptr;
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
+    float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
     uint16_t *dkc = nullptr, *dvc = nullptr;        // [dep_layers][B][Hd][dep_q][Dhd]
     float* noise = nullptr;                         // [B][1+dep_q][kmax]
@@ -354,8 +355,9 @@ int build_program(mmi_lm* lm) {
         const int* user = lm->user_i32; int* tokens = lm->tokens;
         const uint16_t *emb = lm->emb, *temb = lm->text_emb; uint16_t* x = lm->x; const int NC = lm->NC, card1 = c.card + 1;
         const int T = lm->T, xks = packed_ksteps(lm, d);
+        float* rope = lm->rope; const float max_period = c.max_period;
         P.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_lm_prepare, mmi_cdiv(B * NC, 128), 128, 0, s, t, user, n_user, tokens);
+            MMI_LAUNCH(k_lm_prepare, mmi_cdiv(B * NC + B * (Dh / 2), 128), 128, 0, s, t, user, n_user, tokens, rope, Dh, max_period);
             MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d, T, xks);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
@@ -378,7 +380,7 @@ int build_program(mmi_lm* lm) {
             memset(&ga, 0, sizeof(ga));
             ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
             ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets; ga.H = H; ga.Dh = Dh; ga.cap = c.context;
-            ga.max_period = c.max_period;
+            ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
             P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
         }
@@ -581,6 +583,7 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
     ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
+    ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);

@@ -100,6 +100,7 @@ struct GemmArgs {
     const long* offsets;
     int H, Dh, cap;
     float max_period;
+    const float* rope;      // [B][Dh/2][2]: (cos, sin) of the new position's angles, filled once per step by k_lm_prepare
     // k_gemm_xp_norm: RMSNorm of the input rows fused in front of the GEMM (xp holds the un-normalised rows)
     const uint16_t* alpha;  // [D]
     int D;                  // features of a row (the mean is over D, not the padded K)
@@ -138,15 +139,21 @@ template <int TN, int MT, int NTW, int WAVES>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
                                                   int nt0, u32x4 pre) {
     constexpr int R = TN == 32 ? 16 : 4;
-    // ---- split-K reduction across the block's waves (fixed order -> deterministic)
-    constexpr int NE = NTW * MT * R * 64;
-    MMI_SHARED float red[WAVES * NE];
+    // ---- split-K reduction across the block's waves (fixed order -> deterministic).  LDS layout [wave][tile][lane][LS]:
+    // a lane's accumulators are contiguous, so they go out and come back as 16-byte vectors; LS = 20 floats (80 B)
+    // spreads the 8 lanes of a ds_*_b128 group over all 32 banks.
+    constexpr int LS = R == 4 ? 4 : ((WAVES * NTW * MT * 64 * 20 * 4 <= 65536) ? 20 : 16);
+    constexpr int NE = NTW * MT * 64 * LS;
+    MMI_SHARED __attribute__((aligned(16))) float red[WAVES * NE];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < R; ++r) red[wave * NE + ((t * MT + m) * R + r) * 64 + lane] = accv[t][m][r];
+            for (int c = 0; c < R / 4; ++c) {
+                const f32x4 v4 = {accv[t][m][4 * c], accv[t][m][4 * c + 1], accv[t][m][4 * c + 2], accv[t][m][4 * c + 3]};
+                *reinterpret_cast<f32x4*>(&red[wave * NE + ((t * MT + m) * 64 + lane) * LS + 4 * c]) = v4;
+            }
     __syncthreads();
 
     // ---- epilogue: one task = 8 consecutive output features of one session
@@ -164,29 +171,36 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         const int b = m * TN + bl;
         const int n0 = nt * rows_out + 8 * gi;
         if (nt >= a.NT || b >= a.B || n0 >= a.N) continue;
-        const float* rb = red + (t * MT + m) * R * 64;
+        const float* rb = red + (t * MT + m) * 64 * LS;
+        // features 8*gi .. 8*gi+7 of the tile live in two lanes' accumulator quads (MFMA C layout, lm_kernels.h header):
+        //   T = 32: rows i = 8gi+e -> register (e&3) + 4gi of lane bl + 32*(e>>2);  gate partner rows i+16 -> registers + 8
+        //   T = 16: rows i = 8gi+e -> register e&3 of lane bl + 16*(2gi + (e>>2));  gate partner rows i+8 -> lanes + 32
+        int off_lo, off_hi, off2_lo, off2_hi;
+        if constexpr (TN == 32) {
+            off_lo = bl * LS + 4 * gi; off_hi = (bl + 32) * LS + 4 * gi;
+            off2_lo = off_lo + 8; off2_hi = off_hi + 8;
+        } else {
+            off_lo = (bl + 32 * gi) * LS; off_hi = (bl + 32 * gi + 16) * LS;
+            off2_lo = (bl + 32) * LS; off2_hi = (bl + 48) * LS;
+        }
         float s[8], s2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int i = 8 * gi + e;
-            int r, ln, r2, ln2;
-            if constexpr (TN == 32) {
-                r = (i & 3) + 4 * (i >> 3); ln = bl + 32 * ((i >> 2) & 1);
-                const int i2 = i + 16;
-                r2 = (i2 & 3) + 4 * (i2 >> 3); ln2 = bl + 32 * ((i2 >> 2) & 1);
-            } else {
-                r = i & 3; ln = bl + 16 * (i >> 2);
-                const int i2 = (i + 8) & 15;
-                r2 = i2 & 3; ln2 = bl + 16 * (i2 >> 2);
-            }
-            float v = 0.f, v2 = 0.f;
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) v += rb[w * NE + r * 64 + ln];
-            if (gate) {
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(rb + w * NE + off_lo);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(rb + w * NE + off_hi);
 #pragma unroll
-                for (int w = 0; w < WAVES; ++w) v2 += rb[w * NE + r2 * 64 + ln2];
+            for (int e = 0; e < 4; ++e) { s[e] += lo[e]; s[4 + e] += hi[e]; }
+        }
+        if (gate) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(rb + w * NE + off2_lo);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(rb + w * NE + off2_hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s2[e] += lo[e]; s2[4 + e] += hi[e]; }
             }
-            s[e] = v; s2[e] = v2;
         }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
@@ -203,11 +217,11 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = mmi_round_bf16(s[e]);          // in_proj output is a bf16 tensor
             if (sec < 2) {
+                const float* cs = a.rope + ((long)b * (a.Dh / 2) + d0 / 2) * 2;      // 4 (cos, sin) pairs = 32 contiguous bytes
+                const f32x4 cs0 = *reinterpret_cast<const f32x4*>(cs), cs1 = *reinterpret_cast<const f32x4*>(cs + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float freq = expf((float)(d0 / 2 + j) * (-logf(a.max_period) * 2.0f / (float)a.Dh));
-                    const float ang = freq * (float)off;
-                    const float c = cosf(ang), sn = sinf(ang);
+                    const float c = j < 2 ? cs0[2 * j] : cs1[2 * j - 4], sn = j < 2 ? cs0[2 * j + 1] : cs1[2 * j - 3];
                     const float re = v8[2 * j], im = v8[2 * j + 1];
                     v8[2 * j] = re * c - im * sn;
                     v8[2 * j + 1] = re * sn + im * c;
@@ -218,7 +232,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
             else dst = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.Dh + d0;
             u32x4 ov;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)mmi_f32_to_bf16(v8[2 * e]) | ((uint32_t)mmi_f32_to_bf16(v8[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(v8[2 * e], v8[2 * e + 1]);
             *reinterpret_cast<u32x4*>(dst) = ov;
             continue;
         }
@@ -260,7 +274,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         }
         u32x4 ov;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)mmi_f32_to_bf16(o[2 * e]) | ((uint32_t)mmi_f32_to_bf16(o[2 * e + 1]) << 16);
+        for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e], o[2 * e + 1]);
         *reinterpret_cast<u32x4*>(dst) = ov;
     }
 }
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const float lo = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] >> 16));
                 const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
-                xn[q] = (uint32_t)mmi_f32_to_bf16(lo * (alo * rs[m])) | ((uint32_t)mmi_f32_to_bf16(hi * (ahi * rs[m])) << 16);
+                xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
             }
             if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wv[u], xn, acc[m]);
             else acc[m] = mmi_mfma_bf16_16x16x32(wv[u], xn, acc[m]);
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[j][e] = mmi_round_bf16(mmi_round_bf16(u[e]) + f[j][e]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (uint32_t)mmi_f32_to_bf16(f[j][2 * q]) | ((uint32_t)mmi_f32_to_bf16(f[j][2 * q + 1]) << 16);
+            for (int q = 0; q < 4; ++q) v[q] = mmi_pack_bf16x2(f[j][2 * q], f[j][2 * q + 1]);
             *reinterpret_cast<u32x4*>(x + at) = v;
         }
 #pragma unroll
@@ -518,8 +532,7 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float alo = mmi_bf16_to_f32((uint16_t)(al[j][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[j][q] >> 16));
-            uint32_t olo = mmi_f32_to_bf16(f[j][2 * q] * (alo * rs)), ohi = mmi_f32_to_bf16(f[j][2 * q + 1] * (ahi * rs));
-            o[q] = olo | (ohi << 16);
+            o[q] = mmi_pack_bf16x2(f[j][2 * q] * (alo * rs), f[j][2 * q + 1] * (ahi * rs));
         }
         *reinterpret_cast<u32x4*>(y + mmi_xp_index(T, b, i, ksteps)) = o;
     }
@@ -1069,9 +1082,22 @@ struct TokArgs {
 };
 
 // 1. write the user's codes at (offset+delay)%CT, 2. gather the model input at offset%CT with init-token substitution
-__global__ void k_lm_prepare(TokArgs t, const int* __restrict__ user, int n_user, int* __restrict__ tokens) {
+// 3. (threads past B*NC) the RoPE table of the step: (cos, sin)(offset[b] * max_period^(-2j/Dh)) for the new position of
+//    every session (rope.py:11-82), computed once here instead of in each of the temporal layers' in_proj epilogues
+__global__ void k_lm_prepare(TokArgs t, const int* __restrict__ user, int n_user, int* __restrict__ tokens, float* __restrict__ rope,
+                             int Dh, float max_period) {
     int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (idx >= t.B * t.NC) return;
+    if (idx >= t.B * t.NC) {
+        const int r = idx - t.B * t.NC;
+        if (r < t.B * (Dh / 2)) {
+            const int b = r / (Dh / 2), j = r - b * (Dh / 2);
+            const float freq = expf((float)j * (-logf(max_period) * 2.0f / (float)Dh));
+            const float ang = freq * (float)t.offsets[b];
+            rope[2 * r] = cosf(ang);
+            rope[2 * r + 1] = sinf(ang);
+        }
+        return;
+    }
     const int b = idx / t.NC, c = idx % t.NC;
     const long off = t.offsets[b];
     const bool ex = t.exec[b] != 0;

@@ -234,7 +234,7 @@ int load_rvq(mmi_mimi* m, const MmiWeights& W) {
 struct ConvPlan {
     bool wide = false;
     int MTB = 1, W = 1, U = 1;        // wide
-    int NSUB = 1, waves = 4, ksplit = 1;
+    int NSUB = 1, waves = 4, ksplit = 1, nz = 1;
     bool pack = false;
 };
 
@@ -266,9 +266,10 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
     }
     ConvGemmArgs g = a;
     if (p.ksplit > 1) g.out_mode = MMI_GOUT_PARTIAL;
-    const dim3 grid(a.Mt, p.ksplit);
+    const dim3 grid(a.Mt, p.ksplit, p.nz);
     if (p.NSUB == 1) {
-        if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<1, 8, 2>), grid, 512, 0, s, g);
+        if (p.waves == 16) MMI_LAUNCH((k_gemm_f32<1, 16, 2>), grid, 1024, 0, s, g);
+        else if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<1, 8, 2>), grid, 512, 0, s, g);
         else MMI_LAUNCH((k_gemm_f32<1, 4, 2>), grid, 256, 0, s, g);
     } else if (p.NSUB == 2) {
         if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<2, 8, 2>), grid, 512, 0, s, g);
@@ -285,6 +286,8 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
 // `arena`.  `a.x_packed`: the producer writes a.bp itself.  `a.out_mode` PACKED: the result feeds a linear directly.
 int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
     const int N = a.Ntot;
+    if (a.Cin * a.K >= (1 << 17) || N >= (1 << 17) || a.T_out >= (1 << 11) || a.K >= (1 << 11))
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "conv dimensions outside the range of the kernels' index arithmetic");
     if (N > 128) {
         if (a.first || a.x_packed || a.out_mode != MMI_GOUT_NATURAL)
             return mmi_fail(MMI_ERR_UNSUPPORTED, "wide conv path does not take replicate padding / packed operands");
@@ -344,7 +347,15 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         a.partial = part;
     }
     const int qblk = a.Q / ks;
-    p->waves = (p->NSUB <= 2 && qblk >= 32) ? 8 : 4;
+    // small weight matrices (the transformer linears, <= 8 MB): one workgroup per n-subtile, up to 16 waves splitting K
+    const bool spread = nsub >= 2 && (size_t)a.Mt * a.Q * 1024 <= ((size_t)8 << 20) && !getenv("MMI_CONV_NO_SPREAD");
+    if (spread) {
+        p->NSUB = 1;
+        p->nz = nsub;
+        p->waves = qblk >= 256 ? 16 : (qblk >= 16 ? 8 : 4);
+    } else {
+        p->waves = (p->NSUB <= 2 && qblk >= 32) ? 8 : 4;
+    }
     return MMI_OK;
 }
 
@@ -356,6 +367,7 @@ ConvGemmArgs conv_args(const ConvW& w, const Buf& in, int x_off, int T_out, cons
     a.wpk = w.wpk; a.bias = w.bias;
     a.out = out.p; a.out_ld = out.ld; a.out_off = out_off;
     a.B = B; a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K; a.S = w.S; a.T_out = T_out;
+    a.T_magic = mmi_div_magic(T_out); a.K_magic = mmi_div_magic(w.K);
     a.Mt = w.Mt; a.Q = w.Q; a.Ntot = B * T_out;
     a.elu_in = elu_in ? 1 : 0;
     a.act_out = MMI_ACT_NONE;

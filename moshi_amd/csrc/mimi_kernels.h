@@ -88,6 +88,13 @@ __global__ void k_codebook_prepare(const float* __restrict__ esum, const float* 
 //                workgroup, K split over waves (+ workgroups), activations pre-packed into B-fragment order by
 //                k_pack_b_f32 (im2col + ELU + replicate padding) or by the producing kernel.
 enum { MMI_ACT_NONE = 0, MMI_ACT_GELU = 1, MMI_ACT_ELU = 2 };
+
+// n / d for 0 <= n < 2^17 and 1 <= d < 2^11 (column and tap indices) as one multiply-high: an integer division costs
+// ~30 instructions, and the small kernels here are instruction bound.  magic = ceil(2^32 / d), 0 means d == 1.
+MMI_HD unsigned mmi_div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+MMI_HD int mmi_fast_div(int n, unsigned magic) {
+    return magic == 0u ? n : (int)(((unsigned long long)(unsigned)n * magic) >> 32);
+}
 enum { MMI_GOUT_NATURAL = 0, MMI_GOUT_PACKED = 1, MMI_GOUT_PARTIAL = 2 };
 
 struct ConvGemmArgs {
@@ -106,6 +113,7 @@ struct ConvGemmArgs {
     const uint8_t* first; // replicate-pad flags [B] or null (conv.py:253-259)
     const uint8_t* exec;  // exec mask [B] (only read with `first`)
     int B, Cin, Cout, K, S, T_out;
+    unsigned T_magic, K_magic;   // mmi_div_magic(T_out), mmi_div_magic(K)
     int Mt, Q;            // M tiles of 32, packed k-quads (Kdim_pad / 8)
     int Ntot;             // B * T_out
     int elu_in;           // apply ELU(alpha=1) to every loaded input (seanet.py:63,205,222)
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     const int mt0 = (int)blockIdx.y * MTB;
     const bool nvalid = n < a.Ntot;
     const int nn = nvalid ? n : 0;
-    const int b = nn / a.T_out, t = nn - b * a.T_out;
+    const int b = mmi_fast_div(nn, a.T_magic), t = nn - b * a.T_out;
     const float* xb = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
     const int qper = (a.Q + W - 1) / W;
     const int q0 = min(a.Q, wave * qper), q1 = min(a.Q, q0 + qper);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
                 co[i] = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
                 ok[i] = nn2 < a.Ntot && co[i] < a.Cout;
                 const int n3 = ok[i] ? nn2 : 0;
-                bb[i] = n3 / a.T_out;
+                bb[i] = mmi_fast_div(n3, a.T_magic);
                 tt[i] = n3 - bb[i] * a.T_out;
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += red[w * NE + e];
@@ -301,14 +309,14 @@ __global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {
     {   // columns past Ntot / reduction indices past Cin*K read a clamped (valid) element: they meet zero weights or are
         // discarded, and unconditional loads are not serialised by the compiler
         const int nc = n < a.Ntot ? n : 0;
-        const int b = nc / a.T_out, t = nc - b * a.T_out;
+        const int b = mmi_fast_div(nc, a.T_magic), t = nc - b * a.T_out;
         const float* xb = a.x + (long)b * a.x_bstride + a.x_off + t * a.S;
         const bool rep = a.first != nullptr && a.first[b] != 0 && a.exec[b] != 0;
         const int hist = a.H - a.x_off;  // columns (relative to x_off) that belong to the history
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int kd = (q * 4 + e) * 2 + kh;
-            const int ci0 = kd / a.K, k = kd - ci0 * a.K;
+            const int ci0 = mmi_fast_div(kd, a.K_magic), k = kd - ci0 * a.K;
             const int ci = ci0 < a.Cin ? ci0 : a.Cin - 1;
             int p = k;
             if (rep && (t * a.S + p) < hist) p = hist - t * a.S;  // replicate x[..., :1]
@@ -320,7 +328,9 @@ __global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {
     reinterpret_cast<f32x4*>(bp)[idx] = o;
 }
 
-// grid (Mt, ksplit); NSUB n-subtiles of 32 columns (N <= 32*NSUB); the block's WAVES waves split the workgroup's k-quads.
+// grid (Mt, ksplit, n-subtile groups); a workgroup covers NSUB n-subtiles of 32 columns starting at blockIdx.z*NSUB; its
+// WAVES waves split the workgroup's k-quads.  The fp32 MFMA takes 64 cycles, so these GEMMs are matrix-core-latency
+// bound unless they are spread over many waves: small weight matrices give each n-subtile its own workgroup.
 template <int NSUB, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -331,6 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
     const int q0 = min(qb1, qb0 + wave * qper);
     const int nq = min(qb1, q0 + qper) - q0;
     const int ntn = (a.Ntot + 31) / 32;
+    const int s0 = (int)blockIdx.z * NSUB;
 
     f32x16 acc[NSUB];
 #pragma unroll
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpk) + ((long)mt * a.Q + q0) * 64 + lane;
     const f32x4* bp[NSUB];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) bp[s] = reinterpret_cast<const f32x4*>(a.bp) + ((long)min(s, ntn - 1) * a.Q + q0) * 64 + lane;
+    for (int s = 0; s < NSUB; ++s) bp[s] = reinterpret_cast<const f32x4*>(a.bp) + ((long)min(s0 + s, ntn - 1) * a.Q + q0) * 64 + lane;
 
     f32x4 wA[U], bA[U][NSUB], wB[U], bB[U][NSUB];
 #define MMI_F_LOAD(W_, B_, base)                                                              \
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
     for (int i = 0; i < NV; ++i) {
         const int e = (int)threadIdx.x + i * WAVES * 64;
         const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
-        nn[i] = s * 32 + (le & 31);
+        nn[i] = (s0 + s) * 32 + (le & 31);
         co[i] = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
         float x = 0.f;
 #pragma unroll
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
     for (int i = 0; i < NV; ++i) {
         ok[i] = nn[i] < a.Ntot && co[i] < a.Cout;
         const int n3 = ok[i] ? nn[i] : 0;
-        bb[i] = n3 / a.T_out;
+        bb[i] = mmi_fast_div(n3, a.T_magic);
         tt[i] = n3 - bb[i] * a.T_out;
     }
     mmi_conv_store_n<NV>(a, co, bb, tt, ok, v);
@@ -446,7 +457,7 @@ __global__ void k_conv_finish(ConvGemmArgs a, int ksplit) {
     float x = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) x += s < ksplit ? pv[s] : 0.f;
-    const int bq = n / a.T_out;
+    const int bq = mmi_fast_div(n, a.T_magic);
     int co1[1] = {co}, b1[1] = {bq}, t1[1] = {n - bq * a.T_out};
     bool ok1[1] = {true};
     float v1[1] = {x};

@@ -10,15 +10,21 @@
 #include <functional>
 
 #define MMI_HD __host__ __device__ __forceinline__
+MMI_HD uint16_t mmi_f32_to_bf16_bits(float f);
 
 // bf16 <-> f32, round-to-nearest-even, NaN kept quiet: identical to torch's float->bfloat16 cast.
+// Device code on gfx950 uses the hardware conversion (v_cvt_pk_bf16_f32, one instruction per pair) through
+// mmi_device.h's mmi_cvt_bf16 / mmi_cvt_pk_bf16; the bit-level version below is the host side and the definition of it.
 MMI_HD float mmi_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
-MMI_HD uint16_t mmi_f32_to_bf16(float f) {
+MMI_HD uint16_t mmi_f32_to_bf16_bits(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+MMI_HD uint16_t mmi_f32_to_bf16(float f) { return mmi_cvt_bf16(f); }
+// two values -> one packed register (lo in bits 0..15)
+MMI_HD uint32_t mmi_pack_bf16x2(float lo, float hi) { return mmi_cvt_pk_bf16(lo, hi); }
 // round an fp32 value to the nearest bf16 and return it widened again ("bf16 rounding point")
 MMI_HD float mmi_round_bf16(float f) { return mmi_bf16_to_f32(mmi_f32_to_bf16(f)); }
 

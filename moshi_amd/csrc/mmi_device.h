@@ -21,6 +21,25 @@ typedef __bf16 mmi_bf16x8 __attribute__((ext_vector_type(8)));
 #define MMI_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 
+// float -> bf16, round-to-nearest-even.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); host code (weight
+// import helpers) takes the bit-level definition in mmi_common.h.
+typedef __bf16 mmi_bf16x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ uint16_t mmi_f32_to_bf16_bits(float f);
+__host__ __device__ __forceinline__ uint16_t mmi_cvt_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+#else
+    return mmi_f32_to_bf16_bits(f);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t mmi_cvt_pk_bf16(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, mmi_bf16x2));
+#else
+    return (uint32_t)mmi_f32_to_bf16_bits(lo) | ((uint32_t)mmi_f32_to_bf16_bits(hi) << 16);
+#endif
+}
+
 __device__ __forceinline__ int mmi_lane() { return (int)(threadIdx.x & 63u); }
 
 template <class T>

@@ -21,6 +21,29 @@ __global__ void k_copy2(const float* in, float* out, const int* idx) {   // two 
     out[i] = in[j] + 1.0f;
 }
 
+// straight-line code of ~NI instructions (8 bytes each) executed once per wave: does a cold instruction stream cost time?
+template <int ID, int NI>
+__global__ void k_bigcode(const float* in, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = in[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) v = v * (1.0f + 1e-7f * (float)((j * 7 + ID) % 13)) + 1e-9f * (float)(ID + 1);
+    out[i] = v;
+}
+template <int NI>
+void launch_big(int id, int blocks, hipStream_t s, const float* a, float* b) {
+    switch (id & 7) {
+        case 0: hipLaunchKernelGGL((k_bigcode<0, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 1: hipLaunchKernelGGL((k_bigcode<1, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 2: hipLaunchKernelGGL((k_bigcode<2, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 3: hipLaunchKernelGGL((k_bigcode<3, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 4: hipLaunchKernelGGL((k_bigcode<4, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 5: hipLaunchKernelGGL((k_bigcode<5, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        case 6: hipLaunchKernelGGL((k_bigcode<6, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+        default: hipLaunchKernelGGL((k_bigcode<7, NI>), dim3(blocks), dim3(256), 0, s, a, b); break;
+    }
+}
+
 template <class F>
 double run_chain(hipStream_t s, int n, F launch) {
     hipGraph_t g; hipGraphExec_t ge;
@@ -54,6 +77,12 @@ int main() {
         double t3 = run_chain(s, n, [&](int i) { hipLaunchKernelGGL(k_copy2, dim3(blocks), dim3(256), 0, s, (i & 1) ? b : a, (i & 1) ? a : b, idx); });
         printf("blocks %4d: empty %.2f us | load+store %.2f us | +barrier %.2f us | 2 dependent loads %.2f us   (per kernel in a %d-kernel graph chain)\n",
                blocks, t0, t1, t2, t3, n);
+        double b1 = run_chain(s, n, [&](int i) { launch_big<500>(0, blocks, s, (i & 1) ? b : a, (i & 1) ? a : b); });
+        double b8 = run_chain(s, n, [&](int i) { launch_big<500>(i, blocks, s, (i & 1) ? b : a, (i & 1) ? a : b); });
+        double c1 = run_chain(s, n, [&](int i) { launch_big<2000>(0, blocks, s, (i & 1) ? b : a, (i & 1) ? a : b); });
+        double c8 = run_chain(s, n, [&](int i) { launch_big<2000>(i, blocks, s, (i & 1) ? b : a, (i & 1) ? a : b); });
+        printf("             4 KB straight-line code: same kernel %.2f us, 8 alternating kernels %.2f us | 16 KB code: same %.2f us, 8 alternating (128 KB > I-cache) %.2f us\n",
+               b1, b8, c1, c8);
         CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(idx)); free(h);
     }
     return 0;

@@ -33,6 +33,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 using std::min;
 using std::max;
 
+inline uint16_t mmi_f32_to_bf16_bits(float f);
+inline uint16_t mmi_cvt_bf16(float f) { return mmi_f32_to_bf16_bits(f); }
+inline uint32_t mmi_cvt_pk_bf16(float lo, float hi) {
+    return (uint32_t)mmi_f32_to_bf16_bits(lo) | ((uint32_t)mmi_f32_to_bf16_bits(hi) << 16);
+}
+
 inline int mmi_lane() { return hipsim::lane_id(); }
 
 template <class T>
