@@ -268,8 +268,7 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
     if (p.ksplit > 1) g.out_mode = MMI_GOUT_PARTIAL;
     const dim3 grid(a.Mt, p.ksplit, p.nz);
     if (p.NSUB == 1) {
-        if (p.waves == 16) MMI_LAUNCH((k_gemm_f32<1, 16, 2>), grid, 1024, 0, s, g);
-        else if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<1, 8, 2>), grid, 512, 0, s, g);
+        if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<1, 8, 2>), grid, 512, 0, s, g);
         else MMI_LAUNCH((k_gemm_f32<1, 4, 2>), grid, 256, 0, s, g);
     } else if (p.NSUB == 2) {
         if (p.waves == 8) MMI_LAUNCH((k_gemm_f32<2, 8, 2>), grid, 512, 0, s, g);
@@ -331,6 +330,8 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         }
         p->pack = true;
     }
+    // small weight matrices (the transformer linears, <= 8 MB): one workgroup per n-subtile, up to 16 waves splitting K
+    const bool spread = nsub >= 2 && (size_t)a.Mt * a.Q * 1024 <= ((size_t)8 << 20) && !getenv("MMI_CONV_NO_SPREAD");
     int ks = 1;
     if (a.out_mode == MMI_GOUT_NATURAL) {
         // only the large strided convs (>= 2048-deep reductions, tens of MB of weights) are worth a finishing launch
@@ -347,12 +348,10 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         a.partial = part;
     }
     const int qblk = a.Q / ks;
-    // small weight matrices (the transformer linears, <= 8 MB): one workgroup per n-subtile, up to 16 waves splitting K
-    const bool spread = nsub >= 2 && (size_t)a.Mt * a.Q * 1024 <= ((size_t)8 << 20) && !getenv("MMI_CONV_NO_SPREAD");
     if (spread) {
         p->NSUB = 1;
         p->nz = nsub;
-        p->waves = qblk >= 256 ? 16 : (qblk >= 16 ? 8 : 4);
+        p->waves = qblk >= 16 ? 8 : 4;
     } else {
         p->waves = (p->NSUB <= 2 && qblk >= 32) ? 8 : 4;
     }
@@ -405,7 +404,7 @@ int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat
     }
     const int K = m->n_codebooks;
     const int nchunk = m->nchunk;
-    const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 1) + (size_t)8 * D) * sizeof(float);
+    const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 4) + (size_t)8 * D) * sizeof(float);
     for (int k = 0; k < K; ++k) {
         const bool sem = k < c.q_n_q_semantic;
         float* x = m->xq + (sem ? 0 : D);
@@ -733,6 +732,7 @@ int check_cfg(const mmi_mimi_cfg& c) {
     if (Dh * c.tr_num_heads != c.tr_d_model || (Dh & 3) || 256 % Dh != 0)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be a multiple of 4 and divide 256");
     if (c.tr_d_model > 1024) return mmi_fail(MMI_ERR_UNSUPPORTED, "transformer width above the LayerNorm kernel's register budget");
+    if (c.q_dimension % 4) return mmi_fail(MMI_ERR_UNSUPPORTED, "codebook dimension must be a multiple of 4");
     if (c.compress < 1 || c.q_n_q_semantic < 1 || c.q_n_q < c.q_n_q_semantic)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "bad quantizer/compress config");
     return MMI_OK;

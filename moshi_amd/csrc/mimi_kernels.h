@@ -720,27 +720,23 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     }
     __syncthreads();
 
-    // phase 3: softmax per query over [0, L)
-    for (int t = 0; t < T; ++t) {
+    // phase 3: softmax per query over [0, L): wave t owns query t (T <= 4 waves), so the reductions are wave shuffles
+    if (wave < T) {
+        const int t = wave;
         float m = -INFINITY;
-        for (int slot = tid; slot < L; slot += 256) m = fmaxf(m, sc[t * cap + slot]);
+        for (int slot = lane; slot < L; slot += 64) m = fmaxf(m, sc[t * cap + slot]);
         for (int x = 32; x >= 1; x >>= 1) m = fmaxf(m, mmi_shfl_xor(m, x));
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         float sum = 0.f;
-        for (int slot = tid; slot < L; slot += 256) {
+        for (int slot = lane; slot < L; slot += 64) {
             float e = expf(sc[t * cap + slot] - m);
             sc[t * cap + slot] = e;
             sum += e;
         }
         for (int x = 32; x >= 1; x >>= 1) sum += mmi_shfl_xor(sum, x);
-        if (lane == 0) red[4 + wave] = sum;
-        __syncthreads();
-        const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-        for (int slot = tid; slot < L; slot += 256) sc[t * cap + slot] *= inv;
-        __syncthreads();
+        const float inv = 1.0f / sum;
+        for (int slot = lane; slot < L; slot += 64) sc[t * cap + slot] *= inv;
     }
+    __syncthreads();
 
     // phase 4: out[t][d] = sum_slot p[t][slot] * V[slot][d]
     float acc[4][4];
@@ -778,47 +774,59 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
 // nearest centroid of the fp32 inputs, lowest index on ties - the answer the reference's fp32 cdist
 // agrees with except at ~1e-7-relative near-ties.
 #define MMI_RVQ_CHUNK 32
+// grid (chunks of 32 codes, groups of 8 rows); 256 threads: thread (c, g) owns code c0+c and row rg0+g.  The chunk of the
+// codebook and the 8 rows are staged in LDS with 16-byte accesses (row stride D+4 floats keeps ds_read_b128 conflict
+// free); the dot product runs in four independent fp64 chains.  D % 4 == 0.
 __global__ __launch_bounds__(256) void k_rvq_dist(const float* __restrict__ x, int x_rstride,
                                                   const float* __restrict__ E, const double* __restrict__ e2,
                                                   double* __restrict__ best_d, int* __restrict__ best_i, int Bn, int D,
                                                   int bins) {
     MMI_DYN_SHARED(float, sm);
-    const int ldE = D + 1;
-    float* Es = sm;                          // [CHUNK][D+1]
-    float* xs = sm + MMI_RVQ_CHUNK * ldE;    // [Bn][D]
+    const int ldE = D + 4;
+    float* Es = sm;                          // [CHUNK][D+4]
+    float* xs = sm + MMI_RVQ_CHUNK * ldE;    // [8][D]
     const int chunk = blockIdx.x;
     const int c0 = chunk * MMI_RVQ_CHUNK;
     const int tid = threadIdx.x;
-    for (int i = tid; i < MMI_RVQ_CHUNK * D; i += 256) {
-        int c = i / D, d = i % D;
-        Es[c * ldE + d] = (c0 + c) < bins ? E[(long)(c0 + c) * D + d] : 0.f;
-    }
-    const int rg0 = (int)blockIdx.y * 8;   // this block's 8 rows (grid.y = ceil(Bn / 8))
-    for (int i = tid; i < 8 * D; i += 256) {
-        int r = i / D, d = i % D;
-        xs[r * D + d] = (rg0 + r) < Bn ? x[(long)(rg0 + r) * x_rstride + d] : 0.f;
+    const int rg0 = (int)blockIdx.y * 8;     // this block's 8 rows (grid.y = ceil(Bn / 8))
+    const int D4 = D >> 2;
+    {   // 8 threads per code / row, each copying every 8th float4 of it
+        const int r = tid >> 3, j0 = tid & 7;
+        const int code = min(c0 + r, bins - 1);
+        for (int j = j0; j < D4; j += 8)
+            *reinterpret_cast<f32x4*>(Es + r * ldE + 4 * j) = *reinterpret_cast<const f32x4*>(E + (long)code * D + 4 * j);
+        if (r < 8) {
+            const int row = min(rg0 + r, Bn - 1);
+            for (int j = j0; j < D4; j += 8)
+                *reinterpret_cast<f32x4*>(xs + r * D + 4 * j) = *reinterpret_cast<const f32x4*>(x + (long)row * x_rstride + 4 * j);
+        }
     }
     __syncthreads();
     const int c = tid & 31, g = tid >> 5;  // 8 rows, 32 codes
     const bool cvalid = (c0 + c) < bins;
     const double en = cvalid ? e2[c0 + c] : 0.0;
-    {
-        const int r = rg0 + g;
-        const bool rvalid = r < Bn;
-        double acc = 0.0;
-        if (rvalid)
-            for (int d = 0; d < D; ++d) acc += (double)Es[c * ldE + d] * (double)xs[g * D + d];
-        double dist = (cvalid && rvalid) ? en - 2.0 * acc : INFINITY;
-        int idx = c0 + c;
-        // argmin over the 32 codes held by this half-wave (xor masks < 32 stay inside it)
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {
-            double od = mmi_shfl_xor(dist, m);
-            int oi = mmi_shfl_xor(idx, m);
-            if (od < dist || (od == dist && oi < idx)) { dist = od; idx = oi; }
-        }
-        if (c == 0 && rvalid) { best_d[(long)chunk * Bn + r] = dist; best_i[(long)chunk * Bn + r] = idx; }
+    const int r = rg0 + g;
+    const bool rvalid = r < Bn;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = 0; j < D4; ++j) {
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(Es + c * ldE + 4 * j);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + g * D + 4 * j);
+        a0 += (double)ev[0] * (double)xv[0];
+        a1 += (double)ev[1] * (double)xv[1];
+        a2 += (double)ev[2] * (double)xv[2];
+        a3 += (double)ev[3] * (double)xv[3];
     }
+    const double acc = (a0 + a1) + (a2 + a3);
+    double dist = (cvalid && rvalid) ? en - 2.0 * acc : INFINITY;
+    int idx = c0 + c;
+    // argmin over the 32 codes held by this half-wave (xor masks < 32 stay inside it)
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        double od = mmi_shfl_xor(dist, m);
+        int oi = mmi_shfl_xor(idx, m);
+        if (od < dist || (od == dist && oi < idx)) { dist = od; idx = oi; }
+    }
+    if (c == 0 && rvalid) { best_d[(long)chunk * Bn + r] = dist; best_i[(long)chunk * Bn + r] = idx; }
 }
 
 // pick the winning chunk per row, emit the code, subtract the centroid from the residual

@@ -6,6 +6,11 @@ lm_tiny.npz: tiny Moshi LM (moshi_amd.config.tiny_lm_config), bf16, synthetic se
   * a sampled run of 4 steps (temp .8/.7, top-k 20/10) whose Exp(1) draws are recorded at the reference's
     `multinomial` (sampling.py:40-47) so that the same noise can be replayed,
 each with the user codes, the step outputs, the text / audio logits the tokens were sampled from, and the tokens.
+
+lm_wide.npz: Moshi-7B's real layer shapes (dim 4096, 32 heads x 128, FFN 11264, text head 32000; depformer 1024 x 6 layers x
+8 steps) with ONE temporal layer and context 16, bf16, seeded weights, B=2, a greedy run of 3 steps: pins RoPE at head
+dim 128, the 32-head ring attention, the gated FFN width, the full-size depformer and both full-size heads.  Logits are
+stored as the bf16 bit patterns the reference produced.
 """
 from __future__ import annotations
 
@@ -103,7 +108,32 @@ def gen_lm_tiny():
     print("lm_tiny.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd/")})
 
 
+def gen_lm_wide():
+    from moshi.models.lm import LMGen, LMModel
+    from moshi_amd.config import LMConfig
+    from moshi_amd.weights import random_lm_state_dict
+    cfg = LMConfig(num_layers=1, context=16)
+    sd = random_lm_state_dict(cfg, seed=23)
+    lm = LMModel(**cfg.reference_kwargs(), device="cpu", dtype=torch.bfloat16)
+    lm.load_state_dict(sd, strict=True)
+    lm.eval()
+    B, S = 2, 3
+    g = torch.Generator().manual_seed(5)
+    codes = torch.randint(0, cfg.card, (S, B, cfg.n_q - cfg.dep_q, 1), generator=g).numpy()
+    greedy = _run(LMGen(lm, use_sampling=False, support_out_of_sync=True), lm, codes, np.ones((S, B), bool), {}, B, False)
+
+    def bf16_bits(a):   # the logits are bf16 values widened to fp32: keep the upper 16 bits
+        return (np.ascontiguousarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    out = {"codes": codes, "seed": np.array([23]), "g_tokens": greedy["tokens"], "g_text_tok": greedy["text_tok"],
+           "g_audio_tok": greedy["audio_tok"], "g_text_logits_bf16": bf16_bits(greedy["text_logits"]),
+           "g_audio_logits_bf16": bf16_bits(greedy["audio_logits"])}
+    np.savez_compressed(HERE / "lm_wide.npz", **out)
+    print("lm_wide.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     sys.path.insert(0, "/root/reference/moshi")
     sys.path.insert(0, str(HERE.parent.parent))
-    gen_lm_tiny()
+    if "--wide-only" not in sys.argv:
+        gen_lm_tiny()
+    gen_lm_wide()

@@ -72,6 +72,44 @@ def check_golden_greedy(device, lib):
     assert agree >= 0.85 * total, f"greedy agreement with the reference too low: {agree}/{total}"
 
 
+def load_wide():
+    """Reference run at Moshi-7B's real layer shapes (1 temporal layer; tests/golden/make_golden_lm.py gen_lm_wide)."""
+    g = dict(np.load(GOLDEN / "lm_wide.npz"))
+    for k in ("g_text_logits", "g_audio_logits"):
+        g[k] = (g.pop(k + "_bf16").astype(np.uint32) << 16).view(np.float32)
+    return g, LMConfig(num_layers=1, context=16)
+
+
+def check_wide_steps(step_fn, g, cfg):
+    """`step_fn(codes, forced) -> (ring output, text logits, audio logits)` replayed over the wide golden run."""
+    S, B = g["g_text_tok"].shape
+    for s in range(S):
+        forced = np.concatenate([g["g_text_tok"][s][:, None], g["g_audio_tok"][s]], 1)
+        out, tl, al = step_fn(g["codes"][s], forced)
+        assert np.array_equal(out, g["g_tokens"][s]), f"step {s}: ring output differs"
+        for b in range(B):
+            assert logits_close(tl[b], g["g_text_logits"][s, b]), f"step {s} row {b}: text logits"
+            t_e, t_r = int(tl[b].argmax()), int(g["g_text_tok"][s, b])
+            assert t_e == t_r or near_tie(g["g_text_logits"][s, b], t_e, t_r)
+            for k in range(cfg.dep_q):
+                assert logits_close(al[b, k], g["g_audio_logits"][s, b, k]), f"step {s} row {b} cb {k}: audio logits"
+                a_e, a_r = int(al[b, k].argmax()), int(g["g_audio_tok"][s, b, k])
+                assert a_e == a_r or near_tie(g["g_audio_logits"][s, b, k], a_e, a_r)
+
+
+def check_golden_wide(device, lib):
+    """The engine at the 7B layer shapes against the reference's own output (greedy, teacher-forced)."""
+    g, cfg = load_wide()
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]), device=device)
+    B = g["codes"].shape[1]
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    with gen.streaming(B):
+        def step(codes, forced):
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            return out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+        check_wide_steps(step, g, cfg)
+
+
 def check_golden_sampled(device, lib):
     """Replays the reference's sampled run with the Exp(1) draws recorded at its `multinomial`."""
     g = np.load(GOLDEN / "lm_tiny.npz")

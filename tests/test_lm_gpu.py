@@ -17,6 +17,11 @@ def test_greedy_schedule_matches_reference_golden(gpu_lib):
     lm_cases.check_golden_greedy(DEV, None)
 
 
+def test_7b_layer_shapes_match_reference_golden(gpu_lib):
+    """Engine vs the reference's own output at Moshi-7B's real layer widths (tests/golden/lm_wide.npz)."""
+    lm_cases.check_golden_wide(DEV, None)
+
+
 def test_sampled_run_matches_reference_golden_given_its_noise(gpu_lib):
     lm_cases.check_golden_sampled(DEV, None)
 
@@ -31,9 +36,10 @@ def test_full_size_sampler_follows_the_reference_rule(gpu_lib):
     lm_cases.engine_sampling_matches_oracle_rule(DEV, None, cfg, top_k=250, top_k_text=25, B=5, steps=3)
 
 
-@pytest.mark.parametrize("B", [1, 5])
+@pytest.mark.parametrize("B", [1, 5, 18, 40])
 def test_tiny_matches_oracle_with_masks_and_reset(gpu_lib, B):
-    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=50 + B, B=B, S=16)   # S > context=12: the ring wraps
+    # B <= 16: 16x16x32 MFMA tile; 17..32: 32x32x16; 33..64: two batch tiles per weight fragment.  S > context=12: the ring wraps
+    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=50 + B, B=B, S=16 if B <= 5 else 4)
 
 
 def test_full_width_layers_match_oracle(gpu_lib):

@@ -86,3 +86,20 @@ def test_lm_oracle_matches_reference_golden():
             tok = sample_token(lg, True, temp, k, nz)
             for b in range(B):
                 assert tok[b] == ref_tok[b] or lg[b, tok[b]] == lg[b, ref_tok[b]], "sampling rule restatement disagrees"
+
+
+def test_lm_oracle_matches_reference_at_7b_layer_shapes():
+    """oracle/lm_oracle.py against the reference at Moshi-7B's real widths (dim 4096, 32 heads x 128, FFN 11264, 32000-way
+    text head, full depformer), one temporal layer: tests/golden/lm_wide.npz."""
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle
+    from tests import lm_cases
+    g, cfg = lm_cases.load_wide()
+    o = LMOracle(random_lm_state_dict(cfg, seed=int(g["seed"][0])), cfg)
+    B = g["codes"].shape[1]
+    o.streaming(B)
+
+    def step(codes, forced):
+        out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+        return out, tl, al
+    lm_cases.check_wide_steps(step, g, cfg)
