@@ -171,10 +171,22 @@ def main():
 
     ms = 1e3 * dt / args.steps
     value = job_value(world, B, args.steps, dt)
+
+    # p50 / p95 latency of a single step (BASELINE.json's second figure): a separate, untimed-for-`value` pass with a
+    # device event before and after every step and no host synchronisation inside the loop
+    n_lat = max(8, min(args.steps, 40))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
+    for a_ev, b_ev in evs:
+        a_ev.record()
+        step()
+        b_ev.record()
+    torch.cuda.synchronize(dev)
+    lat = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
+    p50, p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
     out = {
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",

@@ -60,6 +60,8 @@ class LMModel:
             lib = _capi.load()
         self._lib = lib
         self._handle = C.c_void_p()
+        from .weights import normalize_lm_state_dict
+        state_dict = normalize_lm_state_dict(state_dict, self.config)     # fused multi-step projections of released checkpoints
         sd = {k: v.detach().to(device=self.device, dtype=torch.bfloat16) for k, v in state_dict.items()}
         descs, keep = _capi.tensor_descs(sd)
         cfg = _lm_cfg_struct(self.config)

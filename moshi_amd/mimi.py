@@ -70,6 +70,8 @@ class MimiModel:
         self._lib = lib
         self._handle = C.c_void_p()
         self._batch: Optional[int] = None
+        from .weights import normalize_mimi_state_dict
+        state_dict = normalize_mimi_state_dict(state_dict)               # legacy codebook / fused-projection key names
         sd = {k: v.detach().to(device=self.device, dtype=torch.float32) for k, v in state_dict.items()
               if v.dtype.is_floating_point}
         descs, keep = _capi.tensor_descs(sd)

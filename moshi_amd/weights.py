@@ -165,3 +165,50 @@ def random_mimi_state_dict(cfg: MimiConfig, seed: int = 1234, device="cpu") -> D
 
 def random_lm_state_dict(cfg: LMConfig, seed: int = 4242, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
     return random_state_dict(lm_state_spec(cfg), seed, device, dtype)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# checkpoint key normalisation (what the reference does in its state-dict load hooks)
+# --------------------------------------------------------------------------------------------------------------------
+def normalize_lm_state_dict(sd: Dict[str, torch.Tensor], cfg: LMConfig) -> Dict[str, torch.Tensor]:
+    """Released Moshi checkpoints store multi-step attention projections fused over the steps
+    (`...self_attn.in_proj_weight` [mult*3*dim, dim], `...self_attn.out_proj.weight` [mult*dim, dim]); the reference splits
+    them into `in_projs.{i}.weight` / `out_projs.{i}.weight` in `StreamingMultiheadAttention._load_hook`
+    (modules/transformer.py:422-446; `scripts/import_rust.py:91-101` shows the depformer layout).  Same mapping here, so a
+    checkpoint's state dict can be handed to `LMModel` as is.  mult = 1 for the temporal transformer, dep_q for the depformer."""
+    out: Dict[str, torch.Tensor] = {}
+    sources = {"in_proj_weight": "in_projs.{i}.weight", "in_proj.weight": "in_projs.{i}.weight", "out_proj.weight": "out_projs.{i}.weight"}
+    for key, val in sd.items():
+        hit = None
+        for src, dst in sources.items():
+            if key.endswith(".self_attn." + src):
+                hit = (key[: -len(src)], dst)
+                break
+        if hit is None:
+            out[key] = val
+            continue
+        prefix, dst = hit
+        mult = cfg.dep_q if prefix.startswith("depformer.") else 1
+        assert val.shape[0] % mult == 0, f"{key}: leading dimension {val.shape[0]} is not a multiple of {mult} steps"
+        parts = val.view(mult, -1, *val.shape[1:])
+        for i in range(mult):
+            out[prefix + dst.format(i=i)] = parts[i]
+    return out
+
+
+def normalize_mimi_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Legacy codebook buffer names (`inited`, `cluster_size`, `embed_avg` / `embed_sum`) -> current ones, as
+    `EuclideanCodebook._load_from_state_dict` does (quantization/core_vq.py:162-176); the transformer projections get the
+    same un-fusing as the LM (mult = 1)."""
+    ren = {"inited": "_initialized", "cluster_size": "cluster_usage", "embed_avg": "embedding_sum", "embed_sum": "embedding_sum"}
+    out: Dict[str, torch.Tensor] = {}
+    for key, val in sd.items():
+        head, _, leaf = key.rpartition(".")
+        if head.endswith("._codebook") and leaf in ren:
+            key = head + "." + ren[leaf]
+        for src, dst in (("in_proj_weight", "in_projs.0.weight"), ("in_proj.weight", "in_projs.0.weight"), ("out_proj.weight", "out_projs.0.weight")):
+            if key.endswith(".self_attn." + src):
+                key = key[: -len(src)] + dst
+                break
+        out[key] = val
+    return out

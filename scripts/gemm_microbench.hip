@@ -40,6 +40,32 @@ __global__ __launch_bounds__(256) void k_stream_read(const u32x4* __restrict__ p
     if (acc == 0x12345678u) *sink = acc;
 }
 
+// What do the activation-fragment loads cost?  The production main loop (one n-tile per workgroup, K split over 8 waves,
+// U fragments per buffer) with XMODE 0 = activation fragments from global/L2 as in k_gemm_xp, 1 = no activation loads at
+// all (a constant register): the difference is the price of the operand traffic.  Trivial epilogue (no LDS reduction).
+template <int WAVES, int U, int XMODE>
+__global__ __launch_bounds__(WAVES * 64) void k_probe_xcost(const u32x4* __restrict__ wpk, const u32x4* __restrict__ xpk, int KSTEPS, float* sink) {
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int kper = KSTEPS / WAVES, ks0 = wave * kper;
+    const u32x4* wp = wpk + ((long)blockIdx.x * KSTEPS + ks0) * 64 + lane;
+    const u32x4* xp = xpk + (long)ks0 * 64 + lane;
+    acc_t acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    u32x4 wA[U], xA[U], wB[U], xB[U];
+    const u32x4 xc = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#define P_LOAD(W_, X_, base) _Pragma("unroll") for (int u = 0; u < U; ++u) { W_[u] = mmi_load_nt(wp + ((base) + u) * 64); X_[u] = XMODE == 0 ? xp[((base) + u) * 64] : xc; }
+#define P_MMA(W_, X_) _Pragma("unroll") for (int u = 0; u < U; ++u) acc = mmi_mfma_bf16_32x32x16(W_[u], X_[u], acc);
+    const int nfull = kper / U;
+    P_LOAD(wA, xA, 0);
+    int g = 0;
+    for (; g + 2 < nfull; g += 2) { P_LOAD(wB, xB, (g + 1) * U); P_MMA(wA, xA); P_LOAD(wA, xA, (g + 2) * U); P_MMA(wB, xB); }
+    if (nfull - g == 2) { P_LOAD(wB, xB, (g + 1) * U); P_MMA(wA, xA); P_MMA(wB, xB); } else { P_MMA(wA, xA); }
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += acc[r];
+    if (t == 12345.678f) sink[threadIdx.x] = t;
+}
+
 struct Shape { const char* name; int N, K, gate; };
 
 typedef void (*launch_fn)(dim3 groups, hipStream_t s, const GemmArgs& a);
@@ -88,6 +114,7 @@ int main(int argc, char** argv) {
         int nbuf = (int)((size_t)1400 * 1024 * 1024 / wbytes) + 1;
         if (nbuf > 64) nbuf = 64;
         if (nbuf < 4) nbuf = 4;
+        if (getenv("MB_NBUF")) nbuf = atoi(getenv("MB_NBUF"));   // 1: the same weights every launch (L2 / Infinity Cache resident)
         uint16_t* w;
         CK(hipMalloc(&w, wbytes * nbuf));
         k_fill_rand_bf16<<<2048, 256, 0, s>>>(w, welems * nbuf, 12345u);
@@ -117,6 +144,26 @@ int main(int argc, char** argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = 1e3 * ms / (reps * nbuf);
             printf("   pure nt read, %4d blocks                 %8.2f us  %7.0f GB/s\n", blocks, us, wbytes / us / 1e3);
+        }
+        if (T == 32 && MT == 1 && KS % 64 == 0) {   // operand-traffic probe on the same buffers
+            for (int mode = 0; mode < 2; ++mode) {
+                const int reps = wbytes > 50e6 ? 3 : 10;
+                auto go = [&](int i) {
+                    const u32x4* wv = (const u32x4*)(w + welems * i);
+                    if (mode == 0) hipLaunchKernelGGL((k_probe_xcost<8, 2, 0>), dim3(NT), dim3(512), 0, s, wv, (const u32x4*)x, KS, (float*)out);
+                    else hipLaunchKernelGGL((k_probe_xcost<8, 2, 1>), dim3(NT), dim3(512), 0, s, wv, (const u32x4*)x, KS, (float*)out);
+                };
+                for (int i = 0; i < nbuf; ++i) go(i);
+                CK(hipStreamSynchronize(s));
+                CK(hipEventRecord(e0, s));
+                for (int r = 0; r < reps; ++r) for (int i = 0; i < nbuf; ++i) go(i);
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double us = 1e3 * ms / (reps * nbuf);
+                printf("   main loop only, %-24s %8.2f us  %7.0f GB/s\n", mode == 0 ? "operand fragments from L2" : "no operand loads", us, wbytes / us / 1e3);
+            }
         }
         for (const Variant& v : variants) {
             if (v.TN != T || v.MT != MT) continue;

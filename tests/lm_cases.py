@@ -100,7 +100,7 @@ def check_wide_steps(step_fn, g, cfg):
 def check_golden_wide(device, lib):
     """The engine at the 7B layer shapes against the reference's own output (greedy, teacher-forced)."""
     g, cfg = load_wide()
-    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]), device=device)
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))     # drawn on the CPU, like the generator script: the CUDA RNG stream differs
     B = g["codes"].shape[1]
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
     with gen.streaming(B):
