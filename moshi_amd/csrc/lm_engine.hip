@@ -60,7 +60,7 @@ struct mmi_lm {
     int* text_tok = nullptr;        // [B]
     int* audio_tok = nullptr;       // [B][dep_q]
     int* out_i32 = nullptr;         // [B][dep_q+1]
-    uint16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *hb = nullptr;
+    uint16_t *x = nullptr, *xn = nullptr, *qrot = nullptr, *att = nullptr, *hb = nullptr;
     uint16_t *tout = nullptr, *text_logits = nullptr;
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
     float *opart = nullptr, *ml = nullptr;
@@ -371,7 +371,7 @@ int build_program(mmi_lm* lm) {
         const LayerW& L = lm->layers[l];
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
         LmAttnArgs a;
-        a.qkv = nullptr; a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
+        a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);

@@ -9,7 +9,8 @@
 //                   A wave streams its K-slice of an n-tile as consecutive non-temporal 16-byte-per-lane loads.
 //                   The SiLU-gated FFN's linear_in interleaves gate rows and value rows inside each tile so that
 //                   the epilogue can form silu(g)*u without another pass (gating.py:19-20).
-//   activations     [B][features] bf16 row-major.
+//   activations     between GEMMs: MFMA B-fragment order Xp[mt][ks][lane][8] (see "fragment-packed layouts" below), written
+//                   by the producing epilogue; only q (for attention), the depformer's qkv and the logits are row-major.
 //   KV ring         [layer][2][B][H][cap][Dh] bf16 (row = one position of one head: 256 contiguous bytes at Dh=128).
 //   token ring      [B][17][max_delay+2] int32 (lm.py:605-613).
 #pragma once
@@ -566,8 +567,7 @@ __global__ void k_lm_embed(const int* __restrict__ tokens, int n_codebooks, cons
 // temporal attention: RoPE + ring-KV write, split decode attention over the VALID part of the ring, combine
 // ------------------------------------------------------------------------------------------------
 struct LmAttnArgs {
-    const uint16_t* qkv;   // [B][3*H*Dh]
-    uint16_t* qrot;        // [B][H][Dh]
+    uint16_t* qrot;        // [B][H][Dh] roped queries (written by in_proj's epilogue)
     uint16_t* kc;          // [B][H][cap][Dh]
     uint16_t* vc;
     const long* offsets;   // [B]

@@ -464,7 +464,8 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
         MMI_HIP_CHECK(hipMemsetAsync(hbp, 0, (size_t)nsub * Qff * 256 * sizeof(float), init_stream));
     }
     const size_t kv_layer = (size_t)B * H * cap * Dh;
-    if (T > 4) return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi attention kernel handles at most 4 transformer steps per frame");
+    if (T > 2 || (Dh != 16 && Dh != 32 && Dh != 64))
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi attention: head dim 16/32/64 and 1 or 2 steps per frame are built");
     const size_t attn_smem = ((size_t)T * Dh + (size_t)T * cap + (size_t)(256 / (Dh / 4)) * T * Dh + 8) * sizeof(float);
     auto add_norm = [&](const float* w, const float* bb) {
         const float* xp = xb.p; int xld = xb.ld; float* yn = y.p;
@@ -487,7 +488,15 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
             aa.context = c.tr_context; aa.max_period = c.tr_max_period;
             aa.outp = attp; aa.outQ = Qd;
             prog.add([=](hipStream_t s) {
-                MMI_LAUNCH(k_mimi_attn, B * H, 256, attn_smem, s, aa);
+#define MMI_ATT(D_, T_) MMI_LAUNCH((k_mimi_attn<D_, T_>), B * H, 256, attn_smem, s, aa)
+                if (Dh == 64 && T == 2) MMI_ATT(64, 2);
+                else if (Dh == 64 && T == 1) MMI_ATT(64, 1);
+                else if (Dh == 32 && T == 2) MMI_ATT(32, 2);
+                else if (Dh == 32 && T == 1) MMI_ATT(32, 1);
+                else if (Dh == 16 && T == 2) MMI_ATT(16, 2);
+                else if (Dh == 16 && T == 1) MMI_ATT(16, 1);
+                else return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi attention: head dim 16/32/64 and 1 or 2 steps per frame are built");
+#undef MMI_ATT
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });

@@ -649,18 +649,20 @@ struct MimiAttnArgs {
 };
 
 // 256 threads; D/4 lanes share a ring row (one 16-byte load each), so a wave instruction reads 64/(D/4) consecutive
-// rows.  Only the min(offset + T, cap) valid slots are visited (the reference masks all `cap`).  T <= 4, D % 4 == 0,
-// 256 % (D/4) == 0.  Dynamic LDS: qs[T][D] | sc[T][cap] | red[(256/(D/4)) * T * D] (also the block-reduction scratch).
+// rows.  Only the min(offset + T, cap) valid slots are visited (the reference masks all `cap`).  Head dim D and the
+// steps per frame T are compile-time so that the query slices live in registers and every loop unrolls.
+// Dynamic LDS: qs[T][D] | sc[T][cap] | red[(256/(D/4)) * T * D].
+template <int D, int T>
 __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
+    constexpr int LPR = D / 4;             // lanes per row
+    constexpr int RPB = 256 / LPR;         // rows per block pass
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int D = a.D, T = a.T, cap = a.cap;
-    const int LPR = D / 4;             // lanes per row
-    const int RPB = 256 / LPR;         // rows per block pass
+    const int cap = a.cap;
     MMI_DYN_SHARED(float, sm);
     float* qs = sm;               // [T][D] roped queries
     float* sc = qs + T * D;       // [T][cap] scores / probabilities
-    float* red = sc + T * cap;    // [RPB][T][D] partial outputs; first 8 floats double as reduction scratch
+    float* red = sc + T * cap;    // [RPB][T][D] partial outputs
     const long off = a.offsets[b];
     const int HD = a.H * D;
     const float* qrow = a.qkv + (long)b * 3 * HD * T;
@@ -669,22 +671,22 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
 
     // phase 1: rope(q), rope(k) -> ring, v -> ring (written unconditionally, transformer.py:243-250)
     for (int i = tid; i < T * (D / 2); i += 256) {
-        int t = i / (D / 2), j = i % (D / 2);
-        float freq = expf((float)j * (-logf(a.max_period) * 2.0f / (float)D));
-        float ts = (float)(off + t);
-        float ang = freq * ts;
-        float c = cosf(ang), s = sinf(ang);
-        float qr = qrow[(long)(h * D + 2 * j) * T + t], qi = qrow[(long)(h * D + 2 * j + 1) * T + t];
-        float kr = qrow[(long)(HD + h * D + 2 * j) * T + t], ki = qrow[(long)(HD + h * D + 2 * j + 1) * T + t];
+        const int t = i / (D / 2), j = i % (D / 2);
+        const float freq = expf((float)j * (-logf(a.max_period) * 2.0f / (float)D));
+        const float ts = (float)(off + t);
+        const float ang = freq * ts;
+        const float c = cosf(ang), s = sinf(ang);
+        const float qr = qrow[(long)(h * D + 2 * j) * T + t], qi = qrow[(long)(h * D + 2 * j + 1) * T + t];
+        const float kr = qrow[(long)(HD + h * D + 2 * j) * T + t], ki = qrow[(long)(HD + h * D + 2 * j + 1) * T + t];
         qs[t * D + 2 * j] = qr * c - qi * s;
         qs[t * D + 2 * j + 1] = qr * s + qi * c;
-        int slot = (int)((off + t) % cap);
+        const int slot = (int)((off + t) % cap);
         kcb[(long)slot * D + 2 * j] = kr * c - ki * s;
         kcb[(long)slot * D + 2 * j + 1] = kr * s + ki * c;
     }
     for (int i = tid; i < T * D; i += 256) {
-        int t = i / D, d = i % D;
-        int slot = (int)((off + t) % cap);
+        const int t = i / D, d = i % D;
+        const int slot = (int)((off + t) % cap);
         vcb[(long)slot * D + d] = qrow[(long)(2 * HD + h * D + d) * T + t];
     }
     __syncthreads();
@@ -696,6 +698,9 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     const int L = (int)(end_new < (long)cap ? end_new : (long)cap);
     const float scale = 1.0f / sqrtf((float)D);
     const int seg = tid % LPR, rsub = tid / LPR;
+    f32x4 qv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) qv[t] = *reinterpret_cast<const f32x4*>(qs + t * D + seg * 4);
     constexpr int NP = 8;                             // ring rows in flight per thread (unconditional, clamped loads)
     for (int s0 = 0; s0 < L; s0 += NP * RPB) {        // block-uniform trip count
         f32x4 kk[NP];
@@ -704,11 +709,12 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int slot = s0 + i * RPB + rsub;
-            int delta = slot - end_index;
+            const int delta = slot - end_index;
             const long pos = delta <= 0 ? last + delta : last + delta - cap;
+#pragma unroll
             for (int t = 0; t < T; ++t) {
-                const float* q = qs + t * D + seg * 4;
-                float dv = (q[0] * kk[i][0] + q[1] * kk[i][1]) + (q[2] * kk[i][2] + q[3] * kk[i][3]);
+                float dv = (qv[t][0] * kk[i][0] + qv[t][1] * kk[i][1]) + (qv[t][2] * kk[i][2] + qv[t][3] * kk[i][3]);
+#pragma unroll
                 for (int m = LPR / 2; m >= 1; m >>= 1) dv += mmi_shfl_xor(dv, m);
                 if (seg == 0 && slot < L) {
                     const long dq = (off + t) - pos;
@@ -725,13 +731,15 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
         const int t = wave;
         float m = -INFINITY;
         for (int slot = lane; slot < L; slot += 64) m = fmaxf(m, sc[t * cap + slot]);
+#pragma unroll
         for (int x = 32; x >= 1; x >>= 1) m = fmaxf(m, mmi_shfl_xor(m, x));
         float sum = 0.f;
         for (int slot = lane; slot < L; slot += 64) {
-            float e = expf(sc[t * cap + slot] - m);
+            const float e = expf(sc[t * cap + slot] - m);
             sc[t * cap + slot] = e;
             sum += e;
         }
+#pragma unroll
         for (int x = 32; x >= 1; x >>= 1) sum += mmi_shfl_xor(sum, x);
         const float inv = 1.0f / sum;
         for (int slot = lane; slot < L; slot += 64) sc[t * cap + slot] *= inv;
@@ -739,8 +747,10 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     __syncthreads();
 
     // phase 4: out[t][d] = sum_slot p[t][slot] * V[slot][d]
-    float acc[4][4];
-    for (int t = 0; t < 4; ++t)
+    float acc[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
     for (int s0 = 0; s0 < L; s0 += NP * RPB) {
         f32x4 vv[NP];
@@ -749,18 +759,22 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int slot = s0 + i * RPB + rsub;
+#pragma unroll
             for (int t = 0; t < T; ++t) {
                 const float pr = slot < L ? sc[t * cap + slot] : 0.f;
+#pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][e] += pr * vv[i][e];
             }
         }
     }
+#pragma unroll
     for (int t = 0; t < T; ++t)
-        for (int e = 0; e < 4; ++e) red[(rsub * T + t) * D + seg * 4 + e] = acc[t][e];
+        *reinterpret_cast<f32x4*>(red + (rsub * T + t) * D + seg * 4) = f32x4{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
     __syncthreads();
     for (int i = tid; i < T * D; i += 256) {
         const int t = i / D, d = i % D;
         float s = 0.f;
+#pragma unroll 8
         for (int r = 0; r < RPB; ++r) s += red[(r * T + t) * D + d];
         if (a.outp) a.outp[mmi_bp_index(h * D + d, b * T + t, a.outQ)] = s;
         else a.out[((long)b * HD + h * D + d) * T + t] = s;
