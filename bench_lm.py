@@ -21,6 +21,10 @@ def make_lm(dev, B, args):
     if args.lm_layers:
         cfg.num_layers = args.lm_layers
     sd = random_lm_state_dict(cfg, seed=4242, device=dev)       # drawn on the GPU: 7.7 B parameters in bf16
+    if getattr(args, "quant", "none") == "q8":                  # quantise tensor by tensor (frees the bf16 copy as it goes)
+        from moshi_amd.weights import is_lm_linear_weight, quantize_lm_state_dict
+        for k in [k for k in sd if is_lm_linear_weight(k)]:
+            sd.update(quantize_lm_state_dict({k: sd.pop(k)}))
     lm = LMModel(sd, cfg, device=dev, max_batch=B)
     del sd
     torch.cuda.empty_cache()
@@ -48,7 +52,7 @@ def stagger(mimi, lm_gen, step_fn, B, frames_apart, dev):
     return n
 
 
-def lm_step_algorithmic_bytes(cfg, L_per_row):
+def lm_step_algorithmic_bytes(cfg, L_per_row):   # bf16 weights
     """weights once per step + per-stream KV read/write (bf16)."""
     d, dd, h, dh = cfg.dim, cfg.depformer_dim, cfg.ffn_hidden, cfg.depformer_ffn_hidden
     per_layer = 3 * d * d + d * d + 2 * h * d + d * h

@@ -176,7 +176,9 @@ typedef struct mmi_sampling {
 
 typedef struct mmi_lm mmi_lm;
 
-/* loaders.get_moshi_lm (loaders.py:366-446): build LMModel from bf16 state-dict tensors. */
+/* loaders.get_moshi_lm (loaders.py:366-446): build LMModel from state-dict tensors - bf16, or with the linears in the
+ * reference's quantised storage (utils/quantize.py:13-22): `<linear>.weight` MMI_I8 [out,in] row-wise absmax codes plus
+ * `<linear>.weight_scb` MMI_F32 [out] row absmax; embeddings and norms stay bf16.  The linears must be all bf16 or all int8. */
 int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights,
                   int32_t max_batch, mmi_lm** out);
 void mmi_lm_destroy(mmi_lm* lm);

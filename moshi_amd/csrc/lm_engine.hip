@@ -12,6 +12,7 @@ namespace {
 struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
     int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
+    float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; KSTEPS then counts k-step PAIRS
     size_t bytes = 0;
 };
 
@@ -33,6 +34,7 @@ struct mmi_lm {
     mmi_lm_cfg cfg;
     int max_batch = 0;
     int T = 32;                     // MFMA tile of the whole model: 16 when max_batch <= 16, else 32 (lm_kernels.h)
+    int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py)
     int NC = 0, CT = 0, max_delay = 0;
     MmiArena wts;
     // weights
@@ -98,10 +100,19 @@ int need(const MmiWeights& W, const std::string& name, int ndim, const mmi_tenso
 }
 
 // nn.Linear weight [N][K] -> packed; gate_hidden > 0: [2*hidden][K] gate|value matrix
+__global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict__ scale, int n) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) scale[i] = scb[i] / 127.0f;
+}
+
 int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g) {
-    const mmi_tensor_desc* d;
-    int rc = need(W, name, 2, &d);
-    if (rc) return rc;
+    const mmi_tensor_desc* d = W.find(name);
+    if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
+    if (d->dtype != MMI_BF16 && d->dtype != MMI_I8) return mmi_fail(MMI_ERR_UNSUPPORTED, "LM linear weights must be bf16 or int8: " + name);
+    if (d->ndim != 2) return mmi_fail(MMI_ERR_SHAPE, "unexpected rank for " + name);
+    const int q8 = d->dtype == MMI_I8 ? 1 : 0;
+    if (lm->q8 >= 0 && lm->q8 != q8) return mmi_fail(MMI_ERR_UNSUPPORTED, "mixed bf16 / int8 linear weights: " + name);
+    lm->q8 = q8;
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
     const int TN = lm->T;
@@ -111,15 +122,32 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     if (g->N % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "out_features must be a multiple of 8: " + name);
     const int rows_per_tile = gate_hidden > 0 ? TN / 2 : TN;
     g->NT = mmi_cdiv(g->N, rows_per_tile);
-    g->KSTEPS = mmi_cdiv(K, mmi_kstep(TN));
-    size_t n = (size_t)g->NT * g->KSTEPS * 512;
-    uint16_t* p = nullptr;
-    MMI_HIP_CHECK(lm->wts.alloc(&p, n));
-    g->wp = reinterpret_cast<u32x4*>(p);
-    g->bytes = n * sizeof(uint16_t);
+    const int ksteps = mmi_cdiv(K, mmi_kstep(TN));
+    if (!q8) {
+        g->KSTEPS = ksteps;
+        size_t n = (size_t)g->NT * g->KSTEPS * 512;
+        uint16_t* p = nullptr;
+        MMI_HIP_CHECK(lm->wts.alloc(&p, n));
+        g->wp = reinterpret_cast<u32x4*>(p);
+        g->bytes = n * sizeof(uint16_t);
+        MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
+                   TN, g->NT, g->KSTEPS, gate_hidden);
+    } else {
+        const mmi_tensor_desc* sc = W.find(name + "_scb");
+        if (!sc) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name + "_scb");
+        if (sc->dtype != MMI_F32 || sc->shape[0] != N) return mmi_fail(MMI_ERR_SHAPE, "weight_scb must be fp32 [out_features]: " + name);
+        g->KSTEPS = mmi_cdiv(ksteps, 2);                       // pairs of k-steps
+        size_t n = (size_t)g->NT * g->KSTEPS * 1024;
+        int8_t* p = nullptr;
+        MMI_HIP_CHECK(lm->wts.alloc(&p, n));
+        g->wp = reinterpret_cast<u32x4*>(p);
+        MMI_HIP_CHECK(lm->wts.alloc(&g->scale, (size_t)N));
+        g->bytes = n + (size_t)N * sizeof(float);
+        MMI_LAUNCH(k_pack_w_i8, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const int8_t*)d->data, p, N, K, TN,
+                   g->NT, g->KSTEPS, gate_hidden);
+        MMI_LAUNCH(k_scb_to_scale, mmi_cdiv(N, 256), 256, 0, (hipStream_t)0, (const float*)sc->data, g->scale, N);
+    }
     lm->weight_bytes += g->bytes;
-    MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
-               TN, g->NT, g->KSTEPS, gate_hidden);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
@@ -158,6 +186,7 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     // fragments in flight per register buffer: 2 for the widest GEMM (the temporal FFN linear_in, 704 n-tiles: fewer
     // registers -> 3 workgroups per CU -> all 704 resident at once; 36.8 vs 39.3 us in the microbenchmark), else 4
     p.u = (g.gate && g.NT >= 512 && p.waves == 8) ? 2 : 4;
+    if (g.scale) p.u = 2;            // int8 entries carry two k-steps each
     const char* e = getenv("MMI_GEMM_WAVES");
     if (e && atoi(e) > 0) p.waves = atoi(e);
     e = getenv("MMI_GEMM_NTW");
@@ -166,7 +195,17 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
 }
 
 template <int TN, int MT, int NTW>
-int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, const GemmArgs& a) {
+int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, bool w8, const GemmArgs& a) {
+    if (w8) {
+        if constexpr (MT * NTW <= 2) {
+            if (waves == 8) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2, true>), groups, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, true>), groups, 256, 0, s, a);
+        } else {
+            MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, true>), groups, 256, 0, s, a);
+        }
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
     if (waves == 8 && u == 2 && MT * NTW == 1) {
         if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
         MMI_CHECK_LAUNCH();
@@ -186,15 +225,17 @@ int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, const GemmArgs& 
 template <int TN>
 int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
     const dim3 groups(mmi_cdiv(NT, p.ntw), p.ksplit);
-    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, a);
-    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, a);
-    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, a);
-    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, p.u, a);
+    const bool w8 = a.wscale != nullptr;
+    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, w8, a);
+    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, w8, a);
+    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, w8, a);
+    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, p.u, w8, a);
     return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
 }
 
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     EvPair* ev = nullptr;
@@ -216,10 +257,15 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
 }
 
 // number of bf16 elements of a packed activation buffer with `features` columns
-size_t packed_elems(const mmi_lm* lm, int features) {
-    return (size_t)mmi_cdiv(lm->batch, lm->T) * mmi_cdiv(features, mmi_kstep(lm->T)) * 512;
+// k-steps of a packed activation buffer with `features` columns (even when the linears are int8: their weight entries
+// carry k-step pairs, and the padding k-step reads as zero)
+int packed_ksteps(const mmi_lm* lm, int features) {
+    const int ks = mmi_cdiv(features, mmi_kstep(lm->T));
+    return lm->q8 == 1 ? 2 * mmi_cdiv(ks, 2) : ks;
 }
-int packed_ksteps(const mmi_lm* lm, int features) { return mmi_cdiv(features, mmi_kstep(lm->T)); }
+size_t packed_elems(const mmi_lm* lm, int features) {
+    return (size_t)mmi_cdiv(lm->batch, lm->T) * packed_ksteps(lm, features) * 512;
+}
 
 // x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
 void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
@@ -269,7 +315,8 @@ void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, ui
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
                    int out_features, bool out_packed, int epi) {
-    const bool fuse = g.KSTEPS <= 64 && !getenv("MMI_NO_NORM_FUSION");
+    const bool w8 = g.scale != nullptr;
+    const bool fuse = g.KSTEPS <= (w8 ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
         add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr);
@@ -283,11 +330,18 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.out_ksteps = packed_ksteps(lm, out_features);
     a.alpha = alpha; a.D = D; a.eps = 1e-8f;
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT;
     lm->prog.add([=](hipStream_t s) {
-        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
-        else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
-        else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
+        if (w8) {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, true>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, true>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, true>), NT, 512, 0, s, a);
+        } else {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
+        }
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -730,9 +784,12 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (bytes_per_launch) {
         const mmi_lm_cfg& c = lm->cfg;
         // algorithmic bytes of one FFN linear_in launch: packed weights + activations in + gated activations out
-        *bytes_per_launch = (int64_t)2 * c.ffn_hidden * c.dim * 2 + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
+        const int64_t wbytes = lm->q8 == 1 ? (int64_t)2 * c.ffn_hidden * c.dim + (int64_t)2 * c.ffn_hidden * 4 : (int64_t)2 * c.ffn_hidden * c.dim * 2;
+        *bytes_per_launch = wbytes + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
     }
-    if (kernel_name) *kernel_name = "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
+    if (kernel_name)
+        *kernel_name = lm->q8 == 1 ? "k_gemm_xp<32, 1, 1, 8, 2, true> (temporal FFN linear_in, int8 weights + SiLU gate)"
+                                   : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;
 }

@@ -67,6 +67,51 @@ __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restri
     P[idx] = v;
 }
 
+// int8 weights (bitsandbytes-style per-output-row absmax quantisation, utils/quantize.py:13-22: `weight` int8 CB +
+// `weight_scb` fp32 row absmax; W ~= CB * SCB / 127).  Same tile order as the bf16 packing with TWO k-steps per 16-byte
+// lane entry: Wq[nt][kp][lane][16], entries 0..7 = k-step 2kp, 8..15 = k-step 2kp+1 (zero padded to an even count).
+// The GEMM widens the bytes to bf16 in registers (exact: |q| <= 127) and scales the fp32 accumulator by SCB/127.
+__global__ void k_pack_w_i8(const int8_t* __restrict__ W, int8_t* __restrict__ P, int N, int K, int TN, int NT, int KP,
+                            int gate_hidden) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)NT * KP * 1024;
+    if (idx >= total) return;
+    int e = (int)(idx & 15);
+    int lane = (int)((idx >> 4) & 63);
+    long rest = idx >> 10;
+    int kp = (int)(rest % KP);
+    int nt = (int)(rest / KP);
+    int i, kq, kstep;
+    if (TN == 32) { i = lane & 31; kq = lane >> 5; kstep = 16; } else { i = lane & 15; kq = lane >> 4; kstep = 32; }
+    int k = (2 * kp + (e >> 3)) * kstep + 8 * kq + (e & 7);
+    long row;
+    bool valid;
+    if (gate_hidden > 0) {
+        int half = TN / 2;
+        int r = nt * half + (i < half ? i : i - half);
+        valid = r < gate_hidden;
+        row = (i < half ? 0 : gate_hidden) + r;
+    } else {
+        row = (long)nt * TN + i;
+        valid = row < N;
+    }
+    int8_t v = 0;
+    if (valid && k < K) v = W[row * K + k];
+    P[idx] = v;
+}
+
+// 16 int8 -> two bf16 fragments (k-step 2kp, k-step 2kp+1)
+__device__ __forceinline__ void mmi_i8x16_to_bf16(u32x4 q, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int w = (int)q[d];
+        const float f0 = (float)((w << 24) >> 24), f1 = (float)((w << 16) >> 24), f2 = (float)((w << 8) >> 24), f3 = (float)(w >> 24);
+        const uint32_t p0 = mmi_pack_bf16x2(f0, f1), p1 = mmi_pack_bf16x2(f2, f3);
+        if (d < 2) { lo[2 * d] = p0; lo[2 * d + 1] = p1; }
+        else { hi[2 * (d - 2)] = p0; hi[2 * (d - 2) + 1] = p1; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
 // ------------------------------------------------------------------------------------------------
@@ -90,6 +135,8 @@ struct GemmArgs {
     int B, N, KSTEPS, NT;
     int out_mode, out_ld, out_ksteps;
     int epi;
+    const float* wscale;    // int8 weights: SCB / 127 per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
+    int gate_rows;          // H of a gated linear_in (value row of feature n is H + n)
     float* partial;         // EPI_PARTIAL: fp32 partial sums [gridDim.y][B][N] (K split over gridDim.y workgroups so that
                             // GEMMs with few n-tiles still cover every CU); summed by k_resid_rmsnorm
     // EPI_ROPE_KV (temporal in_proj): features [q | k | v], each H heads x Dh.  RoPE (rope.py:11-82, interleaved, fp32) on
@@ -203,6 +250,16 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 for (int e = 0; e < 4; ++e) { s2[e] += lo[e]; s2[4 + e] += hi[e]; }
             }
         }
+        if (a.wscale) {   // int8 weights: y = (sum_k q x) * SCB / 127, per original weight row
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.wscale + n0), c1 = *reinterpret_cast<const f32x4*>(a.wscale + n0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] *= c0[e]; s[4 + e] *= c1[e]; }
+            if (gate) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.wscale + a.gate_rows + n0), g1 = *reinterpret_cast<const f32x4*>(a.wscale + a.gate_rows + n0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s2[e] *= g0[e]; s2[4 + e] *= g1[e]; }
+            }
+        }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
             f32x4 lo = {s[0], s[1], s[2], s[3]}, hi = {s[4], s[5], s[6], s[7]};
@@ -280,9 +337,12 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
     }
 }
 
-template <int TN, int MT, int NTW, int WAVES, int U>
+// W8: int8 weights - one 16-byte weight entry carries two k-steps, so the loop runs over k-step PAIRS (a.KSTEPS then
+// counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
+template <int TN, int MT, int NTW, int WAVES, int U, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
+    constexpr int XS = W8 ? 2 : 1;                // activation fragments per weight entry
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int nt0 = (int)blockIdx.x * NTW;
@@ -300,7 +360,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * 64 + lane;
+    for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * XS * 64 + lane;
 
     acc_t acc[NTW][MT];
 #pragma unroll
@@ -310,19 +370,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[t][m][r] = 0.f;
 
-    u32x4 wA[U][NTW], xA[U][MT], wB[U][NTW], xB[U][MT];
+    u32x4 wA[U][NTW], xA[U][MT][XS], wB[U][NTW], xB[U][MT][XS];
 #define MMI_G_LOAD(W_, X_, base)                                                              \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) X_[u][m] = xp[m][((base) + u) * 64];  \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+            _Pragma("unroll") for (int x = 0; x < XS; ++x) X_[u][m][x] = xp[m][(((base) + u) * XS + x) * 64]; \
     }
+#define MMI_G_MFMA(WF, XF, ACC)                                                               \
+    if constexpr (TN == 32) ACC = mmi_mfma_bf16_32x32x16(WF, XF, ACC);                        \
+    else ACC = mmi_mfma_bf16_16x16x32(WF, XF, ACC);
 #define MMI_G_MMA(W_, X_)                                                                     \
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
-        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                       \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
-                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(W_[u][t], X_[u][m], acc[t][m]); \
-                else acc[t][m] = mmi_mfma_bf16_16x16x32(W_[u][t], X_[u][m], acc[t][m]);      \
-            }
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                     \
+            if constexpr (W8) {                                                               \
+                u32x4 wlo_, whi_;                                                             \
+                mmi_i8x16_to_bf16(W_[u][t], wlo_, whi_);                                      \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                              \
+                    MMI_G_MFMA(wlo_, X_[u][m][0], acc[t][m])                                  \
+                    MMI_G_MFMA(whi_, X_[u][m][XS - 1], acc[t][m])                             \
+                }                                                                             \
+            } else {                                                                          \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) { MMI_G_MFMA(W_[u][t], X_[u][m][0], acc[t][m]) } \
+            }                                                                                 \
+        }
     const int nfull = nks / U;
     if (nfull > 0) {
         // steady state has no conditional loads, so that the compiler's s_waitcnt vmcnt(N) before each MFMA only waits
@@ -343,21 +414,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
             MMI_G_MMA(wA, xA);
         }
     }
-    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U k-steps)
+    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U entries)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) wA[0][t] = mmi_load_nt(wp[t] + ks * 64);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xA[0][m] = xp[m][ks * 64];
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+            for (int x = 0; x < XS; ++x) xA[0][m][x] = xp[m][(ks * XS + x) * 64];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if constexpr (TN == 32) acc[t][m] = mmi_mfma_bf16_32x32x16(wA[0][t], xA[0][m], acc[t][m]);
-                else acc[t][m] = mmi_mfma_bf16_16x16x32(wA[0][t], xA[0][m], acc[t][m]);
+        for (int t = 0; t < NTW; ++t) {
+            if constexpr (W8) {
+                u32x4 wlo_, whi_;
+                mmi_i8x16_to_bf16(wA[0][t], wlo_, whi_);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    MMI_G_MFMA(wlo_, xA[0][m][0], acc[t][m])
+                    MMI_G_MFMA(whi_, xA[0][m][XS - 1], acc[t][m])
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { MMI_G_MFMA(wA[0][t], xA[0][m][0], acc[t][m]) }
             }
+        }
     }
 #undef MMI_G_LOAD
 #undef MMI_G_MMA
+#undef MMI_G_MFMA
     float accv[NTW][MT][R];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -373,10 +455,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // out = y @ W^T.  A wave's whole K-slice of activation and weight fragments (<= KMAX k-steps) is loaded in one go -
 // everything in flight at once, these GEMMs are latency bound - the waves combine their sums of squares through
 // LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
-template <int TN, int MT, int WAVES, int KMAX>
+// W8: int8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
+template <int TN, int MT, int WAVES, int KMAX, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
+    constexpr int XS = W8 ? 2 : 1;
+    constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int nt0 = (int)blockIdx.x;
@@ -385,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
     const int kq = TN == 32 ? (lane >> 5) : (lane >> 4);
 
-    u32x4 wv[KMAX], xv[MT][KMAX], al[KMAX];
+    u32x4 wv[KMAX], xv[MT][XMAX], al[XMAX];
     const u32x4 zero = {0u, 0u, 0u, 0u};
     // every load is unconditional from a clamped (valid) address and masked afterwards: conditional loads would be
     // serialised behind s_waitcnt vmcnt(0) by the compiler, and these GEMMs live on having the whole slice in flight
@@ -394,20 +479,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         const int uu = min(u, nks > 0 ? nks - 1 : 0);
-        const int k = (ksl + uu) * KS + 8 * kq;
         wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + lane);
-        al[u] = *reinterpret_cast<const u32x4*>(a.alpha + min(k, dmax));
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xv[m][u] = a.xp[((long)m * a.KSTEPS + ksl + uu) * 64 + lane];
+        for (int x = 0; x < XS; ++x) {
+            const int k = ((ksl + uu) * XS + x) * KS + 8 * kq;
+            al[u * XS + x] = *reinterpret_cast<const u32x4*>(a.alpha + min(k, dmax));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xv[m][u * XS + x] = a.xp[(((long)m * a.KSTEPS + ksl + uu) * XS + x) * 64 + lane];
+        }
     }
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         const bool on = u < nks;
-        const int k = (ks0 + u) * KS + 8 * kq;
         if (!on) wv[u] = zero;
-        if (!on || k >= a.D) al[u] = zero;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) if (!on) xv[m][u] = zero;
+        for (int x = 0; x < XS; ++x) {
+            const int k = ((ks0 + u) * XS + x) * KS + 8 * kq;
+            if (!on || k >= a.D) al[u * XS + x] = zero;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) if (!on) xv[m][u * XS + x] = zero;
+        }
     }
     // sum of squares of this lane's row over the wave's slice (the kq lane groups hold different k of the same row)
     MMI_SHARED float ssum[WAVES][MT][TN];
@@ -416,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     for (int m = 0; m < MT; ++m) {
         float ss = 0.f;
 #pragma unroll
-        for (int u = 0; u < KMAX; ++u)
+        for (int u = 0; u < XMAX; ++u)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float lo = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] >> 16));
@@ -442,17 +533,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
         for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
+        u32x4 wf[XS];
+        if constexpr (W8) mmi_i8x16_to_bf16(wv[u], wf[0], wf[XS - 1]);
+        else wf[0] = wv[u];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            u32x4 xn;
+        for (int x = 0; x < XS; ++x) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float lo = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[m][u][q] >> 16));
-                const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
-                xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
+            for (int m = 0; m < MT; ++m) {
+                u32x4 xn;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4& xr = xv[m][u * XS + x];
+                    const u32x4& ar = al[u * XS + x];
+                    const float lo = mmi_bf16_to_f32((uint16_t)(xr[q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xr[q] >> 16));
+                    const float alo = mmi_bf16_to_f32((uint16_t)(ar[q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(ar[q] >> 16));
+                    xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
+                }
+                if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wf[x], xn, acc[m]);
+                else acc[m] = mmi_mfma_bf16_16x16x32(wf[x], xn, acc[m]);
             }
-            if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wv[u], xn, acc[m]);
-            else acc[m] = mmi_mfma_bf16_16x16x32(wv[u], xn, acc[m]);
         }
     }
     float accv[1][MT][R];

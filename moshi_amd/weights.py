@@ -212,3 +212,33 @@ def normalize_mimi_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Te
                 break
         out[key] = val
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# int8 weights (the reference's `quantize=True`: utils/quantize.py QLinear, bitsandbytes int8_vectorwise_quant)
+# --------------------------------------------------------------------------------------------------------------------
+def is_lm_linear_weight(key: str) -> bool:
+    """The nn.Linear weights `replace_linear_with_qlinear` converts (lm.py:242-243, transformer.py:885-888): every linear of
+    the temporal and depth transformers, `depformer_in`, `linears`, `text_linear`.  Embeddings and norms stay bf16."""
+    if not key.endswith(".weight"):
+        return False
+    return (".self_attn.in_projs." in key or ".self_attn.out_projs." in key or ".linear_in.weight" in key
+            or ".linear_out.weight" in key or key.startswith("depformer_in.") or key.startswith("linears.")
+            or key == "text_linear.weight")
+
+
+def quantize_lm_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Row-wise absmax int8, as `QLinear.__init__` does it: the weight goes to fp16, `CB = round(W * 127 / absmax_row)`
+    (int8) is stored under the weight's key and `SCB = absmax_row` (fp32) under `<key>_scb` (utils/quantize.py:17-22;
+    the key suffix is the one the reference's load hook handles, transformer.py:435-446).  W ~= CB * SCB / 127."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, w in sd.items():
+        if not is_lm_linear_weight(key) or w.dtype == torch.int8:
+            out[key] = w
+            continue
+        w16 = w.detach().to(torch.float16).float()
+        absmax = w16.abs().amax(dim=1)
+        scale = torch.where(absmax > 0, 127.0 / absmax, torch.zeros_like(absmax))
+        out[key] = torch.round(w16 * scale[:, None]).clamp_(-127, 127).to(torch.int8)
+        out[key + "_scb"] = absmax.to(torch.float32)
+    return out

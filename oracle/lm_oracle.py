@@ -34,8 +34,29 @@ def _np(t) -> np.ndarray:
     return t.detach().cpu().float().numpy()
 
 
-def linear(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+class QWeight:
+    """Row-wise int8 weight: W ~= q * scb / 127 (utils/quantize.py:17-22 storage; weight-only dequantisation - the engine
+    keeps activations bf16, unlike bitsandbytes' int8 x int8 matmul, which is absent here: parity with the reference's
+    quantised path is UNPINNED)."""
+
+    def __init__(self, q: np.ndarray, scb: np.ndarray):
+        self.q = q.astype(f32)
+        self.scale = (scb.astype(f32) / f32(127.0)).astype(f32)
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    def rows(self, lo: int, hi: int) -> "QWeight":
+        w = QWeight.__new__(QWeight)
+        w.q, w.scale = self.q[lo:hi], self.scale[lo:hi]
+        return w
+
+
+def linear(x: np.ndarray, w) -> np.ndarray:
     """nn.Linear(bias=False) on bf16 tensors: fp32 accumulate, bf16 result."""
+    if isinstance(w, QWeight):
+        return bf16r(((x @ w.q.T).astype(f32) * w.scale[None, :]).astype(f32))
     return bf16r((x @ w.T).astype(f32))
 
 
@@ -96,6 +117,8 @@ class LMOracle:
     def __init__(self, state_dict, cfg):
         self.cfg = cfg
         sd = {k: _np(v) for k, v in state_dict.items()}
+        for k in [k for k in sd if k.endswith("_scb")]:          # int8 linears: `weight` (int8) + `weight_scb`
+            sd[k[:-4]] = QWeight(sd[k[:-4]], sd.pop(k))
         c = cfg
         self.emb = [sd[f"emb.{i}.weight"] for i in range(c.n_q)]
         self.text_emb = sd["text_emb.weight"]

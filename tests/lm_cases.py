@@ -167,8 +167,11 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
             prev_tt, prev_a0 = tt, toks[0]
 
 
-def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True):
+def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False):
     sd = random_lm_state_dict(cfg, seed=seed)
+    if quantize:    # row-wise int8 linears (the reference's `quantize=True` storage); engine and oracle get the same int8 tensors
+        from moshi_amd.weights import quantize_lm_state_dict
+        sd = quantize_lm_state_dict(sd)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
     orc = LMOracle(sd, cfg)
     orc.streaming(B)

@@ -42,6 +42,18 @@ def test_tiny_matches_oracle_with_masks_and_reset(gpu_lib, B):
     lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=50 + B, B=B, S=16 if B <= 5 else 4)
 
 
+@pytest.mark.parametrize("B", [2, 18, 40])
+def test_int8_weights_match_the_int8_oracle(gpu_lib, B):
+    """C5's weight format (`quantize=True`: row-wise int8 + `weight_scb`) on the tiny model, all three batch tilings."""
+    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
+
+
+def test_int8_full_width_layers_match_oracle(gpu_lib):
+    """int8 linears at the 7B layer shapes (2 temporal layers, full depformer), B=3 with masks."""
+    cfg = LMConfig(num_layers=2, context=64)
+    lm_cases.oracle_vs_engine(DEV, None, cfg, seed=9, B=3, S=3, use_masks=True, quantize=True)
+
+
 def test_full_width_layers_match_oracle(gpu_lib):
     """Moshi-7B layer shapes (dim 4096, 32 heads x 128, FFN 11264, text head 32000; depformer 1024 x 6 layers x 8 steps)
     with 2 temporal layers, so that the numpy oracle finishes in seconds: exercises every GEMM tile variant,

@@ -47,6 +47,27 @@ def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=78, B=3, S=3)
 
 
+@pytest.mark.parametrize("B", [2, 18])
+def test_int8_weights_match_the_int8_oracle(sim_lib, B):
+    """`quantize=True`: row-wise int8 linears (utils/quantize.py storage), widened to bf16 in registers.  Same tolerance as
+    the bf16 path against an oracle holding the same int8 tensors."""
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
+
+
+def test_int8_quantisation_error_is_small_and_storage_is_bnb_style():
+    from moshi_amd.weights import quantize_lm_state_dict
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=4)
+    q = quantize_lm_state_dict(sd)
+    k = "transformer.layers.0.gating.linear_in.weight"
+    assert q[k].dtype == torch.int8 and q[k + "_scb"].dtype == torch.float32 and q[k + "_scb"].shape == (sd[k].shape[0],)
+    assert q["emb.0.weight"].dtype == torch.bfloat16 and "emb.0.weight_scb" not in q          # embeddings are not quantised
+    deq = q[k].float() * (q[k + "_scb"] / 127.0)[:, None]
+    w = sd[k].float()
+    assert (deq - w).abs().max() <= 0.51 * (q[k + "_scb"] / 127.0).max() + 1e-3 * w.abs().max()   # half a step (+ the fp16 cast)
+    assert int(q[k].abs().max()) == 127
+
+
 def test_none_during_delay_and_errors(sim_lib):
     g = np.load(lm_cases.GOLDEN / "lm_tiny.npz")
     cfg = tiny_lm_config()
