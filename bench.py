@@ -124,7 +124,9 @@ def main():
         workload = "duplex" if have_lm else "mimi"
     B = args.batch
     mcfg = MimiConfig()
-    msd = random_mimi_state_dict(mcfg, seed=1234, device=dev)
+    from bench_lm import replicated_state_dict
+    from moshi_amd.weights import mimi_state_spec
+    msd = replicated_state_dict(lambda: random_mimi_state_dict(mcfg, seed=1234, device=dev), mimi_state_spec(mcfg), torch.float32, dev)
     mimi = MimiModel(msd, mcfg, device=dev, max_batch=B, num_codebooks=8)
     mimi.streaming_forever(B)
     lm_gen = None

@@ -13,14 +13,26 @@ import torch
 HBM_PEAK_GBS = 8000.0
 
 
+def replicated_state_dict(draw, spec, dtype, dev):
+    """One process per GPU: rank 0 draws the (7.7 B parameter, bf16, seeded) weights on its GPU and replicates them to the
+    other ranks with RCCL broadcasts in 1 GiB buckets (moshi_amd/dist.py) - the deployment's only collective, at load, as in
+    SURVEY.md 8e.  Single process, or MMI_BENCH_NO_BCAST=1: every rank draws the same seeded weights itself."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or os.environ.get("MMI_BENCH_NO_BCAST"):
+        return draw()
+    from moshi_amd.dist import broadcast_state_dict
+    sd = draw() if dist.get_rank() == 0 else None
+    return broadcast_state_dict(sd, spec, dtype, dev, src=0)
+
+
 def make_lm(dev, B, args):
     from moshi_amd.config import LMConfig
     from moshi_amd.lm import LMGen, LMModel
-    from moshi_amd.weights import random_lm_state_dict
+    from moshi_amd.weights import lm_state_spec, random_lm_state_dict
     cfg = LMConfig()
     if args.lm_layers:
         cfg.num_layers = args.lm_layers
-    sd = random_lm_state_dict(cfg, seed=4242, device=dev)       # drawn on the GPU: 7.7 B parameters in bf16
+    sd = replicated_state_dict(lambda: random_lm_state_dict(cfg, seed=4242, device=dev), lm_state_spec(cfg), torch.bfloat16, dev)
     if getattr(args, "quant", "none") == "q8":                  # quantise tensor by tensor (frees the bf16 copy as it goes)
         from moshi_amd.weights import is_lm_linear_weight, quantize_lm_state_dict
         for k in [k for k in sd if is_lm_linear_weight(k)]:

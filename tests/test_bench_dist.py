@@ -40,3 +40,29 @@ def test_single_rank_passthrough():
     import bench
     assert bench.job_time(0.3, None, None) == 0.3
     assert bench.job_value(1, 32, 10, 0.5) == 640.0
+
+
+def _bcast_worker(rank, world, port, out):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from moshi_amd.config import tiny_lm_config
+    from moshi_amd.dist import broadcast_state_dict
+    from moshi_amd.weights import lm_state_spec, random_lm_state_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = tiny_lm_config()
+    spec = lm_state_spec(cfg)
+    sd = random_lm_state_dict(cfg, seed=31) if rank == 0 else None     # only rank 0 holds the weights
+    got = broadcast_state_dict(sd, spec, torch.bfloat16, "cpu", src=0, bucket_bytes=1 << 16)   # small buckets: several broadcasts
+    ref = random_lm_state_dict(cfg, seed=31)
+    out[rank] = (set(got) == set(ref)) and all(torch.equal(got[k], ref[k]) for k in ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_broadcast_at_load_two_ranks():
+    """The engine's one collective: rank 0's weights replicated to the other rank in flat buckets (gloo here, RCCL on GPUs)."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_bcast_worker, args=(world, 29613, out), nprocs=world, join=True)
+    assert out[0] and out[1]
