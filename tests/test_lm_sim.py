@@ -68,6 +68,27 @@ def test_int8_quantisation_error_is_small_and_storage_is_bnb_style():
     assert int(q[k].abs().max()) == 127
 
 
+def test_depformer_replace_tokens_argument(sim_lib):
+    """`LMGen.step(codes, depformer_replace_tokens=...)` (lm.py:751-755): the given audio tokens enter the delay ring instead
+    of the depformer's own; checked against the oracle teacher-forced on the same audio tokens."""
+    from oracle.lm_oracle import LMOracle
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=33)
+    B = 2
+    gen = lm_cases.make_engine(cfg, sd, "cpu", sim_lib, B, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(B)
+    rng = np.random.default_rng(7)
+    with gen.streaming(B):
+        for s in range(5):
+            codes = rng.integers(0, cfg.card, (B, 8, 1))
+            repl = rng.integers(0, cfg.card, (B, cfg.dep_q, 1))
+            forced = np.concatenate([np.full((B, 1), -1), repl[:, :, 0]], 1)
+            oo, _ = orc.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+            out = gen.step(torch.from_numpy(codes), depformer_replace_tokens=torch.from_numpy(repl))
+            assert np.array_equal(out.numpy()[:, 1:], oo[:, 1:]), f"step {s}: audio rows of the ring differ"
+
+
 def test_none_during_delay_and_errors(sim_lib):
     g = np.load(lm_cases.GOLDEN / "lm_tiny.npz")
     cfg = tiny_lm_config()
