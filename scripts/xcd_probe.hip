@@ -53,7 +53,9 @@ __global__ __launch_bounds__(256) void k_barrier(int want, int nsel, int rounds,
         __syncthreads();
         const int nb = (me + 1) % nsel;
         const float v = __builtin_nontemporal_load(&rec[nb * 256 + threadIdx.x]);
-        if (v != (float)(r * 1000 + nb)) atomicAdd(fail + 1, 1);
+        if (v != (float)(r * 1000 + nb)) {
+            if (atomicAdd(fail + 1, 1) == 0) { fail[2] = r; fail[3] = me; fail[4] = (int)v; fail[5] = (int)threadIdx.x; }   // first stale read: round, reader, value seen
+        }
         __syncthreads();
     }
 }
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void k_barrier(int want, int nsel, int rounds,
 int main() {
     hipStream_t s; CK(hipStreamCreate(&s));
     int *count, *ticket, *fail; unsigned* counter; float* rec; unsigned* sink;
-    CK(hipMalloc(&count, 64)); CK(hipMalloc(&ticket, 4)); CK(hipMalloc(&fail, 8)); CK(hipMalloc(&counter, 4)); CK(hipMalloc(&rec, 256 * 256 * 4)); CK(hipMalloc(&sink, 4));
+    CK(hipMalloc(&count, 64)); CK(hipMalloc(&ticket, 4)); CK(hipMalloc(&fail, 32)); CK(hipMalloc(&counter, 4)); CK(hipMalloc(&rec, 256 * 256 * 4)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(count, 0, 64));
     k_census<<<256, 64, 0, s>>>(count);
     int h[16]; CK(hipMemcpy(h, count, 64, hipMemcpyDeviceToHost));
@@ -81,13 +83,16 @@ int main() {
         }
     }
     for (int rounds : {100, 1000, 100, 5000, 100}) {
-        CK(hipMemset(ticket, 0, 4)); CK(hipMemset(counter, 0, 4)); CK(hipMemset(fail, 0, 8));
+        CK(hipMemset(ticket, 0, 4)); CK(hipMemset(counter, 0, 4)); CK(hipMemset(fail, 0, 32));
+        if (getenv("PROBE_SYNC")) CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, s));
         k_barrier<<<256, 256, 0, s>>>(0, nsel, rounds, counter, ticket, rec, fail);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        int f[2]; CK(hipMemcpy(f, fail, 8, hipMemcpyDeviceToHost));
-        printf("XCC-0 barrier + 1 KiB neighbour hand-off, %d workgroups, %d rounds: %.2f us per round (timeouts %d, stale reads %d)\n", nsel, rounds, 1e3 * ms / rounds, f[0], f[1]);
+        int f[8]; CK(hipMemcpy(f, fail, 32, hipMemcpyDeviceToHost));
+        printf("XCC-0 barrier + 1 KiB neighbour hand-off, %d workgroups, %d rounds: %.2f us per round (timeouts %d, stale reads %d", nsel, rounds, 1e3 * ms / rounds, f[0], f[1]);
+        if (f[1]) printf("; first: round %d reader %d saw %d thread %d", f[2], f[3], f[4], f[5]);
+        printf(")\n");
     }
     return 0;
 }
