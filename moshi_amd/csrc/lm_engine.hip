@@ -44,6 +44,8 @@ struct mmi_lm {
     uint16_t* out_norm = nullptr;
     GemmW text_linear;
     std::vector<GemmW> dep_in, dep_lin;
+    GemmW dep_in_all;               // the dep_q depformer_in linears as one [dep_q * depformer_dim, dim] GEMM
+    bool dep_in_grouped = false;
     std::vector<uint16_t*> dep_emb; // [0] = depformer_text_emb, [k>=1] = depformer_emb[k-1]
     std::vector<DepLayerW> dep_layers;
     int* delays_dev = nullptr;
@@ -69,6 +71,7 @@ struct mmi_lm {
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
+    uint16_t* dpre = nullptr;       // [B][dep_q * depformer_dim] depformer_in[k](transformer_out) of every micro-step
     uint16_t *dkc = nullptr, *dvc = nullptr;        // [dep_layers][B][Hd][dep_q][Dhd]
     float* noise = nullptr;                         // [B][1+dep_q][kmax]
     int* use_noise = nullptr;
@@ -105,7 +108,9 @@ __global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict_
     if (i < n) scale[i] = scb[i] / 127.0f;
 }
 
-int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g) {
+// wp_dst / scale_dst: pack into a slice of a caller-owned allocation instead of a fresh one (see load_dep_in_group)
+int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g,
+                void* wp_dst = nullptr, float* scale_dst = nullptr) {
     const mmi_tensor_desc* d = W.find(name);
     if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
     if (d->dtype != MMI_BF16 && d->dtype != MMI_I8) return mmi_fail(MMI_ERR_UNSUPPORTED, "LM linear weights must be bf16 or int8: " + name);
@@ -126,8 +131,8 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     if (!q8) {
         g->KSTEPS = ksteps;
         size_t n = (size_t)g->NT * g->KSTEPS * 512;
-        uint16_t* p = nullptr;
-        MMI_HIP_CHECK(lm->wts.alloc(&p, n));
+        uint16_t* p = reinterpret_cast<uint16_t*>(wp_dst);
+        if (!p) MMI_HIP_CHECK(lm->wts.alloc(&p, n));
         g->wp = reinterpret_cast<u32x4*>(p);
         g->bytes = n * sizeof(uint16_t);
         MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
@@ -138,10 +143,11 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         if (sc->dtype != MMI_F32 || sc->shape[0] != N) return mmi_fail(MMI_ERR_SHAPE, "weight_scb must be fp32 [out_features]: " + name);
         g->KSTEPS = mmi_cdiv(ksteps, 2);                       // pairs of k-steps
         size_t n = (size_t)g->NT * g->KSTEPS * 1024;
-        int8_t* p = nullptr;
-        MMI_HIP_CHECK(lm->wts.alloc(&p, n));
+        int8_t* p = reinterpret_cast<int8_t*>(wp_dst);
+        if (!p) MMI_HIP_CHECK(lm->wts.alloc(&p, n));
         g->wp = reinterpret_cast<u32x4*>(p);
-        MMI_HIP_CHECK(lm->wts.alloc(&g->scale, (size_t)N));
+        g->scale = scale_dst;
+        if (!g->scale) MMI_HIP_CHECK(lm->wts.alloc(&g->scale, (size_t)N));
         g->bytes = n + (size_t)N * sizeof(float);
         MMI_LAUNCH(k_pack_w_i8, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const int8_t*)d->data, p, N, K, TN,
                    g->NT, g->KSTEPS, gate_hidden);
@@ -347,8 +353,16 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     });
 }
 
-void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride) {
+// next_k >= 0: the sampled token opens depth-transformer micro-step next_k, whose input row the sampler writes itself
+void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride, int next_k = -1) {
     SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    if (next_k >= 0) {
+        const int dd = lm->cfg.depformer_dim;
+        sa.nx_pre = lm->dpre + (size_t)next_k * dd; sa.nx_ld = lm->cfg.dep_q * dd;
+        sa.nx_emb = lm->dep_emb[next_k]; sa.nx_out = lm->dx;
+        sa.nx_D = dd; sa.nx_T = lm->T; sa.nx_ksteps = packed_ksteps(lm, dd);
+    }
     sa.logits = logits; sa.ld = ld; sa.V = V;
     sa.k = text ? lm->samp.top_k_text : lm->samp.top_k;
     sa.temp = text ? lm->samp.temp_text : lm->samp.temp;
@@ -452,13 +466,17 @@ int build_program(mmi_lm* lm) {
     }
     add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
     add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr);
-    add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1);
+    // depformer_in[k](transformer_out) for every micro-step in one launch; each sampler then adds its token's embedding row
+    // and writes the next micro-step's input (lm.py:465-470) - 8 dependent launches less on the sequential chain
+    const bool grouped = lm->dep_in_grouped;
+    if (grouped) add_gemm(lm, lm->dep_in_all, lm->tout, lm->dpre, c.dep_q * dd, false, MMI_EPI_STORE, nullptr);
+    add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1, grouped ? 0 : -1);
     // ---- depformer: dep_q sequential micro-steps
     const size_t dkv_layer = (size_t)B * Hd * c.dep_q * Dhd;
     for (int k = 0; k < c.dep_q; ++k) {
         const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
         const int prev_stride = k == 0 ? 1 : c.dep_q;
-        add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
+        if (!grouped) add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
             add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
@@ -477,7 +495,7 @@ int build_program(mmi_lm* lm) {
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
         add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr);
-        add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q);
+        add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q, grouped && k + 1 < c.dep_q ? k + 1 : -1);
     }
     // ---- token ring out
     {
@@ -560,10 +578,35 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     // depformer (lm.py:179-232; per-step weights transformer.py:291-318)
     lm->dep_in.resize(c.dep_q);
     lm->dep_lin.resize(c.dep_q);
-    for (int k = 0; k < c.dep_q; ++k) {
-        if ((rc = load_linear(lm, W, "depformer_in." + std::to_string(k) + ".weight", dd, d, 0, &lm->dep_in[k]))) return fail(rc);
-        if ((rc = load_linear(lm, W, "linears." + std::to_string(k) + ".weight", c.card, dd, 0, &lm->dep_lin[k]))) return fail(rc);
+    {
+        // depformer_in[k] all read transformer_out, so they are packed back to back and run as ONE GEMM with
+        // dep_q * depformer_dim output features ahead of the micro-step loop (build_program).  Needs whole n-tiles per step.
+        const bool group = dd % lm->T == 0 && !getenv("MMI_NO_DEP_IN_GROUP");
+        uint8_t* wp_all = nullptr;
+        float* scale_all = nullptr;
+        size_t per = 0;
+        if (group) {
+            const int NT = dd / lm->T, ksteps = mmi_cdiv(d, mmi_kstep(lm->T));
+            per = lm->q8 == 1 ? (size_t)NT * mmi_cdiv(ksteps, 2) * 1024 : (size_t)NT * ksteps * 512 * sizeof(uint16_t);
+            if (lm->wts.alloc(&wp_all, per * c.dep_q) != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in)"));
+            if (lm->q8 == 1 && lm->wts.alloc(&scale_all, (size_t)dd * c.dep_q) != hipSuccess)
+                return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in scales)"));
+        }
+        for (int k = 0; k < c.dep_q; ++k) {
+            if ((rc = load_linear(lm, W, "depformer_in." + std::to_string(k) + ".weight", dd, d, 0, &lm->dep_in[k],
+                                  group ? wp_all + per * k : nullptr, scale_all ? scale_all + (size_t)dd * k : nullptr)))
+                return fail(rc);
+        }
+        if (group) {
+            lm->dep_in_all = lm->dep_in[0];
+            lm->dep_in_all.N = dd * c.dep_q;
+            lm->dep_in_all.NT = lm->dep_in[0].NT * c.dep_q;
+            lm->dep_in_all.bytes = lm->dep_in[0].bytes * c.dep_q;
+            lm->dep_in_grouped = true;
+        }
     }
+    for (int k = 0; k < c.dep_q; ++k)
+        if ((rc = load_linear(lm, W, "linears." + std::to_string(k) + ".weight", c.card, dd, 0, &lm->dep_lin[k]))) return fail(rc);
     lm->dep_layers.resize(c.depformer_num_layers);
     for (int l = 0; l < c.depformer_num_layers; ++l) {
         DepLayerW& L = lm->dep_layers[l];
@@ -644,6 +687,7 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     ok &= hipSuccess == A.alloc(&lm->datt, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dhb, packed_elems(lm, c.depformer_ffn_hidden));
     ok &= hipSuccess == A.alloc(&lm->dlogits, (size_t)c.dep_q * B * c.card);
+    ok &= hipSuccess == A.alloc(&lm->dpre, (size_t)B * c.dep_q * dd);
     ok &= hipSuccess == A.alloc(&lm->dkc, dkvn);
     ok &= hipSuccess == A.alloc(&lm->dvc, dkvn);
     ok &= hipSuccess == A.alloc(&lm->noise, (size_t)B * (1 + c.dep_q) * lm->kmax);

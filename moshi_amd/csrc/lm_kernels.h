@@ -927,7 +927,32 @@ struct SampleArgs {
     const int* forced;        // teacher forcing (parity taps / depformer_replace_tokens): forced[b * forced_stride]
     int forced_stride;        // is written instead of the sampled token when *use_forced != 0 and the value is >= 0
     const int* use_forced;
+    // optional: the sampled token opens the next depth-transformer micro-step (lm.py:465-470) - the workgroup also writes
+    // x0[b] = nx_pre[b] + nx_emb[token] (token -1 -> zero row, lm_utils.py:102-124) as the packed activation operand
+    const uint16_t* nx_pre;   // [B][nx_ld] bf16: depformer_in[k](transformer_out), computed for all k ahead of the loop
+    int nx_ld;
+    const uint16_t* nx_emb;   // [card + 1][nx_D]
+    uint16_t* nx_out;         // Xp layout (mmi_xp_index), null = nothing to write
+    int nx_D, nx_T, nx_ksteps;
 };
+
+__device__ __forceinline__ void mmi_sample_next_input(const SampleArgs& a, int b, int tok) {
+    if (!a.nx_out) return;
+    for (int g = (int)threadIdx.x; g < a.nx_D / 8; g += (int)blockDim.x) {
+        const int n0 = 8 * g;
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(a.nx_pre + (long)b * a.nx_ld + n0);
+        u32x4 ev = {0u, 0u, 0u, 0u};
+        if (tok != -1) ev = *reinterpret_cast<const u32x4*>(a.nx_emb + (long)(tok < 0 ? 0 : tok) * a.nx_D + n0);
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = mmi_bf16_to_f32((uint16_t)(pv[e] & 0xffffu)) + mmi_bf16_to_f32((uint16_t)(ev[e] & 0xffffu));
+            const float hi = mmi_bf16_to_f32((uint16_t)(pv[e] >> 16)) + mmi_bf16_to_f32((uint16_t)(ev[e] >> 16));
+            ov[e] = mmi_pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(a.nx_out + mmi_xp_index(a.nx_T, b, n0, a.nx_ksteps)) = ov;
+    }
+}
 
 __device__ __forceinline__ int mmi_apply_forced(const SampleArgs& a, int b, int tok) {
     if (*a.use_forced) {
@@ -1053,7 +1078,13 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         if (tid == 0) {
             for (int w = 1; w < NT / 64; ++w)
                 if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
-            a.out[(long)b * a.out_stride] = mmi_apply_forced(a, b, bi);
+            bi = mmi_apply_forced(a, b, bi);
+            a.out[(long)b * a.out_stride] = bi;
+            redi[0] = bi;
+        }
+        if (a.nx_out) {
+            __syncthreads();
+            mmi_sample_next_input(a, b, redi[0]);
         }
         return;
     }
@@ -1165,7 +1196,13 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     if (tid == 0) {
         for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > score || (redf[w] == score && redr[w] < rank)) { score = redf[w]; rank = redr[w]; tok = redi[w]; }
-        a.out[(long)b * a.out_stride] = mmi_apply_forced(a, b, tok);
+        tok = mmi_apply_forced(a, b, tok);
+        a.out[(long)b * a.out_stride] = tok;
+        redi[0] = tok;
+    }
+    if (a.nx_out) {
+        __syncthreads();
+        mmi_sample_next_input(a, b, redi[0]);
     }
 }
 

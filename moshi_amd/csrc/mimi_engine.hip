@@ -466,7 +466,7 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
     const size_t kv_layer = (size_t)B * H * cap * Dh;
     if (T > 2 || (Dh != 16 && Dh != 32 && Dh != 64))
         return mmi_fail(MMI_ERR_UNSUPPORTED, "Mimi attention: head dim 16/32/64 and 1 or 2 steps per frame are built");
-    const size_t attn_smem = ((size_t)T * Dh + (size_t)T * cap + (size_t)(256 / (Dh / 4)) * T * Dh + 8) * sizeof(float);
+    const size_t attn_smem = ((size_t)T * Dh + (((size_t)T * cap + 3) & ~(size_t)3) + (size_t)(256 / (Dh / 4)) * T * Dh + 8) * sizeof(float);
     auto add_norm = [&](const float* w, const float* bb) {
         const float* xp = xb.p; int xld = xb.ld; float* yn = y.p;
         prog.add([=](hipStream_t s) {
@@ -487,8 +487,11 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
             aa.offsets = offsets; aa.out = att.p; aa.B = B; aa.H = H; aa.D = Dh; aa.T = T; aa.cap = cap;
             aa.context = c.tr_context; aa.max_period = c.tr_max_period;
             aa.outp = attp; aa.outQ = Qd;
+            // one memory round trip when a thread's 16 row slots cover the ring (the Mimi shape: 250 slots of 64 floats)
+            const bool one_pass = cap <= 16 * (256 / (Dh / 4)) && !getenv("MMI_MIMI_ATTN_TWO_PASS");
             prog.add([=](hipStream_t s) {
-#define MMI_ATT(D_, T_) MMI_LAUNCH((k_mimi_attn<D_, T_>), B * H, 256, attn_smem, s, aa)
+#define MMI_ATT(D_, T_) do { if (one_pass) MMI_LAUNCH((k_mimi_attn_1pass<D_, T_>), B * H, 256, 0, s, aa); \
+                             else MMI_LAUNCH((k_mimi_attn<D_, T_>), B * H, 256, attn_smem, s, aa); } while (0)
                 if (Dh == 64 && T == 2) MMI_ATT(64, 2);
                 else if (Dh == 64 && T == 1) MMI_ATT(64, 1);
                 else if (Dh == 32 && T == 2) MMI_ATT(32, 2);

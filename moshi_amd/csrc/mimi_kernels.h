@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
     MMI_DYN_SHARED(float, sm);
     float* qs = sm;               // [T][D] roped queries
     float* sc = qs + T * D;       // [T][cap] scores / probabilities
-    float* red = sc + T * cap;    // [RPB][T][D] partial outputs
+    float* red = sc + ((T * cap + 3) & ~3);   // [RPB][T][D] partial outputs (16-byte aligned: written as f32x4)
     const long off = a.offsets[b];
     const int HD = a.H * D;
     const float* qrow = a.qkv + (long)b * 3 * HD * T;
@@ -778,6 +778,150 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
         for (int r = 0; r < RPB; ++r) s += red[(r * T + t) * D + d];
         if (a.outp) a.outp[mmi_bp_index(h * D + d, b * T + t, a.outQ)] = s;
         else a.out[((long)b * HD + h * D + d) * T + t] = s;
+    }
+}
+
+// Same operation in ONE memory round trip, for rings of at most 16 * (256 / (D/4)) slots (Mimi: 250 slots of 64 floats):
+// every thread first issues its 16 key and 16 value row segments (unconditional, clamped loads: 128 KiB per workgroup in
+// flight), ropes the new tokens while they travel, and then keeps scores, exponentials and the weighted value sum in
+// registers.  Each wave normalises against its own maximum; the four waves are merged through LDS with the usual
+// exp(m_wave - m) rescale.  The slots written by this call are taken from LDS instead of the ring (the ring loads were
+// issued before the write).  Static LDS: qs | kn | vn [T][D], red[4][T][D], mw/sw [4][T].
+template <int D, int T>
+__global__ __launch_bounds__(256) void k_mimi_attn_1pass(MimiAttnArgs a) {
+    constexpr int LPR = D / 4;             // lanes per ring row
+    constexpr int RPB = 256 / LPR;         // rows per block pass
+    constexpr int IT = 16;                 // passes: cap <= IT * RPB
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cap = a.cap;
+    MMI_SHARED __attribute__((aligned(16))) float qs[T * D];
+    MMI_SHARED __attribute__((aligned(16))) float kn[T * D];
+    MMI_SHARED __attribute__((aligned(16))) float vn[T * D];
+    MMI_SHARED __attribute__((aligned(16))) float red[4 * T * D];
+    MMI_SHARED float mw[4 * T];
+    MMI_SHARED float sw[4 * T];
+    const long off = a.offsets[b];
+    const int HD = a.H * D;
+    const float* qrow = a.qkv + (long)b * 3 * HD * T;
+    float* kcb = a.kc + ((long)b * a.H + h) * cap * D;
+    float* vcb = a.vc + ((long)b * a.H + h) * cap * D;
+    const long last = off + T - 1;
+    const int end_index = (int)(last % cap);
+    const long end_new = off + T;
+    const int L = (int)(end_new < (long)cap ? end_new : (long)cap);
+    const int seg = tid % LPR, rsub = tid / LPR;
+
+    f32x4 kk[IT], vv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const long r = (long)min(i * RPB + rsub, L - 1) * D + seg * 4;
+        kk[i] = *reinterpret_cast<const f32x4*>(kcb + r);
+        vv[i] = *reinterpret_cast<const f32x4*>(vcb + r);
+    }
+
+    // rope(q), rope(k) -> LDS and ring, v -> LDS and ring (written unconditionally, transformer.py:243-250)
+    for (int i = tid; i < T * (D / 2); i += 256) {
+        const int t = i / (D / 2), j = i % (D / 2);
+        const float freq = expf((float)j * (-logf(a.max_period) * 2.0f / (float)D));
+        const float ang = freq * (float)(off + t);
+        const float c = cosf(ang), s = sinf(ang);
+        const float qr = qrow[(long)(h * D + 2 * j) * T + t], qi = qrow[(long)(h * D + 2 * j + 1) * T + t];
+        const float kr = qrow[(long)(HD + h * D + 2 * j) * T + t], ki = qrow[(long)(HD + h * D + 2 * j + 1) * T + t];
+        qs[t * D + 2 * j] = qr * c - qi * s;
+        qs[t * D + 2 * j + 1] = qr * s + qi * c;
+        kn[t * D + 2 * j] = kr * c - ki * s;
+        kn[t * D + 2 * j + 1] = kr * s + ki * c;
+    }
+    for (int i = tid; i < T * D; i += 256) {
+        const int t = i / D, d = i % D;
+        vn[i] = qrow[(long)(2 * HD + h * D + d) * T + t];
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += 256) {
+        const int t = i / D, d = i % D;
+        const long slot = (off + t) % cap;
+        kcb[slot * D + d] = kn[i];
+        vcb[slot * D + d] = vn[i];
+    }
+
+    const float scale = 1.0f / sqrtf((float)D);
+    f32x4 qv[T];
+    int newslot[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        qv[t] = *reinterpret_cast<const f32x4*>(qs + t * D + seg * 4);
+        newslot[t] = (int)((off + t) % cap);
+    }
+    float sc[T][IT];
+    float mx[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) mx[t] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int slot = i * RPB + rsub;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (slot == newslot[t]) {      // a later token of this call overwrites an earlier one when T > cap never happens (T <= 2 <= cap)
+                kk[i] = *reinterpret_cast<const f32x4*>(kn + t * D + seg * 4);
+                vv[i] = *reinterpret_cast<const f32x4*>(vn + t * D + seg * 4);
+            }
+        const int delta = slot - end_index;
+        const long pos = delta <= 0 ? last + delta : last + delta - cap;     // position held by the slot (transformer.py:258-286)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float dv = (qv[t][0] * kk[i][0] + qv[t][1] * kk[i][1]) + (qv[t][2] * kk[i][2] + qv[t][3] * kk[i][3]);
+#pragma unroll
+            for (int m = LPR / 2; m >= 1; m >>= 1) dv += mmi_shfl_xor(dv, m);
+            const long dq = (off + t) - pos;
+            const bool ok = slot < L && pos >= 0 && dq >= 0 && dq < a.context;
+            sc[t][i] = ok ? dv * scale : -INFINITY;
+            mx[t] = fmaxf(mx[t], sc[t][i]);
+        }
+    }
+    float acc[T][4], sum[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) mx[t] = fmaxf(mx[t], mmi_shfl_xor(mx[t], m));    // the wave's maximum
+        const float mref = mx[t] == -INFINITY ? 0.f : mx[t];
+        sum[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const float p = expf(sc[t][i] - mref);
+            sum[t] += p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] += p * vv[i][e];
+        }
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) {
+            sum[t] += mmi_shfl_xor(sum[t], m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] += mmi_shfl_xor(acc[t][e], m);
+        }
+        if (lane < LPR) {
+            *reinterpret_cast<f32x4*>(red + (wave * T + t) * D + seg * 4) = f32x4{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+            if (lane == 0) { mw[wave * T + t] = mx[t]; sw[wave * T + t] = sum[t]; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * D; i += 256) {
+        const int t = i / D, d = i % D;
+        float m = mw[t];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = fmaxf(m, mw[w * T + t]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = expf(mw[w * T + t] - m);      // 0 for a wave whose slots were all masked
+            num += f * red[(w * T + t) * D + d];
+            den += f * sw[w * T + t];
+        }
+        const float o = num / den;
+        if (a.outp) a.outp[mmi_bp_index(h * D + d, b * T + t, a.outQ)] = o;
+        else a.out[((long)b * HD + h * D + d) * T + t] = o;
     }
 }
 

@@ -47,6 +47,15 @@ def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=78, B=3, S=3)
 
 
+def test_depformer_in_per_step_launches(sim_lib, monkeypatch):
+    """The engine normally runs the dep_q `depformer_in` linears as one grouped GEMM and lets each sampler add its token's
+    embedding row; depth widths that are not whole n-tiles fall back to one GEMM per micro-step with the embedding in its
+    epilogue.  Force that path."""
+    monkeypatch.setenv("MMI_NO_DEP_IN_GROUP", "1")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=91, B=3, S=4)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=92, B=2, S=3, quantize=True)
+
+
 @pytest.mark.parametrize("B", [2, 18])
 def test_int8_weights_match_the_int8_oracle(sim_lib, B):
     """`quantize=True`: row-wise int8 linears (utils/quantize.py storage), widened to bf16 in registers.  Same tolerance as

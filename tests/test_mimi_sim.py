@@ -36,6 +36,17 @@ def test_conv_kernel_variants(factory, monkeypatch, mtb, w, ks):
     mimi_cases.oracle_vs_engine(factory, "cpu", tiny_mimi_config(), seed=90 + mtb, B=6, F=3, K=5)
 
 
+@pytest.mark.parametrize("heads,two_pass", [(2, False), (4, False), (2, True)])
+def test_attention_head_dims_and_ring_wrap(factory, monkeypatch, heads, two_pass):
+    """Head dims 64 / 32 (the tiny codec has 16) through the one-round-trip attention kernel and its two-pass fallback,
+    with more steps than ring slots so that the ring wraps and old positions fall out of the context."""
+    from dataclasses import replace
+    if two_pass:
+        monkeypatch.setenv("MMI_MIMI_ATTN_TWO_PASS", "1")
+    cfg = replace(tiny_mimi_config(), dimension=128, tr_d_model=128, tr_num_heads=heads, tr_context=5)
+    mimi_cases.oracle_vs_engine(factory, "cpu", cfg, seed=50 + heads, B=2, F=5, K=3)
+
+
 def test_multi_frame_call_equals_frame_by_frame(factory):
     cfg = tiny_mimi_config()
     sd = random_mimi_state_dict(cfg, seed=3)
