@@ -599,14 +599,18 @@ __global__ __launch_bounds__(64) void k_layernorm_ct(const float* __restrict__ x
     const int lane = threadIdx.x;
     const float* xc = x + (long)b * C * x_ld + x_off + t;
     constexpr int NR = 16;                 // channels per lane held in registers (C <= 1024), one round of loads
-    float xv[NR];
+    float xv[NR], wv[NR], bv[NR];          // weight and bias ride along with the input: one memory round trip in all
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int c = lane + i * 64;
-        xv[i] = xc[(long)(c < C ? c : 0) * x_ld];
-        s += c < C ? xv[i] : 0.f;
+        const int cc = c < C ? c : 0;
+        xv[i] = xc[(long)cc * x_ld];
+        wv[i] = w[cc];
+        bv[i] = bvec[cc];
     }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) s += (lane + i * 64) < C ? xv[i] : 0.f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s += mmi_shfl_xor(s, m);
     const float mean = s / (float)C;
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64) void k_layernorm_ct(const float* __restrict__ x
     for (int i = 0; i < NR; ++i) {
         const int c = lane + i * 64;
         if (c < C) {
-            const float o = (xv[i] - mean) * rstd * w[c] + bvec[c];
+            const float o = (xv[i] - mean) * rstd * wv[i] + bv[i];
             if (yp) yp[mmi_bp_index(c, blockIdx.x, yQ)] = o;   // packed B operand of the consuming linear (column n = b*T + t)
             else yc[(long)c * y_ld] = o;
         }
