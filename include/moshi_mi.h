@@ -40,7 +40,8 @@ typedef enum mmi_status {
     MMI_ERR_STATE = -3,          /* not streaming: reference raises RuntimeError (lm.py:673-676)          */
     MMI_ERR_HIP = -4,            /* a HIP runtime call failed                                           */
     MMI_ERR_MISSING_WEIGHT = -5, /* a state-dict key required by the config was not supplied             */
-    MMI_ERR_UNSUPPORTED = -6     /* config outside what the kernels implement                           */
+    MMI_ERR_UNSUPPORTED = -6,    /* config outside what the kernels implement                           */
+    MMI_ERR_BUSY = -7            /* batcher: no free slot / a channel's buffer is full                    */
 } mmi_status;
 
 typedef enum mmi_dtype { MMI_F32 = 0, MMI_BF16 = 1, MMI_I64 = 2, MMI_F16 = 3, MMI_I8 = 4 } mmi_dtype;
@@ -215,6 +216,60 @@ int mmi_lm_profile_begin(mmi_lm* lm);
  * bytes one such launch streams (packed weight bytes + activations in/out). Synchronises the stream. */
 int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,
                        const char** kernel_name);
+
+/* Architecture the handle was created with (what callers read as attributes: frame_size, num_codebooks, dep_q ...). */
+int mmi_mimi_get_cfg(const mmi_mimi* m, mmi_mimi_cfg* out);
+int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Session batcher: many live dialogue sessions on one GPU                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* SURVEY.md 8f-1.  The reference's Python server runs ONE session under a lock (server.py:45,57,154-169);
+ * its Rust server packs up to `batch_size` live channels into one batched model step with a per-row stream
+ * mask and a per-row reset when a channel is (re)opened (rust/moshi-server/src/batched_asr.rs:188-276 model
+ * loop, :279-374 pre_process, :376-437 post_process; py_module.rs:443-470 slot allocation).  This is that
+ * model loop for the full-duplex path, on top of the entry points above:
+ *
+ *   every mmi_batcher_step:  per slot, take one 80 ms frame from the channel's PCM FIFO if it holds one (exec mask),
+ *   reset the rows of channels opened since the last step, then  Mimi encode -> LMGen.step -> Mimi decode  on the
+ *   whole batch, and hand each executed row's (text token, audio tokens, PCM frame) to its channel's output FIFO.
+ *
+ * Host pointers here are HOST memory: the batcher owns pinned staging buffers and its own HIP stream.
+ * open/close/push/pop may be called from any thread; step from one thread at a time (the model loop). */
+typedef struct mmi_batcher_cfg {
+    int32_t slots;                          /* rows of the batch = concurrent channels; <= both handles' max_batch */
+    int32_t reset_codec_after_first_frame;  /* server.py:135-141: the first input frame's encoder state is dropped  */
+    int32_t max_buffered_frames;            /* per-channel cap on queued input frames and on un-popped output frames */
+    mmi_sampling sampling;                  /* LMGen constructor arguments (lm.py:557-574)                          */
+} mmi_batcher_cfg;
+
+typedef struct mmi_batcher_stats {
+    int64_t steps;            /* model steps run (iterations that had at least one row with data)          */
+    int64_t frames;           /* session-frames executed (sum of active rows over steps)                   */
+    int64_t dropped_frames;   /* output frames dropped because a channel's output FIFO was full            */
+    int32_t used_slots, total_slots;
+    float last_step_ms;       /* device time of the last step (hipEvents on the batcher's stream)          */
+} mmi_batcher_stats;
+
+typedef struct mmi_batcher mmi_batcher;
+
+/* Puts both models into streaming mode with batch = cfg->slots (streaming_forever, server.py:59-60).  The handles must
+ * outlive the batcher and must not be driven by anyone else meanwhile. */
+int mmi_batcher_create(mmi_mimi* mimi, mmi_lm* lm, const mmi_batcher_cfg* cfg, mmi_batcher** out);
+void mmi_batcher_destroy(mmi_batcher* b);
+/* Claim a free slot (py_module.rs:443-470); MMI_ERR_BUSY when all are taken.  The row's streaming state is reset at
+ * the next step (handle_chat: mimi.reset_streaming(); lm_gen.reset_streaming(), server.py:163-164). */
+int mmi_batcher_open(mmi_batcher* b, int64_t* channel_id);
+int mmi_batcher_close(mmi_batcher* b, int64_t channel_id);
+/* Append 24 kHz mono PCM (host f32) to the channel's FIFO (batched_asr.rs:77-90 extend_data). */
+int mmi_batcher_push_pcm(mmi_batcher* b, int64_t channel_id, const float* pcm, int32_t n_samples);
+/* One iteration of the model loop.  n_active (host) = rows that had a frame; 0 means nothing was run. */
+int mmi_batcher_step(mmi_batcher* b, int32_t* n_active);
+/* Next un-popped output frame of a channel: pcm f32[frame_size], tokens i64[1 + dep_q] (text, audio...), got = 0/1.
+ * Frames produced while the LM's delay ring was still filling (tokens -2, lm.py:781-782) are never queued, exactly
+ * like the reference server skips `None` (server.py:144-146). */
+int mmi_batcher_pop(mmi_batcher* b, int64_t channel_id, float* pcm, int64_t* tokens, int32_t* got);
+int mmi_batcher_get_stats(mmi_batcher* b, mmi_batcher_stats* out);
 
 #ifdef __cplusplus
 }

@@ -15,8 +15,8 @@ import torch
 _PKG = Path(__file__).resolve().parent
 DEFAULT_LIB = _PKG / "libmoshi_mi.so"
 
-MMI_OK, MMI_ERR_INVALID, MMI_ERR_SHAPE, MMI_ERR_STATE, MMI_ERR_HIP, MMI_ERR_MISSING_WEIGHT, MMI_ERR_UNSUPPORTED = \
-    0, -1, -2, -3, -4, -5, -6
+MMI_OK, MMI_ERR_INVALID, MMI_ERR_SHAPE, MMI_ERR_STATE, MMI_ERR_HIP, MMI_ERR_MISSING_WEIGHT, MMI_ERR_UNSUPPORTED, MMI_ERR_BUSY = \
+    0, -1, -2, -3, -4, -5, -6, -7
 MMI_F32, MMI_BF16, MMI_I64, MMI_F16, MMI_I8 = 0, 1, 2, 3, 4
 
 _DTYPES = {torch.float32: MMI_F32, torch.bfloat16: MMI_BF16, torch.int64: MMI_I64, torch.float16: MMI_F16,
@@ -53,6 +53,16 @@ class Sampling(C.Structure):
                 ("top_k_text", C.c_int32), ("seed", C.c_uint64)]
 
 
+class BatcherCfg(C.Structure):
+    _fields_ = [("slots", C.c_int32), ("reset_codec_after_first_frame", C.c_int32), ("max_buffered_frames", C.c_int32),
+                ("sampling", Sampling)]
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("frames", C.c_int64), ("dropped_frames", C.c_int64), ("used_slots", C.c_int32),
+                ("total_slots", C.c_int32), ("last_step_ms", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/moshi_mi.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -79,6 +89,16 @@ SIGNATURES = {
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),
     "mmi_lm_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     "mmi_lm_force_next_tokens": (C.c_int, [_P, _P, _P]),
+    "mmi_mimi_get_cfg": (C.c_int, [_P, C.POINTER(MimiCfg)]),
+    "mmi_lm_get_cfg": (C.c_int, [_P, C.POINTER(LMCfg)]),
+    "mmi_batcher_create": (C.c_int, [_P, _P, C.POINTER(BatcherCfg), C.POINTER(_P)]),
+    "mmi_batcher_destroy": (None, [_P]),
+    "mmi_batcher_open": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "mmi_batcher_close": (C.c_int, [_P, C.c_int64]),
+    "mmi_batcher_push_pcm": (C.c_int, [_P, C.c_int64, _P, C.c_int32]),
+    "mmi_batcher_step": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "mmi_batcher_pop": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]),
+    "mmi_batcher_get_stats": (C.c_int, [_P, C.POINTER(BatcherStats)]),
     "mmi_lm_profile_begin": (C.c_int, [_P]),
     "mmi_lm_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_char_p)]),
@@ -113,6 +133,8 @@ class Lib:
             raise ValueError(msg)
         if rc == MMI_ERR_MISSING_WEIGHT:
             raise KeyError(msg)
+        if rc == MMI_ERR_BUSY:
+            raise BufferError(msg)
         raise RuntimeError(msg)
 
 

@@ -639,6 +639,12 @@ extern "C" void mmi_lm_destroy(mmi_lm* lm) {
     delete lm;
 }
 
+extern "C" int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out) {
+    if (!lm || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    *out = lm->cfg;
+    return MMI_OK;
+}
+
 extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream) {
     if (!lm || !sampling) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (lm->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");

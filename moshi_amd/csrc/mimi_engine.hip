@@ -878,6 +878,12 @@ extern "C" int mmi_mimi_set_num_codebooks(mmi_mimi* m, int32_t n) {
 
 extern "C" int mmi_mimi_num_codebooks(const mmi_mimi* m) { return m ? m->n_codebooks : 0; }
 
+extern "C" int mmi_mimi_get_cfg(const mmi_mimi* m, mmi_mimi_cfg* out) {
+    if (!m || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    *out = m->cfg;
+    return MMI_OK;
+}
+
 extern "C" int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream stream) {
     if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (m->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");  // streaming.py:113

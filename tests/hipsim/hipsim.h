@@ -55,6 +55,8 @@ enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureMode
 
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
