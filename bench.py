@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="sessions per GPU (BASELINE.json configs[3]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger", type=int, default=8, help="frames between session starts (SURVEY.md 8d C4)")
-    ap.add_argument("--quant", default="none", choices=["none", "q8"], help="q8: row-wise int8 linears (BASELINE configs[4] weight format)")
+    ap.add_argument("--quant", default="none", choices=["none", "q8", "fp8"],
+                    help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears widened to bf16 in registers; fp8 = e4m3 linears on the fp8 MFMA")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
     return ap.parse_args()
 
@@ -190,12 +191,12 @@ def main():
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("bf16" if args.quant == "none" else "bf16 x int8 weights") if workload != "mimi" else "f32", "data": "synthetic",
+        "dtype": {"none": "bf16", "q8": "bf16 x int8 weights", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
                                 "lm": "Moshi-7B LMGen.step (BASELINE configs[2])"}[workload],
                    "sessions_per_gpu": B, "parallelism": f"dp{world} (independent sessions, no collective)",
-                   "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model" + ("" if args.quant == "none" else ", LM linears row-wise int8"),
+                   "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model" + {"none": "", "q8": ", LM linears row-wise int8", "fp8": ", LM linears row-wise e4m3"}[args.quant],
                    "sampling": "temp .8/.7 top-k 250/25 (LMGen defaults), on-device RNG",
                    "session_stagger_frames": args.stagger if lm_gen is not None else 0,
                    "kv_positions_at_end": ([args.stagger * b + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},

@@ -33,10 +33,12 @@ def make_lm(dev, B, args):
     if args.lm_layers:
         cfg.num_layers = args.lm_layers
     sd = replicated_state_dict(lambda: random_lm_state_dict(cfg, seed=4242, device=dev), lm_state_spec(cfg), torch.bfloat16, dev)
-    if getattr(args, "quant", "none") == "q8":                  # quantise tensor by tensor (frees the bf16 copy as it goes)
-        from moshi_amd.weights import is_lm_linear_weight, quantize_lm_state_dict
+    quant = getattr(args, "quant", "none")
+    if quant in ("q8", "fp8"):                                  # quantise tensor by tensor (frees the bf16 copy as it goes)
+        from moshi_amd.weights import is_lm_linear_weight, quantize_lm_state_dict, quantize_lm_state_dict_fp8
+        fn = quantize_lm_state_dict if quant == "q8" else quantize_lm_state_dict_fp8
         for k in [k for k in sd if is_lm_linear_weight(k)]:
-            sd.update(quantize_lm_state_dict({k: sd.pop(k)}))
+            sd.update(fn({k: sd.pop(k)}))
     lm = LMModel(sd, cfg, device=dev, max_batch=B)
     del sd
     torch.cuda.empty_cache()

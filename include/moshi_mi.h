@@ -44,7 +44,7 @@ typedef enum mmi_status {
     MMI_ERR_BUSY = -7            /* batcher: no free slot / a channel's buffer is full                    */
 } mmi_status;
 
-typedef enum mmi_dtype { MMI_F32 = 0, MMI_BF16 = 1, MMI_I64 = 2, MMI_F16 = 3, MMI_I8 = 4 } mmi_dtype;
+typedef enum mmi_dtype { MMI_F32 = 0, MMI_BF16 = 1, MMI_I64 = 2, MMI_F16 = 3, MMI_I8 = 4, MMI_F8E4M3 = 5 /* OCP e4m3fn */ } mmi_dtype;
 
 typedef void* mmi_stream; /* hipStream_t */
 
@@ -179,7 +179,10 @@ typedef struct mmi_lm mmi_lm;
 
 /* loaders.get_moshi_lm (loaders.py:366-446): build LMModel from state-dict tensors - bf16, or with the linears in the
  * reference's quantised storage (utils/quantize.py:13-22): `<linear>.weight` MMI_I8 [out,in] row-wise absmax codes plus
- * `<linear>.weight_scb` MMI_F32 [out] row absmax; embeddings and norms stay bf16.  The linears must be all bf16 or all int8. */
+ * `<linear>.weight_scb` MMI_F32 [out] row absmax; or as fp8 (BASELINE configs[4], run on the fp8 MFMA): `<linear>.weight`
+ * MMI_F8E4M3 [out,in] codes, `<linear>.weight_scale` MMI_F32 [out] (W ~= code * scale) and an optional scalar
+ * `<linear>.input_scale` MMI_F32 (static activation scale: x8 = e4m3(x / input_scale), default 1).  Embeddings and norms
+ * stay bf16.  The linears must be all bf16, all int8 or all fp8. */
 int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weights, int32_t n_weights,
                   int32_t max_batch, mmi_lm** out);
 void mmi_lm_destroy(mmi_lm* lm);

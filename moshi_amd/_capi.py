@@ -17,10 +17,10 @@ DEFAULT_LIB = _PKG / "libmoshi_mi.so"
 
 MMI_OK, MMI_ERR_INVALID, MMI_ERR_SHAPE, MMI_ERR_STATE, MMI_ERR_HIP, MMI_ERR_MISSING_WEIGHT, MMI_ERR_UNSUPPORTED, MMI_ERR_BUSY = \
     0, -1, -2, -3, -4, -5, -6, -7
-MMI_F32, MMI_BF16, MMI_I64, MMI_F16, MMI_I8 = 0, 1, 2, 3, 4
+MMI_F32, MMI_BF16, MMI_I64, MMI_F16, MMI_I8, MMI_F8E4M3 = 0, 1, 2, 3, 4, 5
 
 _DTYPES = {torch.float32: MMI_F32, torch.bfloat16: MMI_BF16, torch.int64: MMI_I64, torch.float16: MMI_F16,
-           torch.int8: MMI_I8}
+           torch.int8: MMI_I8, torch.float8_e4m3fn: MMI_F8E4M3}
 
 
 class TensorDesc(C.Structure):

@@ -12,7 +12,9 @@ namespace {
 struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
     int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
-    float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; KSTEPS then counts k-step PAIRS
+    float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; fp8: weight_scale * input_scale; KSTEPS then counts k-step PAIRS
+    int wq = 0;               // 0 bf16, 1 int8, 2 fp8
+    float xinv = 1.f;         // fp8: 1 / input_scale
     size_t bytes = 0;
 };
 
@@ -34,7 +36,8 @@ struct mmi_lm {
     mmi_lm_cfg cfg;
     int max_batch = 0;
     int T = 32;                     // MFMA tile of the whole model: 16 when max_batch <= 16, else 32 (lm_kernels.h)
-    int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py)
+    int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py),
+                                    // 2 fp8 linears (`weight` e4m3fn + `weight_scale` [+ `input_scale`]) run on the fp8 MFMA
     int NC = 0, CT = 0, max_delay = 0;
     MmiArena wts;
     // weights
@@ -103,9 +106,9 @@ int need(const MmiWeights& W, const std::string& name, int ndim, const mmi_tenso
 }
 
 // nn.Linear weight [N][K] -> packed; gate_hidden > 0: [2*hidden][K] gate|value matrix
-__global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict__ scale, int n) {
+__global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict__ scale, int n, float mul, float div) {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < n) scale[i] = scb[i] / 127.0f;
+    if (i < n) scale[i] = scb[i] * mul / div;
 }
 
 // wp_dst / scale_dst: pack into a slice of a caller-owned allocation instead of a fresh one (see load_dep_in_group)
@@ -113,10 +116,11 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
                 void* wp_dst = nullptr, float* scale_dst = nullptr) {
     const mmi_tensor_desc* d = W.find(name);
     if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
-    if (d->dtype != MMI_BF16 && d->dtype != MMI_I8) return mmi_fail(MMI_ERR_UNSUPPORTED, "LM linear weights must be bf16 or int8: " + name);
+    if (d->dtype != MMI_BF16 && d->dtype != MMI_I8 && d->dtype != MMI_F8E4M3)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "LM linear weights must be bf16, int8 or fp8 (e4m3fn): " + name);
     if (d->ndim != 2) return mmi_fail(MMI_ERR_SHAPE, "unexpected rank for " + name);
-    const int q8 = d->dtype == MMI_I8 ? 1 : 0;
-    if (lm->q8 >= 0 && lm->q8 != q8) return mmi_fail(MMI_ERR_UNSUPPORTED, "mixed bf16 / int8 linear weights: " + name);
+    const int q8 = d->dtype == MMI_I8 ? 1 : (d->dtype == MMI_F8E4M3 ? 2 : 0);
+    if (lm->q8 >= 0 && lm->q8 != q8) return mmi_fail(MMI_ERR_UNSUPPORTED, "mixed bf16 / int8 / fp8 linear weights: " + name);
     lm->q8 = q8;
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
@@ -138,9 +142,23 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
                    TN, g->NT, g->KSTEPS, gate_hidden);
     } else {
-        const mmi_tensor_desc* sc = W.find(name + "_scb");
-        if (!sc) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name + "_scb");
-        if (sc->dtype != MMI_F32 || sc->shape[0] != N) return mmi_fail(MMI_ERR_SHAPE, "weight_scb must be fp32 [out_features]: " + name);
+        // int8: `<linear>.weight_scb` = row absmax (utils/quantize.py:20-22).  fp8: `<linear>.weight_scale` = dequantisation
+        // factor per row, and an optional scalar `<linear>.input_scale` (static activation scale, default 1)
+        const std::string stem = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0 ? name.substr(0, name.size() - 7) : name;
+        const std::string sname = q8 == 1 ? name + "_scb" : name + "_scale";
+        const mmi_tensor_desc* sc = W.find(sname);
+        if (!sc) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + sname);
+        if (sc->dtype != MMI_F32 || sc->shape[0] != N) return mmi_fail(MMI_ERR_SHAPE, "row scales must be fp32 [out_features]: " + sname);
+        float in_scale = 1.f;
+        if (q8 == 2) {
+            if (const mmi_tensor_desc* is = W.find(stem + ".input_scale")) {
+                if (is->dtype != MMI_F32) return mmi_fail(MMI_ERR_SHAPE, "input_scale must be fp32: " + stem);
+                MMI_HIP_CHECK(hipMemcpy(&in_scale, is->data, sizeof(float), hipMemcpyDeviceToHost));
+                if (!(in_scale > 0.f)) return mmi_fail(MMI_ERR_INVALID, "input_scale must be positive: " + stem);
+            }
+        }
+        g->wq = q8;
+        g->xinv = 1.f / in_scale;
         g->KSTEPS = mmi_cdiv(ksteps, 2);                       // pairs of k-steps
         size_t n = (size_t)g->NT * g->KSTEPS * 1024;
         int8_t* p = reinterpret_cast<int8_t*>(wp_dst);
@@ -151,7 +169,8 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         g->bytes = n + (size_t)N * sizeof(float);
         MMI_LAUNCH(k_pack_w_i8, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const int8_t*)d->data, p, N, K, TN,
                    g->NT, g->KSTEPS, gate_hidden);
-        MMI_LAUNCH(k_scb_to_scale, mmi_cdiv(N, 256), 256, 0, (hipStream_t)0, (const float*)sc->data, g->scale, N);
+        MMI_LAUNCH(k_scb_to_scale, mmi_cdiv(N, 256), 256, 0, (hipStream_t)0, (const float*)sc->data, g->scale, N,
+                   q8 == 1 ? 1.f : in_scale, q8 == 1 ? 127.f : 1.f);
     }
     lm->weight_bytes += g->bytes;
     MMI_CHECK_LAUNCH();
@@ -200,18 +219,22 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     return p;
 }
 
-template <int TN, int MT, int NTW>
-int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, bool w8, const GemmArgs& a) {
-    if (w8) {
-        if constexpr (MT * NTW <= 2) {
-            if (waves == 8) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2, true>), groups, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, true>), groups, 256, 0, s, a);
-        } else {
-            MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, true>), groups, 256, 0, s, a);
-        }
-        MMI_CHECK_LAUNCH();
-        return MMI_OK;
+template <int TN, int MT, int NTW, int WQ>
+int launch_gemm_q(hipStream_t s, dim3 groups, int waves, const GemmArgs& a) {
+    if constexpr (MT * NTW <= 2) {
+        if (waves == 8) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2, WQ>), groups, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, WQ>), groups, 256, 0, s, a);
+    } else {
+        MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 4, 2, WQ>), groups, 256, 0, s, a);
     }
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+template <int TN, int MT, int NTW>
+int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, int wq, const GemmArgs& a) {
+    if (wq == 1) return launch_gemm_q<TN, MT, NTW, 1>(s, groups, waves, a);
+    if (wq == 2) return launch_gemm_q<TN, MT, NTW, 2>(s, groups, waves, a);
     if (waves == 8 && u == 2 && MT * NTW == 1) {
         if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
         MMI_CHECK_LAUNCH();
@@ -231,7 +254,7 @@ int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, bool w8, const G
 template <int TN>
 int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
     const dim3 groups(mmi_cdiv(NT, p.ntw), p.ksplit);
-    const bool w8 = a.wscale != nullptr;
+    const int w8 = a.wq;
     if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, w8, a);
     if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, w8, a);
     if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, w8, a);
@@ -242,6 +265,7 @@ int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmAr
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wq = g.wq; a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     EvPair* ev = nullptr;
@@ -267,7 +291,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
 // carry k-step pairs, and the padding k-step reads as zero)
 int packed_ksteps(const mmi_lm* lm, int features) {
     const int ks = mmi_cdiv(features, mmi_kstep(lm->T));
-    return lm->q8 == 1 ? 2 * mmi_cdiv(ks, 2) : ks;
+    return lm->q8 >= 1 ? 2 * mmi_cdiv(ks, 2) : ks;
 }
 size_t packed_elems(const mmi_lm* lm, int features) {
     return (size_t)mmi_cdiv(lm->batch, lm->T) * packed_ksteps(lm, features) * 512;
@@ -321,8 +345,8 @@ void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, ui
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
                    int out_features, bool out_packed, int epi) {
-    const bool w8 = g.scale != nullptr;
-    const bool fuse = g.KSTEPS <= (w8 ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
+    const int wq = g.wq;
+    const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
         add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr);
@@ -337,12 +361,17 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.alpha = alpha; a.D = D; a.eps = 1e-8f;
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wq = g.wq; a.xinv = g.xinv;
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT;
     lm->prog.add([=](hipStream_t s) {
-        if (w8) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, true>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, true>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, true>), NT, 512, 0, s, a);
+        if (wq == 1) {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
+        } else if (wq == 2) {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 2>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 2>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 2>), NT, 512, 0, s, a);
         } else {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
@@ -587,9 +616,9 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
         size_t per = 0;
         if (group) {
             const int NT = dd / lm->T, ksteps = mmi_cdiv(d, mmi_kstep(lm->T));
-            per = lm->q8 == 1 ? (size_t)NT * mmi_cdiv(ksteps, 2) * 1024 : (size_t)NT * ksteps * 512 * sizeof(uint16_t);
+            per = lm->q8 >= 1 ? (size_t)NT * mmi_cdiv(ksteps, 2) * 1024 : (size_t)NT * ksteps * 512 * sizeof(uint16_t);
             if (lm->wts.alloc(&wp_all, per * c.dep_q) != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in)"));
-            if (lm->q8 == 1 && lm->wts.alloc(&scale_all, (size_t)dd * c.dep_q) != hipSuccess)
+            if (lm->q8 >= 1 && lm->wts.alloc(&scale_all, (size_t)dd * c.dep_q) != hipSuccess)
                 return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in scales)"));
         }
         for (int k = 0; k < c.dep_q; ++k) {
@@ -597,6 +626,9 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
                                   group ? wp_all + per * k : nullptr, scale_all ? scale_all + (size_t)dd * k : nullptr)))
                 return fail(rc);
         }
+        for (int k = 1; group && k < c.dep_q; ++k)
+            if (lm->dep_in[k].xinv != lm->dep_in[0].xinv)
+                return fail(mmi_fail(MMI_ERR_UNSUPPORTED, "the depformer_in linears read the same tensor and must share one input_scale"));
         if (group) {
             lm->dep_in_all = lm->dep_in[0];
             lm->dep_in_all.N = dd * c.dep_q;

@@ -112,6 +112,25 @@ __device__ __forceinline__ void mmi_i8x16_to_bf16(u32x4 q, u32x4& lo, u32x4& hi)
     }
 }
 
+// fp8 linears (BASELINE configs[4]: fp8 MFMA GEMMs): `weight` e4m3fn codes + `weight_scale` fp32 per output row (W ~= code *
+// scale), packed exactly like the int8 bytes (two k-steps per 16-byte lane entry).  The activations stay bf16 in HBM and are
+// converted to e4m3 in registers on their way into v_mfma_f32_{32x32x16,16x16x32}_fp8_fp8: x8 = e4m3(x / input_scale) with a
+// static per-linear `input_scale` (a calibration constant, default 1), and the fp32 accumulator is scaled by
+// weight_scale[row] * input_scale in the epilogue (folded into one per-row factor at load).
+// 8 bf16 (one activation fragment) -> 8 fp8 bytes
+__device__ __forceinline__ u32x2 mmi_bf16x8_to_fp8(u32x4 x, float inv) {
+    float f[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[2 * q] = __builtin_bit_cast(float, x[q] << 16) * inv;
+        f[2 * q + 1] = __builtin_bit_cast(float, x[q] & 0xffff0000u) * inv;
+    }
+    u32x2 r;
+    r[0] = mmi_cvt_fp8x4(f[0], f[1], f[2], f[3]);
+    r[1] = mmi_cvt_fp8x4(f[4], f[5], f[6], f[7]);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
 // ------------------------------------------------------------------------------------------------
@@ -135,7 +154,9 @@ struct GemmArgs {
     int B, N, KSTEPS, NT;
     int out_mode, out_ld, out_ksteps;
     int epi;
-    const float* wscale;    // int8 weights: SCB / 127 per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
+    const float* wscale;    // int8 / fp8 weights: dequantisation factor per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
+    float xinv;             // fp8: 1 / input_scale, applied to the activations before the e4m3 conversion
+    int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights
     int gate_rows;          // H of a gated linear_in (value row of feature n is H + n)
     float* partial;         // EPI_PARTIAL: fp32 partial sums [gridDim.y][B][N] (K split over gridDim.y workgroups so that
                             // GEMMs with few n-tiles still cover every CU); summed by k_resid_rmsnorm
@@ -337,12 +358,13 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
     }
 }
 
-// W8: int8 weights - one 16-byte weight entry carries two k-steps, so the loop runs over k-step PAIRS (a.KSTEPS then
-// counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
-template <int TN, int MT, int NTW, int WAVES, int U, bool W8 = false>
+// WQ = 1 (int8) / 2 (fp8) weights: one 16-byte weight entry carries two k-steps, so the loop runs over k-step PAIRS
+// (a.KSTEPS then counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
+template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
+    constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
-    constexpr int XS = W8 ? 2 : 1;                // activation fragments per weight entry
+    constexpr int XS = WQ ? 2 : 1;                // activation fragments per weight entry
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int nt0 = (int)blockIdx.x * NTW;
@@ -380,8 +402,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #define MMI_G_MFMA(WF, XF, ACC)                                                               \
     if constexpr (TN == 32) ACC = mmi_mfma_bf16_32x32x16(WF, XF, ACC);                        \
     else ACC = mmi_mfma_bf16_16x16x32(WF, XF, ACC);
+#define MMI_G_MFMA8(WF, XF, ACC)                                                              \
+    if constexpr (TN == 32) ACC = mmi_mfma_fp8_32x32x16(WF, XF, ACC);                         \
+    else ACC = mmi_mfma_fp8_16x16x32(WF, XF, ACC);
+#define MMI_G_MMA8(W_, X_, u)                                                                 \
+    {                                                                                         \
+        u32x2 xq_[MT][2];                                                                     \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
+            xq_[m][0] = mmi_bf16x8_to_fp8(X_[u][m][0], a.xinv);                               \
+            xq_[m][1] = mmi_bf16x8_to_fp8(X_[u][m][XS - 1], a.xinv);                          \
+        }                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                     \
+            const u32x2 w0_ = {W_[u][t][0], W_[u][t][1]}, w1_ = {W_[u][t][2], W_[u][t][3]};   \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
+                MMI_G_MFMA8(w0_, xq_[m][0], acc[t][m])                                        \
+                MMI_G_MFMA8(w1_, xq_[m][1], acc[t][m])                                        \
+            }                                                                                 \
+        }                                                                                     \
+    }
 #define MMI_G_MMA(W_, X_)                                                                     \
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+        if constexpr (WQ == 2) MMI_G_MMA8(W_, X_, u)                                          \
+        else {                                                                                \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                     \
             if constexpr (W8) {                                                               \
                 u32x4 wlo_, whi_;                                                             \
@@ -393,6 +435,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
             } else {                                                                          \
                 _Pragma("unroll") for (int m = 0; m < MT; ++m) { MMI_G_MFMA(W_[u][t], X_[u][m][0], acc[t][m]) } \
             }                                                                                 \
+        }                                                                                     \
         }
     const int nfull = nks / U;
     if (nfull > 0) {
@@ -421,6 +464,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int x = 0; x < XS; ++x) xA[0][m][x] = xp[m][(ks * XS + x) * 64];
+        if constexpr (WQ == 2) MMI_G_MMA8(wA, xA, 0)
+        else {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             if constexpr (W8) {
@@ -436,10 +481,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
                 for (int m = 0; m < MT; ++m) { MMI_G_MFMA(wA[0][t], xA[0][m][0], acc[t][m]) }
             }
         }
+        }
     }
 #undef MMI_G_LOAD
 #undef MMI_G_MMA
+#undef MMI_G_MMA8
 #undef MMI_G_MFMA
+#undef MMI_G_MFMA8
     float accv[NTW][MT][R];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -455,12 +503,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // out = y @ W^T.  A wave's whole K-slice of activation and weight fragments (<= KMAX k-steps) is loaded in one go -
 // everything in flight at once, these GEMMs are latency bound - the waves combine their sums of squares through
 // LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
-// W8: int8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
-template <int TN, int MT, int WAVES, int KMAX, bool W8 = false>
+// WQ = 1 / 2: int8 / fp8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
+template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
+    constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
-    constexpr int XS = W8 ? 2 : 1;
+    constexpr int XS = WQ ? 2 : 1;
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -536,6 +585,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
         u32x4 wf[XS];
         if constexpr (W8) mmi_i8x16_to_bf16(wv[u], wf[0], wf[XS - 1]);
         else wf[0] = wv[u];
+        const u32x2 w8f[2] = {{wv[u][0], wv[u][1]}, {wv[u][2], wv[u][3]}};   // fp8: the two k-steps of the entry
 #pragma unroll
         for (int x = 0; x < XS; ++x) {
 #pragma unroll
@@ -549,7 +599,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
                     const float alo = mmi_bf16_to_f32((uint16_t)(ar[q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(ar[q] >> 16));
                     xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
                 }
-                if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wf[x], xn, acc[m]);
+                if constexpr (WQ == 2) {        // the norm output is a bf16 tensor; it is that tensor the linear quantises
+                    const u32x2 x8 = mmi_bf16x8_to_fp8(xn, a.xinv);
+                    if constexpr (TN == 32) acc[m] = mmi_mfma_fp8_32x32x16(w8f[x], x8, acc[m]);
+                    else acc[m] = mmi_mfma_fp8_16x16x32(w8f[x], x8, acc[m]);
+                } else if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wf[x], xn, acc[m]);
                 else acc[m] = mmi_mfma_bf16_16x16x32(wf[x], xn, acc[m]);
             }
         }

@@ -69,6 +69,28 @@ __device__ __forceinline__ f32x4 mmi_mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 
                                                    __builtin_bit_cast(mmi_bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- fp8 (OCP e4m3fn on gfx950: 4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinity) -----------------------
+// four fp32 -> four fp8 bytes (byte i = value i), round-to-nearest-even, clamped to +-448 first so that the result does not
+// depend on the conversion's overflow mode
+__device__ __forceinline__ uint32_t mmi_cvt_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+    b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+    d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+// D(32x32) += A(32x16) * B(16x32), fp8 in / fp32 acc.  Same element map as the bf16 32x32x16 form with one byte per
+// element: lane l: a[e] = A[l&31][8*(l>>5)+e], b[e] = B[8*(l>>5)+e][l&31] (8 bytes per operand per lane).
+__device__ __forceinline__ f32x16 mmi_mfma_fp8_32x32x16(u32x2 a, u32x2 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+}
+// D(16x16) += A(16x32) * B(32x16): lane l: a[e] = A[l&15][8*(l>>4)+e], b[e] = B[8*(l>>4)+e][l&15].
+__device__ __forceinline__ f32x4 mmi_mfma_fp8_16x16x32(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+}
+
 // streamed-once weights: non-temporal so they do not evict the activations / KV the other kernels reuse
 __device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_nontemporal_load(p); }

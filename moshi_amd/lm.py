@@ -48,13 +48,14 @@ class LMModel:
         config: architecture hyper-parameters (defaults = Moshi-7B, loaders.py:90-119).
         device: a ROCm `cuda` device for the product library.
         max_batch: largest number of concurrent sessions `LMGen.streaming` will be asked for.
-        quantize: convert the linears to row-wise int8 (`weight` + `weight_scb`), like the reference's `quantize=True`;
-            a state dict that already carries int8 weights is used as is.
+        quantize: True converts the linears to row-wise int8 (`weight` + `weight_scb`), like the reference's `quantize=True`;
+            "fp8" converts them to e4m3fn (`weight` + `weight_scale`) for the fp8 MFMA path (BASELINE configs[4]);
+            a state dict that already carries int8 / fp8 weights is used as is.
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[LMConfig] = None,
                  device: torch.device | str = "cuda", max_batch: int = 32, lib: Optional[_capi.Lib] = None,
-                 quantize: bool = False):
+                 quantize: bool | str = False):
         self.config = config or LMConfig()
         self.device = torch.device(device)
         if lib is None:
@@ -63,16 +64,19 @@ class LMModel:
             lib = _capi.load()
         self._lib = lib
         self._handle = C.c_void_p()
-        from .weights import normalize_lm_state_dict, quantize_lm_state_dict
+        from .weights import normalize_lm_state_dict, quantize_lm_state_dict, quantize_lm_state_dict_fp8
         state_dict = normalize_lm_state_dict(state_dict, self.config)     # fused multi-step projections of released checkpoints
-        if quantize:                                                      # the reference's `quantize=True` (lm.py:242-243)
+        if quantize == "fp8":
+            state_dict = quantize_lm_state_dict_fp8(state_dict)
+        elif quantize:                                                    # the reference's `quantize=True` (lm.py:242-243)
             state_dict = quantize_lm_state_dict(state_dict)
-        self.quantized = any(v.dtype == torch.int8 for v in state_dict.values())
+        self.quantized = any(v.dtype in (torch.int8, torch.float8_e4m3fn) for v in state_dict.values())
 
-        def place(k, v):     # int8 weights and their fp32 row scales keep their dtype (utils/quantize.py:29-34); the rest is bf16
-            if v.dtype == torch.int8:
+        def place(k, v):     # quantised weights and their fp32 scales keep their dtype (utils/quantize.py:29-34); the rest is bf16
+            if v.dtype in (torch.int8, torch.float8_e4m3fn):
                 return v.detach().to(self.device)
-            return v.detach().to(device=self.device, dtype=torch.float32 if k.endswith("_scb") else torch.bfloat16)
+            scale = k.endswith("_scb") or k.endswith(".weight_scale") or k.endswith(".input_scale")
+            return v.detach().to(device=self.device, dtype=torch.float32 if scale else torch.bfloat16)
         sd = {k: place(k, v) for k, v in state_dict.items()}
         descs, keep = _capi.tensor_descs(sd)
         cfg = _lm_cfg_struct(self.config)

@@ -227,6 +227,28 @@ def is_lm_linear_weight(key: str) -> bool:
             or key == "text_linear.weight")
 
 
+E4M3_MAX = 448.0
+
+
+def quantize_lm_state_dict_fp8(sd: Dict[str, torch.Tensor], input_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """fp8 linears for the fp8 MFMA path (BASELINE.json configs[4]): per-output-row scaling, `weight` =
+    e4m3fn(W / weight_scale) with weight_scale = absmax_row / 448 (fp32, `<key>_scale`), and a static scalar activation
+    scale `<linear>.input_scale` (a calibration constant; powers of two cost no precision).  W ~= weight * weight_scale."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, w in sd.items():
+        if not is_lm_linear_weight(key) or w.dtype == torch.float8_e4m3fn:
+            out[key] = w
+            continue
+        wf = w.detach().float()
+        absmax = wf.abs().amax(dim=1)
+        scale = torch.where(absmax > 0, absmax / E4M3_MAX, torch.ones_like(absmax))
+        out[key] = (wf / scale[:, None]).clamp_(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn)
+        out[key + "_scale"] = scale.to(torch.float32)
+        if input_scale != 1.0:
+            out[key[: -len(".weight")] + ".input_scale"] = torch.tensor([input_scale], dtype=torch.float32)
+    return out
+
+
 def quantize_lm_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Row-wise absmax int8, as `QLinear.__init__` does it: the weight goes to fp16, `CB = round(W * 127 / absmax_row)`
     (int8) is stored under the weight's key and `SCB = absmax_row` (fp32) under `<key>_scb` (utils/quantize.py:17-22;

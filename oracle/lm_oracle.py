@@ -53,8 +53,38 @@ class QWeight:
         return w
 
 
+def e4m3r(x: np.ndarray) -> np.ndarray:
+    """Round fp32 values to the nearest OCP e4m3fn value (ties to even), saturating at +-448, returned as fp32: 3 mantissa
+    bits for |x| >= 2^-6, a fixed grid of 2^-9 below."""
+    x = np.ascontiguousarray(x, dtype=f32)
+    a = np.minimum(np.abs(x), f32(448.0))
+    m, e = np.frexp(a)                                   # a = m * 2^e, m in [0.5, 1)
+    step = np.where(a < f32(2.0 ** -6), f32(2.0 ** -9), np.ldexp(f32(1.0), e - 4)).astype(f32)
+    return (np.sign(x) * np.round(a / step) * step).astype(f32)     # np.round: half to even
+
+
+class F8Weight:
+    """fp8 linear of the fp8-MFMA path: W ~= code * weight_scale, activations quantised to e4m3 after dividing by the static
+    `input_scale`; products accumulate in fp32 (the MFMA's accumulator)."""
+
+    def __init__(self, codes: np.ndarray, scale: np.ndarray, input_scale: float = 1.0):
+        self.q = codes.astype(f32)
+        self.scale = scale.astype(f32)
+        self.input_scale = f32(input_scale)
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    def rows(self, lo: int, hi: int) -> "F8Weight":
+        return F8Weight(self.q[lo:hi], self.scale[lo:hi], self.input_scale)
+
+
 def linear(x: np.ndarray, w) -> np.ndarray:
     """nn.Linear(bias=False) on bf16 tensors: fp32 accumulate, bf16 result."""
+    if isinstance(w, F8Weight):
+        x8 = e4m3r((x * (f32(1.0) / w.input_scale)).astype(f32))
+        return bf16r(((x8 @ w.q.T).astype(f32) * (w.scale * w.input_scale)[None, :]).astype(f32))
     if isinstance(w, QWeight):
         return bf16r(((x @ w.q.T).astype(f32) * w.scale[None, :]).astype(f32))
     return bf16r((x @ w.T).astype(f32))
@@ -119,6 +149,10 @@ class LMOracle:
         sd = {k: _np(v) for k, v in state_dict.items()}
         for k in [k for k in sd if k.endswith("_scb")]:          # int8 linears: `weight` (int8) + `weight_scb`
             sd[k[:-4]] = QWeight(sd[k[:-4]], sd.pop(k))
+        for k in [k for k in sd if k.endswith(".weight_scale")]:  # fp8 linears: `weight` (e4m3fn) + `weight_scale` [+ `input_scale`]
+            stem = k[: -len(".weight_scale")]
+            ins = sd.pop(stem + ".input_scale", None)
+            sd[stem + ".weight"] = F8Weight(sd[stem + ".weight"], sd.pop(k), 1.0 if ins is None else float(np.asarray(ins).reshape(-1)[0]))
         c = cfg
         self.emb = [sd[f"emb.{i}.weight"] for i in range(c.n_q)]
         self.text_emb = sd["text_emb.weight"]

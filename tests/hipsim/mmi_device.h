@@ -161,6 +161,90 @@ inline f32x4 mmi_mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
     return d;
 }
 
+// ---- fp8 e4m3fn (OCP): software encode (round-to-nearest-even, clamp to +-448) / decode, and the two fp8 MFMA forms ----
+namespace hipsim_detail {
+inline uint8_t f32_to_e4m3(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    float a = fabsf(x);
+    if (!(a == a)) return (uint8_t)(sign | 0x7f);
+    if (a > 448.f) a = 448.f;
+    if (a < 0.015625f) {                               // below 2^-6: subnormal grid of 2^-9
+        const int q = (int)nearbyintf(a * 512.f);      // 0..8, ties to even (default rounding mode); 8 encodes as the first normal
+        return (uint8_t)(sign | q);
+    }
+    int e; const float m = frexpf(a, &e);              // a = m * 2^e, m in [0.5, 1)
+    int q = (int)nearbyintf((m * 2.f - 1.f) * 8.f);    // mantissa of 1.mmm
+    int E = e - 1 + 7;
+    if (q == 8) { q = 0; E += 1; }
+    return (uint8_t)(sign | (E << 3) | q);
+}
+inline float e4m3_to_f32(uint8_t b) {
+    const int E = (b >> 3) & 15, m = b & 7;
+    float v = E == 0 ? ldexpf((float)m, -9) : ldexpf(1.f + (float)m / 8.f, E - 7);
+    if (E == 15 && m == 7) v = NAN;
+    return (b & 0x80) ? -v : v;
+}
+struct OpF8 { uint8_t a[8], b[8]; };
+}  // namespace hipsim_detail
+
+inline uint32_t mmi_cvt_fp8x4(float a, float b, float c, float d) {
+    using namespace hipsim_detail;
+    return (uint32_t)f32_to_e4m3(a) | ((uint32_t)f32_to_e4m3(b) << 8) | ((uint32_t)f32_to_e4m3(c) << 16) | ((uint32_t)f32_to_e4m3(d) << 24);
+}
+
+inline f32x16 mmi_mfma_fp8_32x32x16(u32x2 a, u32x2 b, f32x16 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpF8 me;
+    memcpy(me.a, &a, 8);
+    memcpy(me.b, &b, 8);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x16 d;
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            OpF8 oa, ob;
+            memcpy(&oa, s[i + 32 * (k >> 3)].b, sizeof(oa));
+            memcpy(&ob, s[j + 32 * (k >> 3)].b, sizeof(ob));
+            acc = fmaf(e4m3_to_f32(oa.a[k & 7]), e4m3_to_f32(ob.b[k & 7]), acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
+inline f32x4 mmi_mfma_fp8_16x16x32(u32x2 a, u32x2 b, f32x4 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpF8 me;
+    memcpy(me.a, &a, 8);
+    memcpy(me.b, &b, 8);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    f32x4 d;
+    const int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            OpF8 oa, ob;
+            memcpy(&oa, s[i + 16 * (k >> 3)].b, sizeof(oa));
+            memcpy(&ob, s[j + 16 * (k >> 3)].b, sizeof(ob));
+            acc = fmaf(e4m3_to_f32(oa.a[k & 7]), e4m3_to_f32(ob.b[k & 7]), acc);
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
 inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }

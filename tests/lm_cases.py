@@ -167,9 +167,12 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
             prev_tt, prev_a0 = tt, toks[0]
 
 
-def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False):
+def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0):
     sd = random_lm_state_dict(cfg, seed=seed)
-    if quantize:    # row-wise int8 linears (the reference's `quantize=True` storage); engine and oracle get the same int8 tensors
+    if quantize == "fp8":   # e4m3fn linears on the fp8 MFMA (BASELINE configs[4]); engine and oracle get the same fp8 tensors
+        from moshi_amd.weights import quantize_lm_state_dict_fp8
+        sd = quantize_lm_state_dict_fp8(sd, input_scale=input_scale)
+    elif quantize:  # row-wise int8 linears (the reference's `quantize=True` storage); engine and oracle get the same int8 tensors
         from moshi_amd.weights import quantize_lm_state_dict
         sd = quantize_lm_state_dict(sd)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)

@@ -63,6 +63,47 @@ def test_int8_weights_match_the_int8_oracle(sim_lib, B):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
 
 
+@pytest.mark.parametrize("B,input_scale", [(2, 1.0), (18, 0.25), (34, 1.0)])
+def test_fp8_weights_on_the_fp8_mfma_match_the_fp8_oracle(sim_lib, B, input_scale):
+    """`quantize="fp8"` (BASELINE configs[4]): e4m3fn linears with per-row scales, activations converted to e4m3 in registers,
+    v_mfma_*_fp8_fp8.  Same tolerance as the bf16 path against an oracle that holds the same fp8 tensors and quantises the
+    activations at the same points."""
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=90 + B, B=B, S=3, quantize="fp8", input_scale=input_scale)
+
+
+def test_fp8_without_norm_fusion_and_with_split_k(sim_lib, monkeypatch):
+    monkeypatch.setenv("MMI_NO_NORM_FUSION", "1")
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=97, B=18, S=3, quantize="fp8")
+
+
+def test_e4m3_rounding_of_oracle_matches_torch_float8():
+    """The oracle's e4m3 rounding (what the engine's v_cvt_pk_fp8_f32 does on gfx950: OCP e4m3fn, round-to-nearest-even,
+    saturating) against torch's own float8_e4m3fn cast on every bf16 value in range and on exact ties."""
+    from oracle.lm_oracle import e4m3r
+    bits = np.arange(0, 1 << 16, dtype=np.uint32)
+    x = (bits << 16).astype(np.uint32).view(np.float32)
+    x = x[np.isfinite(x) & (np.abs(x) <= 448.0)]
+    ties = np.array([0.0009765625, 0.0029296875, 0.017578125, 18.0, 22.0, 416.0, 448.0, 464.0, 1e4, -1e4], np.float32)
+    for v in (x, ties):
+        ref = torch.from_numpy(np.clip(v, -448, 448)).to(torch.float8_e4m3fn).float().numpy()
+        assert np.array_equal(e4m3r(v), ref)
+
+
+def test_fp8_quantisation_error_and_storage():
+    from moshi_amd.weights import quantize_lm_state_dict_fp8
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=4)
+    q = quantize_lm_state_dict_fp8(sd, input_scale=0.5)
+    k = "transformer.layers.0.gating.linear_in.weight"
+    assert q[k].dtype == torch.float8_e4m3fn and q[k + "_scale"].shape == (sd[k].shape[0],)
+    assert q["transformer.layers.0.gating.linear_in.input_scale"].item() == 0.5
+    assert q["emb.0.weight"].dtype == torch.bfloat16
+    deq = q[k].float() * q[k + "_scale"][:, None]
+    w = sd[k].float()
+    assert ((deq - w).abs() <= w.abs() / 16 + q[k + "_scale"][:, None] * 2.0 ** -9).all()   # 3 mantissa bits: half a step <= 1/16
+
+
 def test_int8_quantisation_error_is_small_and_storage_is_bnb_style():
     from moshi_amd.weights import quantize_lm_state_dict
     cfg = tiny_lm_config()
