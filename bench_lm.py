@@ -91,6 +91,16 @@ def roofline_lm(lm_gen, step_fn, args, sync):
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "traffic": None, "kernel": kname, "avg_launch_ms": mean_ms.value,
            "launches_timed": n.value, "algorithmic_bytes_per_launch": nbytes.value}
+    # secondary figure (north_star: "achieved MFMA/HBM fraction"): the same launch's matrix-core rate.  The GEMM is
+    # 2 * N * K * B flops with N = 2 * ffn_hidden rows, K = dim, B sessions; dense peaks from MI355X_MICROARCH.md.
+    cfg = lm_gen.lm_model.config
+    flops = 2.0 * (2 * cfg.ffn_hidden) * cfg.dim * lm_gen._batch
+    quant = getattr(args, "quant", "none")
+    mfma_peak = 2500.0                       # TFLOP/s: bf16 MFMA; the non-scaled fp8 MFMA (K=16/32) runs at the bf16 rate
+    tf = flops / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
+    out["mfma"] = {"achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak,
+                   "instruction": "v_mfma_f32_32x32x16_fp8_fp8" if quant == "fp8" else "v_mfma_f32_32x32x16_bf16",
+                   "note": "decode GEMM at B sessions: arithmetic intensity ~B flop/byte, far below the ~310 flop/byte ridge"}
     # HBM bytes per launch from the PMC counters: rocprofv3 --pmc cannot run inside the benchmark (and crashes on this
     # process), so the figure is the committed measurement of the same kernel, shape and batch.
     pmc = Path(__file__).resolve().parent / "profiles" / "pmc_dominant_kernel.json"

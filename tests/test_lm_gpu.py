@@ -54,6 +54,19 @@ def test_int8_full_width_layers_match_oracle(gpu_lib):
     lm_cases.oracle_vs_engine(DEV, None, cfg, seed=9, B=3, S=3, use_masks=True, quantize=True)
 
 
+@pytest.mark.parametrize("B,input_scale", [(2, 1.0), (18, 0.25), (40, 1.0)])
+def test_fp8_weights_on_the_fp8_mfma_match_the_fp8_oracle(gpu_lib, B, input_scale):
+    """BASELINE configs[4]'s fp8 MFMA GEMMs (`quantize="fp8"`) on the tiny model, all three batch tilings: the hardware's
+    v_cvt_pk_fp8_f32 / v_mfma_*_fp8_fp8 against the oracle's e4m3 rounding (itself pinned on torch's float8_e4m3fn cast)."""
+    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=90 + B, B=B, S=3, quantize="fp8", input_scale=input_scale)
+
+
+def test_fp8_full_width_layers_match_oracle(gpu_lib):
+    """fp8 linears at the 7B layer shapes (2 temporal layers, full depformer), B=3 with masks."""
+    cfg = LMConfig(num_layers=2, context=64)
+    lm_cases.oracle_vs_engine(DEV, None, cfg, seed=10, B=3, S=3, use_masks=True, quantize="fp8")
+
+
 def test_full_width_layers_match_oracle(gpu_lib):
     """Moshi-7B layer shapes (dim 4096, 32 heads x 128, FFN 11264, text head 32000; depformer 1024 x 6 layers x 8 steps)
     with 2 temporal layers, so that the numpy oracle finishes in seconds: exercises every GEMM tile variant,
