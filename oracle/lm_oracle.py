@@ -176,17 +176,48 @@ class LMOracle:
                 w_in=[sd[p + f".gating.{k}.linear_in.weight"] for k in range(c.dep_q)],
                 w_out=[sd[p + f".gating.{k}.linear_out.weight"] for k in range(c.dep_q)]))
         self.linears = [sd[f"linears.{k}.weight"] for k in range(c.dep_q)]
+        self.extra_heads = []                                   # lm.py:224-226
+        while f"extra_heads.{len(self.extra_heads)}.weight" in sd:
+            self.extra_heads.append(sd[f"extra_heads.{len(self.extra_heads)}.weight"])
         self.B = 0
 
     # ---- streaming state (lm.py:605-666; transformer.py:448-486) -----------------------------------
-    def streaming(self, B: int):
+    def streaming(self, B: int, cfg_coef: float = 1.0, cfg_is_no_text: bool = False, cfg_is_masked_until=None,
+                  condition_sum=None):
+        """`condition_sum`: the fuser's summed condition [model rows, dim] (lm.py:621-628); with guidance (cfg_coef != 1) the
+        model runs 2B rows, conditioned half first (lm.py:646-651)."""
         c = self.cfg
+        self.cfg_coef, self.cfg_is_no_text = float(cfg_coef), bool(cfg_is_no_text)
+        self.cfg_is_masked_until = None if cfg_is_masked_until is None else np.asarray(cfg_is_masked_until, np.int64)
+        self.gen_B = B
+        self.condition_sum = None if condition_sum is None else bf16r(_np(condition_sum).reshape(-1, c.dim))
+        if self.cfg_coef != 1.0:
+            B = 2 * B
+        if self.condition_sum is not None:
+            assert self.condition_sum.shape[0] == B, "cfg requires 2x more conditions."
+        self._streaming_model(B)
+        B = self.gen_B
         self.B = B
         self.exec_mask = np.ones(B, bool)
         self.CT = max(c.delays) + 2
         self.cache = np.full((B, c.n_q + 1, self.CT), -2, np.int64)
         self.offsets = np.zeros(B, np.int64)
         self.offset_cpu = 0
+
+    def _model_rows(self, per_session: np.ndarray) -> np.ndarray:
+        """Per-session quantity -> per model row (`.repeat(2)` under guidance, lm.py:655-663)."""
+        return np.concatenate([per_session, per_session]) if self.cfg_coef != 1.0 else per_session
+
+    def _guide(self, logits: np.ndarray) -> np.ndarray:
+        """logits_null + (logits - logits_null) * cfg_coef on bf16 tensors (lm.py:733, 830-832)."""
+        B = self.gen_B
+        lg, null = logits[:B], logits[B:]
+        return bf16r(null + bf16r(bf16r(lg - null) * f32(self.cfg_coef)))
+
+    def _streaming_model(self, B: int):
+        c = self.cfg
+        self.model_B = B
+        self.CT = max(c.delays) + 2
         H, Dh = c.num_heads, c.dim // c.num_heads
         self.kv = [np.zeros((2, B, H, c.context, Dh), f32) for _ in range(c.num_layers)]
         self.tr_offset = np.zeros(B, np.int64)          # MHA offset == RingKVCache.end_offset for every layer
@@ -195,7 +226,7 @@ class LMOracle:
         mask = np.ones(self.B, bool) if mask is None else np.asarray(mask, bool)
         self.exec_mask[mask] = True
         self.offsets[mask] = 0
-        self.tr_offset[mask] = 0
+        self.tr_offset[self._model_rows(mask)] = 0
         self.offset_cpu = 0
 
     def set_exec_mask(self, mask):
@@ -215,8 +246,11 @@ class LMOracle:
             e = self._embed(self.emb[i], tokens[:, i + 1])
             x = e if x is None else bf16r(x + e)
         x = bf16r(x + self._embed(self.text_emb, tokens[:, 0]))
+        if self.condition_sum is not None:                       # lm.py:399-400
+            x = bf16r(x + self.condition_sum)
         H, Dh, cap = c.num_heads, c.dim // c.num_heads, c.context
         off = self.tr_offset
+        exec_rows = self._model_rows(self.exec_mask)
         for l, L in enumerate(self.layers):
             qkv = linear(rms_norm(x, L["n1"]), L["in_proj"]).reshape(B, 3, H, Dh)
             q, k = rope_1(qkv[:, 0], qkv[:, 1], off, c.max_period)
@@ -228,7 +262,7 @@ class LMOracle:
                 cache[0, b, :, slot] = k[b]              # written unconditionally (transformer.py:243-250)
                 cache[1, b, :, slot] = v[b]
                 last = int(off[b])
-                end_new = last + 1 if self.exec_mask[b] else last
+                end_new = last + 1 if exec_rows[b] else last
                 idx = np.arange(cap)
                 delta = idx - (last % cap)
                 pos = np.where(delta <= 0, last + delta, last + delta - cap)
@@ -252,9 +286,9 @@ class LMOracle:
     # ---- depformer (lm.py:450-493, 809-850) ------------------------------------------------------------
     def depformer_step(self, text_token, tout, use_sampling, temp, top_k, noise, forced):
         c = self.cfg
-        B = tout.shape[0]
+        B = tout.shape[0]                                        # model rows (2x the sessions under guidance)
         Hd, Dhd = c.depformer_num_heads, c.depformer_dim // c.depformer_num_heads
-        prev = text_token
+        prev = self._model_rows(text_token)
         keys: List[List[np.ndarray]] = [[] for _ in self.dep_layers]
         vals: List[List[np.ndarray]] = [[] for _ in self.dep_layers]
         tokens, logits_all = [], []
@@ -272,12 +306,14 @@ class LMOracle:
                 x = bf16r(x + linear(att, L["out_proj"][k]))
                 x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"][k], L["w_out"][k]))
             lg = linear(x, self.linears[k])
+            if self.cfg_coef != 1.0:
+                lg = self._guide(lg)
             nz = None if noise is None else noise[:, 1 + k]
             tok = sample_token(lg, use_sampling, temp, top_k, nz)
             if forced is not None:
                 tok = np.where(forced[:, 1 + k] >= 0, forced[:, 1 + k], tok)
             tokens.append(tok); logits_all.append(lg)
-            prev = tok
+            prev = self._model_rows(tok)
         return np.stack(tokens, 1), np.stack(logits_all, 1)
 
     # ---- LMGen._step (lm.py:668-783) ---------------------------------------------
@@ -301,8 +337,20 @@ class LMOracle:
         inp = self.cache[np.arange(B)[:, None], np.arange(c.n_q + 1)[None, :], (self.offsets % CT)[:, None]]
         initial = np.array([c.text_card] + [c.card] * c.n_q)
         inp = np.where(is_init, initial[None, :], inp)
+        if self.cfg_coef != 1.0:                                  # lm.py:712-725
+            null = inp.copy()
+            if self.cfg_is_masked_until is not None:
+                zeroed = self.offsets[:, None] <= delays[None, :] + self.cfg_is_masked_until[:, None]
+                null = np.where(zeroed & ~is_init, -1, null)
+            if self.cfg_is_no_text:
+                null[:, 0] = np.where(~is_init[:, 0], -1, null[:, 0])
+            inp = np.concatenate([inp, null], 0)
         tout, text_logits = self.forward_text(inp)
-        self.tr_offset = np.where(ex, self.tr_offset + 1, self.tr_offset)
+        self.last_tout = tout
+        if self.cfg_coef != 1.0:                                  # lm.py:727-733
+            text_logits = text_logits[:B] if self.cfg_is_no_text else self._guide(text_logits)
+        exm = self._model_rows(ex)
+        self.tr_offset = np.where(exm, self.tr_offset + 1, self.tr_offset)
         text_token = sample_token(text_logits, use_sampling, temp_text, top_k_text, None if noise is None else noise[:, 0])
         if forced is not None:
             text_token = np.where(forced[:, 0] >= 0, forced[:, 0], text_token)
@@ -324,3 +372,13 @@ class LMOracle:
         hide = (self.offsets <= max_delay) | ~ex
         out = np.where(hide[:, None], -2, out)
         return out[:, :, None], taps
+
+    def extra_head_probs(self) -> np.ndarray:
+        """`step_with_extra_heads` (lm.py:793-807): softmax(extra_head(transformer_out)) per head, on the last step's
+        transformer output -> [model rows, n_heads, extra_heads_dim] (bf16 values)."""
+        outs = []
+        for w in self.extra_heads:
+            lg = linear(self.last_tout, w)
+            e = np.exp(lg - lg.max(-1, keepdims=True)).astype(f32)
+            outs.append(bf16r(e / e.sum(-1, keepdims=True, dtype=f32)))
+        return np.stack(outs, 1)

@@ -20,10 +20,16 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 LOGIT_MAX_REL, LOGIT_MEAN_REL = 0.05, 0.012
 
 
-def logits_close(a: np.ndarray, ref: np.ndarray) -> bool:
+def logits_close(a: np.ndarray, ref: np.ndarray, widen: float = 1.0) -> bool:
     scale = float(np.abs(ref).max()) + 1e-6
     d = np.abs(a - ref)
-    return float(d.max()) <= LOGIT_MAX_REL * scale and float(d.mean()) <= LOGIT_MEAN_REL * scale
+    return float(d.max()) <= widen * LOGIT_MAX_REL * scale and float(d.mean()) <= widen * LOGIT_MEAN_REL * scale
+
+
+# Guided logits are null + (cond - null) * coef: the rounding noise of BOTH model rows enters, weighted |coef| and |coef - 1|,
+# while the scale of the result grows less than that.  Measured on tests/golden/lm_cfg.npz: the numpy oracle sits at max 4.0 % /
+# mean 1.4 % of max|ref| from the reference at coef 2 (3.2 % / 0.8 % at coef 3 with a condition) -> tolerance widened 1.5x.
+GUIDED_WIDEN = 1.5
 
 
 def near_tie(ref_logits: np.ndarray, tok_a: int, tok_b: int) -> bool:
@@ -211,3 +217,51 @@ def smoke_lm(dev):
     cfg = tiny_lm_config()
     oracle_vs_engine(dev, None, cfg, seed=3, B=2, S=3, use_masks=False)
     print("smoke: LMGen.step ring outputs identical to the oracle, logits within tolerance")
+
+
+# ---- classifier-free guidance, sum-conditioning, extra heads (tests/golden/lm_cfg.npz) -------------------
+CFG_SCENARIOS = {
+    "a": dict(cfg_coef=2.0, masked_until=True),
+    "b": dict(cfg_coef=1.5, cfg_is_no_text=True),
+    "c": dict(cfg_coef=3.0, cond="cond2"),
+    "d": dict(cfg_coef=1.0, cond="cond1", heads=True),
+}
+
+
+def load_cfg_golden():
+    g = np.load(GOLDEN / "lm_cfg.npz")
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+    for i, w in enumerate(g["heads_w"]):
+        sd[f"extra_heads.{i}.weight"] = torch.from_numpy(w).to(torch.bfloat16)
+    return g, cfg, sd
+
+
+def check_cfg_scenario(g, cfg, name, start, step, heads=None):
+    """Replays scenario `name` of the reference's guided / conditioned runs, teacher-forced with the reference's tokens.
+    start(**opts) opens the stream; step(codes, forced, mask, reset_mask_or_None) -> (out [B, 1+dep_q, 1], text logits
+    [B, V], audio logits [B, dep_q, card]) - the logits the tokens were sampled from, i.e. after the guidance mix;
+    heads() -> [rows >= B, n_heads, dim] extra-head probabilities of the last step."""
+    sc = CFG_SCENARIOS[name]
+    S, B = g["masks"].shape
+    wd = GUIDED_WIDEN if sc["cfg_coef"] != 1.0 else 1.0
+    start(cfg_coef=sc["cfg_coef"], cfg_is_no_text=sc.get("cfg_is_no_text", False),
+          cfg_is_masked_until=[int(v) for v in g["masked_until"]] if sc.get("masked_until") else None,
+          condition_sum=g[sc["cond"]][:, 0] if sc.get("cond") else None)
+    for s in range(S):
+        reset = g["reset_mask"] if s == int(g["reset_step"][0]) else None
+        forced = np.concatenate([g[f"{name}_text_tok"][s][:, None], g[f"{name}_audio_tok"][s]], 1)
+        out, tl, al = step(g["codes"][s], forced, g["masks"][s], reset)
+        for b in range(B):
+            if not g["masks"][s, b]:
+                continue
+            assert np.array_equal(out[b], g[f"{name}_tokens"][s, b]), f"{name} step {s} row {b}: ring output differs"
+            assert logits_close(tl[b], g[f"{name}_text_logits"][s, b], wd), f"{name} step {s} row {b}: text logits"
+            for k in range(cfg.dep_q):
+                assert logits_close(al[b, k], g[f"{name}_audio_logits"][s, b, k], wd), f"{name} step {s} row {b} cb {k}: audio logits"
+        if sc.get("heads") and heads is not None:
+            pr = heads()
+            for b in range(B):
+                if g["masks"][s, b]:
+                    assert np.abs(pr[b] - g["d_heads"][s, b]).max() <= 0.02, f"extra heads step {s} row {b}"
+                    assert np.abs(pr[b].sum(-1) - 1).max() < 0.02

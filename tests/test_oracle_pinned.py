@@ -103,3 +103,22 @@ def test_lm_oracle_matches_reference_at_7b_layer_shapes():
         out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
         return out, tl, al
     lm_cases.check_wide_steps(step, g, cfg)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_lm_oracle_guidance_conditioning_and_extra_heads_match_reference(name):
+    """oracle/lm_oracle.py against the reference's LMGen with classifier-free guidance (masked-until / no-text / condition
+    tensors), a `sum` condition and extra heads: tests/golden/lm_cfg.npz (make_golden_lm_cfg.py)."""
+    from oracle.lm_oracle import LMOracle
+    from tests import lm_cases
+    g, cfg, sd = lm_cases.load_cfg_golden()
+    o = LMOracle(sd, cfg)
+    B = g["masks"].shape[1]
+
+    def step(codes, forced, mask, reset):
+        if reset is not None:
+            o.reset_streaming(reset)
+        o.set_exec_mask(mask)
+        out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+        return out, tl, al
+    lm_cases.check_cfg_scenario(g, cfg, name, lambda **kw: o.streaming(B, **kw), step, o.extra_head_probs)
