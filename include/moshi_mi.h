@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MMI_ABI_VERSION 1
+#define MMI_ABI_VERSION 2
 
 typedef enum mmi_status {
     MMI_OK = 0,
@@ -163,6 +163,8 @@ typedef struct mmi_lm_cfg {
     int32_t depformer_ffn_hidden; /* 2816 */
     int32_t delays[64];     /* num_codebooks = n_q + 1 entries (text first) */
     int32_t existing_text_padding_id; /* 3 */
+    int32_t extra_heads_num_heads;    /* 0: nn.Linear(dim, extra_heads_dim) heads on the transformer output (lm.py:101-102, 224-226) */
+    int32_t extra_heads_dim;          /* 6 */
 } mmi_lm_cfg;
 
 /* LMGen constructor arguments that change what step computes (lm.py:557-574). */
@@ -189,6 +191,26 @@ void mmi_lm_destroy(mmi_lm* lm);
 
 /* LMGen.streaming(batch) enter/exit (lm.py:605-666). */
 int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream);
+/* LMGen's classifier-free guidance and conditioning arguments (lm.py:566-574, 612-651).  With
+ * cfg_coef != 1 the model runs two rows per session (conditioned, unconditioned) - 2 * batch must fit max_batch - and every
+ * sampling site draws from logits_null + (logits - logits_null) * cfg_coef (lm.py:727-733, 828-832).
+ *   cfg_is_masked_until  host i64 [batch] or NULL: the unconditioned row reads zero tokens until offset > delay + value (lm.py:713-721)
+ *   cfg_is_no_text       the unconditioned row never reads text tokens and the text logits stay unguided (lm.py:724-732)
+ *   condition_sum        device bf16 [model rows, dim] or NULL: ConditionFuser.get_sum of the condition tensors, added to the
+ *                        input embeddings of every step (lm.py:621-628, 399-400); model rows = batch, or 2 * batch when guided
+ *                        (conditioned rows first).  Cross-attention conditioning is not implemented. */
+typedef struct mmi_guidance {
+    float cfg_coef;
+    int32_t cfg_is_no_text;
+    const int64_t* cfg_is_masked_until;
+    const void* condition_sum;
+} mmi_guidance;
+int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide_or_null,
+                                  mmi_stream stream);
+int mmi_lm_model_rows(const mmi_lm* lm);   /* rows the model runs for the current stream: batch, or 2 * batch when guided */
+/* LMGen.step_with_extra_heads (lm.py:793-807): softmax(extra_head(transformer_out)) of the LAST step for every head:
+ * probs f32 [model rows, extra_heads_num_heads, extra_heads_dim]. */
+int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream);
 int mmi_lm_streaming_stop(mmi_lm* lm);
 int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream);        /* lm.py:544-547 */
 int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask_or_null, mmi_stream stream);        /* lm.py:537-542 */

@@ -45,12 +45,18 @@ class LMCfg(C.Structure):
                 ("card", C.c_int32), ("text_card", C.c_int32), ("text_card_out", C.c_int32),
                 ("depformer_dim", C.c_int32), ("depformer_num_heads", C.c_int32),
                 ("depformer_num_layers", C.c_int32), ("depformer_ffn_hidden", C.c_int32),
-                ("delays", C.c_int32 * 64), ("existing_text_padding_id", C.c_int32)]
+                ("delays", C.c_int32 * 64), ("existing_text_padding_id", C.c_int32),
+                ("extra_heads_num_heads", C.c_int32), ("extra_heads_dim", C.c_int32)]
 
 
 class Sampling(C.Structure):
     _fields_ = [("use_sampling", C.c_int32), ("temp", C.c_float), ("temp_text", C.c_float), ("top_k", C.c_int32),
                 ("top_k_text", C.c_int32), ("seed", C.c_uint64)]
+
+
+class Guidance(C.Structure):
+    _fields_ = [("cfg_coef", C.c_float), ("cfg_is_no_text", C.c_int32), ("cfg_is_masked_until", C.c_void_p),
+                ("condition_sum", C.c_void_p)]
 
 
 class BatcherCfg(C.Structure):
@@ -84,6 +90,9 @@ SIGNATURES = {
     "mmi_lm_create": (C.c_int, [C.POINTER(LMCfg), C.POINTER(TensorDesc), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "mmi_lm_destroy": (None, [_P]),
     "mmi_lm_streaming_start": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), _P]),
+    "mmi_lm_streaming_start_guided": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), C.POINTER(Guidance), _P]),
+    "mmi_lm_model_rows": (C.c_int, [_P]),
+    "mmi_lm_extra_heads": (C.c_int, [_P, _P, _P]),
     "mmi_lm_streaming_stop": (C.c_int, [_P]),
     "mmi_lm_set_exec_mask": (C.c_int, [_P, _P, _P]),
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),

@@ -109,6 +109,8 @@ class LMConfig:
     depformer_num_heads: int = 16
     depformer_num_layers: int = 6
     delays: List[int] = field(default_factory=lambda: [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1])
+    extra_heads_num_heads: int = 0      # lm.py:101-102: linear heads on the transformer output (step_with_extra_heads)
+    extra_heads_dim: int = 6
 
     @staticmethod
     def _gating_hidden(dim: int, dim_feedforward: int) -> int:

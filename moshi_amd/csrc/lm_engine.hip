@@ -55,7 +55,15 @@ struct mmi_lm {
     size_t weight_bytes = 0;
     // streaming state
     bool streaming = false;
-    int batch = 0;
+    int batch = 0;                  // MODEL rows: the sessions, doubled under classifier-free guidance (lm.py:646-651)
+    int gen_batch = 0;              // sessions (rows of the token ring, the samplers and the caller's tensors)
+    float cfg_coef = 1.f;           // LMGen(cfg_coef, cfg_is_no_text, cfg_is_masked_until) (lm.py:566-574)
+    int cfg_no_text = 0;
+    int* masked_until = nullptr;    // [gen_batch] or null
+    uint16_t* cond = nullptr;       // [batch][dim] summed `sum` conditions (lm.py:621-628) or null
+    long* offsets_m = nullptr;      // [batch] offsets per model row (== offsets without guidance)
+    std::vector<uint16_t*> extra_heads;   // nn.Linear(dim, extra_heads_dim) weights, row-major
+    uint16_t* extra_heads_all = nullptr;
     mmi_sampling samp;
     int kmax = 0;
     MmiArena st;
@@ -304,7 +312,7 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
-    a.tok_stride = tok_stride; a.B = lm->batch;
+    a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
     a.out_ld = out_features;
     a.out_ksteps = packed_ksteps(lm, out_features);
@@ -383,9 +391,20 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
 }
 
 // next_k >= 0: the sampled token opens depth-transformer micro-step next_k, whose input row the sampler writes itself
-void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride, int next_k = -1) {
+void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site, int* out, int out_stride, int next_k = -1) {
+    const bool guided = lm->cfg_coef != 1.f;
+    if (guided && !(text && lm->cfg_no_text)) {     // lm.py:727-733 (text; `cfg_is_no_text` keeps the conditioned logits), 828-832
+        const int G = lm->gen_batch;
+        const float coef = lm->cfg_coef;
+        lm->prog.add([=](hipStream_t s) {
+            MMI_LAUNCH(k_cfg_mix, dim3(mmi_cdiv(V, 256), G), 256, 0, s, logits, ld, V, G, coef);
+            MMI_CHECK_LAUNCH();
+            return (int)MMI_OK;
+        });
+    }
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
+    sa.nx_dup = guided ? lm->gen_batch : 0;
     if (next_k >= 0) {
         const int dd = lm->cfg.depformer_dim;
         sa.nx_pre = lm->dpre + (size_t)next_k * dd; sa.nx_ld = lm->cfg.dep_q * dd;
@@ -400,9 +419,9 @@ void add_sample(mmi_lm* lm, const uint16_t* logits, int ld, int V, bool text, in
     sa.noise = lm->noise + (size_t)site * lm->kmax;
     sa.noise_ld = (1 + lm->cfg.dep_q) * lm->kmax;
     sa.use_noise = lm->use_noise; sa.rng = lm->rng; sa.site = site; sa.out = out; sa.out_stride = out_stride;
-    sa.B = lm->batch;
+    sa.B = lm->gen_batch;
     sa.forced = lm->forced + site; sa.forced_stride = 1 + lm->cfg.dep_q; sa.use_forced = lm->use_forced;
-    const int B = lm->batch;
+    const int B = lm->gen_batch;
     lm->prog.add([=](hipStream_t s) {
         if (V <= 2048) MMI_LAUNCH((k_sample<256, 8, true>), B, 256, 0, s, sa);
         else if (V <= 8192) MMI_LAUNCH((k_sample<1024, 8, true>), B, 1024, 0, s, sa);
@@ -435,7 +454,7 @@ int launch_attn_split(hipStream_t s, const LmAttnArgs& a) {
 TokArgs tok_args(mmi_lm* lm) {
     TokArgs t;
     t.cache = lm->cache; t.offsets = lm->offsets; t.exec = lm->exec; t.delays = lm->delays_dev;
-    t.B = lm->batch; t.NC = lm->NC; t.CT = lm->CT; t.dep_q = lm->cfg.dep_q; t.max_delay = lm->max_delay;
+    t.B = lm->gen_batch; t.NC = lm->NC; t.CT = lm->CT; t.dep_q = lm->cfg.dep_q; t.max_delay = lm->max_delay;
     t.card = lm->cfg.card; t.text_card = lm->cfg.text_card;
     return t;
 }
@@ -453,9 +472,15 @@ int build_program(mmi_lm* lm) {
         const uint16_t *emb = lm->emb, *temb = lm->text_emb; uint16_t* x = lm->x; const int NC = lm->NC, card1 = c.card + 1;
         const int T = lm->T, xks = packed_ksteps(lm, d);
         float* rope = lm->rope; const float max_period = c.max_period;
+        const int G = lm->gen_batch;
+        const bool guided = lm->cfg_coef != 1.f;
+        const int* masked_until = lm->masked_until; const int no_text = lm->cfg_no_text; long* offsets_m = lm->offsets_m;
+        const uint16_t* cond = lm->cond;
         P.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_lm_prepare, mmi_cdiv(B * NC + B * (Dh / 2), 128), 128, 0, s, t, user, n_user, tokens, rope, Dh, max_period);
-            MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d, T, xks);
+            MMI_LAUNCH(k_lm_prepare, mmi_cdiv(G * NC + G * (Dh / 2), 128), 128, 0, s, t, user, n_user, tokens, rope, Dh, max_period);
+            if (guided)
+                MMI_LAUNCH(k_lm_cfg_twins, mmi_cdiv(G * NC + G * Dh + G, 128), 128, 0, s, t, tokens, masked_until, no_text, offsets_m, rope, Dh);
+            MMI_LAUNCH(k_lm_embed, dim3(mmi_cdiv(d, 256), B), 256, 0, s, (const int*)tokens, NC, emb, card1, temb, x, d, T, xks, cond);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
@@ -469,14 +494,14 @@ int build_program(mmi_lm* lm) {
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
         LmAttnArgs a;
         a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
-        a.offsets = lm->offsets; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
+        a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
             memset(&ga, 0, sizeof(ga));
             ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
-            ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets; ga.H = H; ga.Dh = Dh; ga.cap = c.context;
+            ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context;
             ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
             P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
@@ -531,7 +556,7 @@ int build_program(mmi_lm* lm) {
         TokArgs t = tok_args(lm);
         const int *tt = lm->text_tok, *at = lm->audio_tok; int* out = lm->out_i32; unsigned long long* rng = lm->rng;
         P.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_lm_commit, mmi_cdiv(B, 64), 64, 0, s, t, tt, at, out, rng);
+            MMI_LAUNCH(k_lm_commit, mmi_cdiv(t.B, 64), 64, 0, s, t, tt, at, out, rng);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
@@ -604,6 +629,13 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     }
     if ((rc = load_copy(lm, W, "out_norm.alpha", 3, d, &lm->out_norm))) return fail(rc);
     if ((rc = load_linear(lm, W, "text_linear.weight", c.text_card_out, d, 0, &lm->text_linear))) return fail(rc);
+    if (c.extra_heads_num_heads > 0) {   // lm.py:224-226: nn.Linear(dim, extra_heads_dim, bias=False) read by step_with_extra_heads
+        if (c.extra_heads_dim < 1 || c.extra_heads_dim > 64) return fail(mmi_fail(MMI_ERR_UNSUPPORTED, "extra_heads_dim must be 1..64"));
+        const size_t per = (size_t)c.extra_heads_dim * d;
+        if (hipSuccess != lm->wts.alloc(&lm->extra_heads_all, per * c.extra_heads_num_heads)) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory"));
+        for (int i = 0; i < c.extra_heads_num_heads; ++i)
+            if ((rc = load_copy(lm, W, "extra_heads." + std::to_string(i) + ".weight", 2, per, nullptr, lm->extra_heads_all + per * i))) return fail(rc);
+    }
     // depformer (lm.py:179-232; per-step weights transformer.py:291-318)
     lm->dep_in.resize(c.dep_q);
     lm->dep_lin.resize(c.dep_q);
@@ -678,34 +710,52 @@ extern "C" int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out) {
 }
 
 extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream) {
+    return mmi_lm_streaming_start_guided(lm, batch, sampling, nullptr, stream);
+}
+
+extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide,
+                                             mmi_stream stream) {
     if (!lm || !sampling) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (lm->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");
-    if (batch <= 0 || batch > lm->max_batch) return mmi_fail(MMI_ERR_SHAPE, "batch exceeds max_batch");
+    const bool guided = guide && guide->cfg_coef != 1.0f;
+    const int rows = guided ? 2 * batch : batch;              // lm.py:646-647 `batch_size *= 2`
+    if (batch <= 0 || rows > lm->max_batch)
+        return mmi_fail(MMI_ERR_SHAPE, guided ? "guidance runs two model rows per session: 2 * batch exceeds max_batch" : "batch exceeds max_batch");
     if (sampling->top_k > 256 || sampling->top_k_text > 256) return mmi_fail(MMI_ERR_UNSUPPORTED, "top_k > 256");
     if (sampling->use_sampling && (sampling->top_k <= 0 || sampling->top_k_text <= 0))
         return mmi_fail(MMI_ERR_UNSUPPORTED, "sampling without top-k is not implemented");
     hipStream_t s = (hipStream_t)stream;
     const mmi_lm_cfg& c = lm->cfg;
-    lm->batch = batch;
+    lm->batch = rows;
+    lm->gen_batch = batch;
+    lm->cfg_coef = guided ? guide->cfg_coef : 1.f;
+    lm->cfg_no_text = guided && guide->cfg_is_no_text ? 1 : 0;
+    lm->masked_until = nullptr;
+    lm->cond = nullptr;
     lm->samp = *sampling;
     lm->kmax = sampling->top_k > sampling->top_k_text ? sampling->top_k : sampling->top_k_text;
     if (lm->kmax < 1) lm->kmax = 1;
     lm->offset_cpu = 0;
-    const int B = batch, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
+    const int G = batch;
+    const int B = rows, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
     const int NS = attn_splits(c, B);
     auto fail = [&](int code) { lm->streaming = true; mmi_lm_streaming_stop(lm); return code; };
     MmiArena& A = lm->st;
     const size_t kvn = (size_t)c.num_layers * B * H * c.context * Dh;
     const size_t dkvn = (size_t)c.depformer_num_layers * B * Hd * c.dep_q * Dhd;
     bool ok = true;
-    ok &= hipSuccess == A.alloc(&lm->exec, (size_t)B);
-    ok &= hipSuccess == A.alloc(&lm->offsets, (size_t)B);
-    ok &= hipSuccess == A.alloc(&lm->cache, (size_t)B * lm->NC * lm->CT);
-    ok &= hipSuccess == A.alloc(&lm->user_i32, (size_t)B * (c.n_q - c.dep_q));
+    ok &= hipSuccess == A.alloc(&lm->exec, (size_t)G);
+    ok &= hipSuccess == A.alloc(&lm->offsets, (size_t)G);
+    lm->offsets_m = lm->offsets;
+    if (guided) ok &= hipSuccess == A.alloc(&lm->offsets_m, (size_t)B);
+    if (guided && guide->cfg_is_masked_until) ok &= hipSuccess == A.alloc(&lm->masked_until, (size_t)G);
+    if (guide && guide->condition_sum) ok &= hipSuccess == A.alloc(&lm->cond, (size_t)B * d);
+    ok &= hipSuccess == A.alloc(&lm->cache, (size_t)G * lm->NC * lm->CT);
+    ok &= hipSuccess == A.alloc(&lm->user_i32, (size_t)G * (c.n_q - c.dep_q));
     ok &= hipSuccess == A.alloc(&lm->tokens, (size_t)B * lm->NC);
-    ok &= hipSuccess == A.alloc(&lm->text_tok, (size_t)B);
-    ok &= hipSuccess == A.alloc(&lm->audio_tok, (size_t)B * c.dep_q);
-    ok &= hipSuccess == A.alloc(&lm->out_i32, (size_t)B * (c.dep_q + 1));
+    ok &= hipSuccess == A.alloc(&lm->text_tok, (size_t)G);
+    ok &= hipSuccess == A.alloc(&lm->audio_tok, (size_t)G * c.dep_q);
+    ok &= hipSuccess == A.alloc(&lm->out_i32, (size_t)G * (c.dep_q + 1));
     ok &= hipSuccess == A.alloc(&lm->x, packed_elems(lm, d));
     ok &= hipSuccess == A.alloc(&lm->xn, packed_elems(lm, d));
     ok &= hipSuccess == A.alloc(&lm->qrot, (size_t)B * d);
@@ -728,15 +778,22 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
     ok &= hipSuccess == A.alloc(&lm->dpre, (size_t)B * c.dep_q * dd);
     ok &= hipSuccess == A.alloc(&lm->dkc, dkvn);
     ok &= hipSuccess == A.alloc(&lm->dvc, dkvn);
-    ok &= hipSuccess == A.alloc(&lm->noise, (size_t)B * (1 + c.dep_q) * lm->kmax);
+    ok &= hipSuccess == A.alloc(&lm->noise, (size_t)G * (1 + c.dep_q) * lm->kmax);
     ok &= hipSuccess == A.alloc(&lm->use_noise, (size_t)1);
-    ok &= hipSuccess == A.alloc(&lm->forced, (size_t)B * (1 + c.dep_q));
+    ok &= hipSuccess == A.alloc(&lm->forced, (size_t)G * (1 + c.dep_q));
     ok &= hipSuccess == A.alloc(&lm->use_forced, (size_t)1);
     ok &= hipSuccess == A.alloc(&lm->rng, (size_t)2);
     if (!ok) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (LM streaming state)"));
-    MMI_HIP_CHECK(hipMemsetAsync(lm->exec, 1, B, s));
-    MMI_HIP_CHECK(hipMemsetAsync(lm->offsets, 0, B * sizeof(long), s));
-    MMI_LAUNCH(k_fill_i32, mmi_cdiv(B * lm->NC * lm->CT, 256), 256, 0, s, lm->cache, -2, (long)B * lm->NC * lm->CT);   // lm.py:608-613
+    MMI_HIP_CHECK(hipMemsetAsync(lm->exec, 1, G, s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->offsets, 0, G * sizeof(long), s));
+    if (guided) MMI_HIP_CHECK(hipMemsetAsync(lm->offsets_m, 0, B * sizeof(long), s));
+    if (lm->masked_until) {   // host int64[batch] (LMGen(cfg_is_masked_until=[...]), lm.py:637-640)
+        std::vector<int> mu(G);
+        for (int i = 0; i < G; ++i) mu[i] = (int)guide->cfg_is_masked_until[i];
+        MMI_HIP_CHECK(hipMemcpy(lm->masked_until, mu.data(), G * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (lm->cond) MMI_HIP_CHECK(hipMemcpyAsync(lm->cond, guide->condition_sum, (size_t)B * d * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+    MMI_LAUNCH(k_fill_i32, mmi_cdiv(G * lm->NC * lm->CT, 256), 256, 0, s, lm->cache, -2, (long)G * lm->NC * lm->CT);   // lm.py:608-613
     MMI_HIP_CHECK(hipMemsetAsync(lm->kc, 0, kvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->vc, 0, kvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dkc, 0, dkvn * sizeof(uint16_t), s));
@@ -749,8 +806,8 @@ extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampl
                                                {lm->dx, dd}, {lm->dxn, dd}, {lm->datt, dd}, {lm->dhb, c.depformer_ffn_hidden}};
         for (auto& e : pk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, packed_elems(lm, e.f) * sizeof(uint16_t), s));
     }
-    MMI_HIP_CHECK(hipMemsetAsync(lm->text_tok, 0, B * sizeof(int), s));
-    MMI_HIP_CHECK(hipMemsetAsync(lm->audio_tok, 0, (size_t)B * c.dep_q * sizeof(int), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->text_tok, 0, G * sizeof(int), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->audio_tok, 0, (size_t)G * c.dep_q * sizeof(int), s));
     unsigned long long r0[2] = {sampling->seed, 0ull};
     MMI_HIP_CHECK(hipMemcpyAsync(lm->rng, r0, sizeof(r0), hipMemcpyHostToDevice, s));
     MMI_CHECK_LAUNCH();
@@ -769,13 +826,15 @@ extern "C" int mmi_lm_streaming_stop(mmi_lm* lm) {
     lm->st.release();
     lm->streaming = false;
     lm->batch = 0;
+    lm->gen_batch = 0;
+    lm->cfg_coef = 1.f;
     return MMI_OK;
 }
 
 extern "C" int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) {
     if (!lm || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
-    MMI_HIP_CHECK(hipMemcpyAsync(lm->exec, mask, lm->batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    MMI_HIP_CHECK(hipMemcpyAsync(lm->exec, mask, lm->gen_batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MMI_OK;
 }
 
@@ -783,7 +842,7 @@ extern "C" int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) 
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     TokArgs t = tok_args(lm);
-    MMI_LAUNCH(k_lm_reset, mmi_cdiv(lm->batch, 64), 64, 0, (hipStream_t)stream, t, mask, lm->exec);
+    MMI_LAUNCH(k_lm_reset, mmi_cdiv(lm->gen_batch, 64), 64, 0, (hipStream_t)stream, t, mask, lm->exec);
     MMI_CHECK_LAUNCH();
     lm->offset_cpu = 0;   // lm.py:540: any reset, even partial, zeroes the host-side step counter
     return MMI_OK;
@@ -794,7 +853,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     if (!lm || !user_codes || !out_tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming)
         return mmi_fail(MMI_ERR_STATE, "You should wrap those calls with a `with lm_gen.streaming(): ...`.");   // lm.py:673-676
-    if (batch != lm->batch) return mmi_fail(MMI_ERR_SHAPE, "Got a different batch size than the streaming batch");   // lm.py:681
+    if (batch != lm->gen_batch) return mmi_fail(MMI_ERR_SHAPE, "Got a different batch size than the streaming batch");   // lm.py:681
     const mmi_lm_cfg& c = lm->cfg;
     const int need_user = c.n_q - c.dep_q;
     if (n_user < need_user) return mmi_fail(MMI_ERR_SHAPE, "not enough user tokens");   // lm.py:683-686
@@ -817,7 +876,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
         // internal layout [dep_q][B][card] -> caller's [B][dep_q][card]
         for (int k = 0; k < c.dep_q; ++k)
             for (int b = 0; b < B; ++b)
-                MMI_LAUNCH(k_bf16_to_f32, mmi_cdiv(c.card, 256), 256, 0, s, (const uint16_t*)(lm->dlogits + ((size_t)k * B + b) * c.card),
+                MMI_LAUNCH(k_bf16_to_f32, mmi_cdiv(c.card, 256), 256, 0, s, (const uint16_t*)(lm->dlogits + ((size_t)k * lm->batch + b) * c.card),
                            opt_audio_logits + ((size_t)b * c.dep_q + k) * c.card, (long)c.card);
     }
     MMI_CHECK_LAUNCH();
@@ -834,13 +893,26 @@ extern "C" int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_s
     if (!lm || !tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     hipStream_t s = (hipStream_t)stream;
-    const int n = lm->batch * (1 + lm->cfg.dep_q);
-    MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(n, 256), 256, 0, s, (const long*)tokens, (long)(1 + lm->cfg.dep_q), lm->forced, lm->batch, 1 + lm->cfg.dep_q);
+    const int n = lm->gen_batch * (1 + lm->cfg.dep_q);
+    MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(n, 256), 256, 0, s, (const long*)tokens, (long)(1 + lm->cfg.dep_q), lm->forced, lm->gen_batch, 1 + lm->cfg.dep_q);
     MMI_CHECK_LAUNCH();
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 1, 1, s));
     lm->forced_armed = true;
     return MMI_OK;
 }
+
+extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
+    if (!lm || !probs) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    const mmi_lm_cfg& c = lm->cfg;
+    if (c.extra_heads_num_heads <= 0) return MMI_OK;
+    MMI_LAUNCH(k_extra_heads, dim3(lm->batch, c.extra_heads_num_heads), 64, 0, (hipStream_t)stream, (const uint16_t*)lm->tout, lm->T,
+               packed_ksteps(lm, c.dim), (const uint16_t*)lm->extra_heads_all, c.dim, c.extra_heads_dim, c.extra_heads_num_heads, probs);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_model_rows(const mmi_lm* lm) { return lm ? lm->batch : 0; }
 
 extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");

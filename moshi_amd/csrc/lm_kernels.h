@@ -149,8 +149,9 @@ struct GemmArgs {
     uint16_t* out;          // row-major [B][out_ld] or packed [.][out_ksteps][64][8]
     const uint16_t* resid;  // EPI_RESID: same geometry as out
     const uint16_t* emb;    // EPI_EMB: embedding table [rows][N]
-    const int* tok;         // EPI_EMB: token per session, tok[b * tok_stride]
-    int tok_stride;
+    const int* tok;         // EPI_EMB: token per session, tok[(b % tok_rows) * tok_stride] (model rows beyond tok_rows are the
+    int tok_stride;         // guidance twins of the sessions and take the same token)
+    int tok_rows;
     int B, N, KSTEPS, NT;
     int out_mode, out_ld, out_ksteps;
     int epi;
@@ -196,7 +197,7 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
         const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.resid + (long)b * a.out_ld + n0;
         pre = *reinterpret_cast<const u32x4*>(rs);
     } else {
-        const int tk = a.tok[(long)b * a.tok_stride];
+        const int tk = a.tok[(long)(b % a.tok_rows) * a.tok_stride];
         if (tk != -1) pre = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
     }
     return pre;
@@ -338,7 +339,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         } else if (a.epi == MMI_EPI_EMB) {
             u32x4 ev = pre;
             if (q != (int)threadIdx.x) {
-                const int tk = a.tok[(long)b * a.tok_stride];
+                const int tk = a.tok[(long)(b % a.tok_rows) * a.tok_stride];
                 ev = u32x4{0u, 0u, 0u, 0u};
                 if (tk != -1) ev = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
             }
@@ -695,9 +696,10 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 // input embedding sum (lm.py:388-397): ((emb0[t1] + emb1[t2]) + ...) + text_emb[t0], each add rounded to bf16
 // ------------------------------------------------------------------------------------------------
+// cond: the fuser's summed condition [rows][D] (lm.py:399-400: input_ = input_ + sum_condition), or null
 __global__ void k_lm_embed(const int* __restrict__ tokens, int n_codebooks, const uint16_t* __restrict__ emb,
                            int card1, const uint16_t* __restrict__ text_emb, uint16_t* __restrict__ x, int D, int T,
-                           int ksteps) {
+                           int ksteps, const uint16_t* __restrict__ cond) {
     const int b = blockIdx.y;
     const int d = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (d >= D) return;
@@ -713,6 +715,7 @@ __global__ void k_lm_embed(const int* __restrict__ tokens, int n_codebooks, cons
     float tv = 0.f;
     if (t0 != -1) tv = mmi_bf16_to_f32(text_emb[(long)(t0 < 0 ? 0 : t0) * D + d]);
     acc = n_codebooks > 1 ? mmi_round_bf16(acc + tv) : tv;
+    if (cond) acc = acc + mmi_bf16_to_f32(cond[(long)b * D + d]);
     x[mmi_xp_index(T, b, d, ksteps)] = mmi_f32_to_bf16(acc);
 }
 
@@ -988,11 +991,15 @@ struct SampleArgs {
     const uint16_t* nx_emb;   // [card + 1][nx_D]
     uint16_t* nx_out;         // Xp layout (mmi_xp_index), null = nothing to write
     int nx_D, nx_T, nx_ksteps;
+    int nx_dup;               // classifier-free guidance: the unconditioned twin of session b is model row b + nx_dup and
+                              // opens the micro-step with the same token (lm.py:823-826 `input_.repeat(2, 1, 1)`); 0 = none
 };
 
-__device__ __forceinline__ void mmi_sample_next_input(const SampleArgs& a, int b, int tok) {
+__device__ __forceinline__ void mmi_sample_next_input(const SampleArgs& a, int b0, int tok) {
     if (!a.nx_out) return;
-    for (int g = (int)threadIdx.x; g < a.nx_D / 8; g += (int)blockDim.x) {
+    const int per = a.nx_D / 8;
+    for (int gg = (int)threadIdx.x; gg < (a.nx_dup ? 2 : 1) * per; gg += (int)blockDim.x) {
+        const int g = gg % per, b = b0 + (gg / per) * a.nx_dup;
         const int n0 = 8 * g;
         const u32x4 pv = *reinterpret_cast<const u32x4*>(a.nx_pre + (long)b * a.nx_ld + n0);
         u32x4 ev = {0u, 0u, 0u, 0u};
@@ -1348,4 +1355,73 @@ __global__ void k_lm_reset(TokArgs t, const uint8_t* __restrict__ mask, uint8_t*
     if (mask && !mask[idx]) return;
     t.offsets[idx] = 0;           // lm.py:537-542; transformer.py:329-334 (KV end_offset, MHA offset)
     exec[idx] = 1;                // streaming.py:43-44
+}
+
+// ------------------------------------------------------------------------------------------------
+// classifier-free guidance (lm.py:646-665, 712-733, 823-832) and extra heads (lm.py:793-807)
+// ------------------------------------------------------------------------------------------------
+// With cfg_coef != 1 the model runs 2G rows for G sessions: rows [0,G) conditioned, rows [G,2G) their unconditioned twins.
+// After k_lm_prepare has built the G conditioned input rows, this kernel derives the twins: the same tokens, except
+//   cfg_is_masked_until: every codebook reads the zero token (-1 -> zero embedding) while offset <= delay + masked_until[b],
+//   cfg_is_no_text     : the text codebook reads the zero token,
+// in both cases only where the row is past its initial token; it also replicates the per-session offset and RoPE angles
+// onto the model rows (reset / exec masks reach the twins the same way: `.repeat(2)`, lm.py:655-663).
+__global__ void k_lm_cfg_twins(TokArgs t, int* __restrict__ tokens, const int* __restrict__ masked_until, int no_text,
+                               long* __restrict__ offsets_m, float* __restrict__ rope, int Dh) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int G = t.B;
+    const int n_tok = G * t.NC, n_rope = G * Dh;
+    if (idx < n_tok) {
+        const int b = idx / t.NC, c = idx % t.NC;
+        const long off = t.offsets[b];
+        const bool is_init = off <= (long)t.delays[c] || !t.exec[b];
+        int tok = tokens[idx];
+        if (!is_init) {
+            if (masked_until && off <= (long)t.delays[c] + (long)masked_until[b]) tok = -1;
+            if (no_text && c == 0) tok = -1;
+        }
+        tokens[n_tok + idx] = tok;
+    } else if (idx < n_tok + n_rope) {
+        const int r = idx - n_tok;
+        rope[n_rope + r] = rope[r];
+    } else if (idx < n_tok + n_rope + G) {
+        const int b = idx - n_tok - n_rope;
+        offsets_m[b] = t.offsets[b];
+        offsets_m[G + b] = t.offsets[b];
+    }
+}
+
+// logits[b] <- logits_null + (logits - logits_null) * coef, each operation on bf16 tensors (lm.py:733, 830-832);
+// logits rows [0,G) conditioned, [G,2G) unconditioned; the mix lands in row b, which the sampler and the taps then read
+__global__ void k_cfg_mix(uint16_t* __restrict__ logits, int ld, int V, int G, float coef) {
+    const int b = blockIdx.y;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= V) return;
+    uint16_t* c = logits + (long)b * ld + i;
+    const float l = mmi_bf16_to_f32(*c), n = mmi_bf16_to_f32(logits[(long)(G + b) * ld + i]);
+    const float d = mmi_round_bf16(l - n);
+    const float m = mmi_round_bf16(d * coef);
+    *c = mmi_f32_to_bf16(n + m);
+}
+
+// softmax(extra_head(transformer_out)) (lm.py:803-806): one workgroup per (head, model row), one wave per output feature
+// group; tout is the packed activation operand of the text head.  probs [rows][n_heads][hdim] fp32 (bf16 values).
+__global__ __launch_bounds__(64) void k_extra_heads(const uint16_t* __restrict__ tout, int T, int ksteps, const uint16_t* __restrict__ w,
+                                                   int D, int hdim, int n_heads, float* __restrict__ probs) {
+    const int b = blockIdx.x, h = blockIdx.y, lane = (int)threadIdx.x;
+    MMI_SHARED float lg[64];
+    for (int j = 0; j < hdim; ++j) {
+        const uint16_t* wr = w + ((long)h * hdim + j) * D;
+        float acc = 0.f;
+        for (int k = lane; k < D; k += 64) acc += mmi_bf16_to_f32(tout[mmi_xp_index(T, b, k, ksteps)]) * mmi_bf16_to_f32(wr[k]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += mmi_shfl_xor(acc, m);
+        if (lane == 0) lg[j] = mmi_round_bf16(acc);          // nn.Linear output in bf16
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = 0; j < hdim; ++j) mx = fmaxf(mx, lg[j]);
+    float den = 0.f;
+    for (int j = 0; j < hdim; ++j) den += expf(lg[j] - mx);
+    if (lane < hdim) probs[((long)b * n_heads + h) * hdim + lane] = mmi_round_bf16(expf(lg[lane] - mx) / den);
 }

@@ -37,7 +37,34 @@ def _lm_cfg_struct(cfg: LMConfig) -> _capi.LMCfg:
     for i, d in enumerate(cfg.delays):
         s.delays[i] = d
     s.existing_text_padding_id = cfg.existing_text_padding_id
+    s.extra_heads_num_heads = cfg.extra_heads_num_heads
+    s.extra_heads_dim = cfg.extra_heads_dim
     return s
+
+
+class ConditionFuser:
+    """The part of the reference's `ConditionFuser` that `LMGen` uses (conditioners/base.py:349-421): which named condition
+    tensors are summed into the model input.  Cross-attention conditioning is not implemented by the engine."""
+
+    def __init__(self, fuse2cond: Dict[str, List[str]]):
+        for method, names in fuse2cond.items():
+            if method not in ("sum", "cross", "prepend"):
+                raise AssertionError(f"Got invalid fuse method {method}")
+            if method != "sum" and names:
+                raise RuntimeError(f"only `sum` conditioning is supported by the engine, got {method}.")
+        self.fuse2cond = {"sum": list(fuse2cond.get("sum", [])), "cross": [], "prepend": []}
+
+    def get_sum(self, conditions) -> Optional[torch.Tensor]:
+        """conditioners/base.py:410-421: conditions[name] = (tensor [B, 1, dim], mask)."""
+        total = None
+        for name in self.fuse2cond["sum"]:
+            cond = conditions[name][0]
+            assert cond.shape[1] == 1, cond.shape
+            total = cond if total is None else total + cond
+        return total
+
+    def get_cross(self, conditions):
+        return None
 
 
 class LMModel:
@@ -55,8 +82,9 @@ class LMModel:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[LMConfig] = None,
                  device: torch.device | str = "cuda", max_batch: int = 32, lib: Optional[_capi.Lib] = None,
-                 quantize: bool | str = False):
+                 quantize: bool | str = False, fuser: Optional[ConditionFuser] = None):
         self.config = config or LMConfig()
+        self.fuser = fuser
         self.device = torch.device(device)
         if lib is None:
             if self.device.type != "cuda":
@@ -160,8 +188,9 @@ class LMModel:
 
 
 class LMGen:
-    """Streaming generation (reference: lm.py:556-850).  Options outside Moshi's own inference path (CFG,
-    condition tensors, hooks) are rejected loudly rather than silently ignored."""
+    """Streaming generation (reference: lm.py:556-850), including classifier-free guidance (`cfg_coef`,
+    `cfg_is_masked_until`, `cfg_is_no_text`) and `sum` condition tensors through `lm_model.fuser`.  Per-step Python hooks
+    and cross-attention conditioning are rejected loudly rather than silently ignored."""
 
     def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
                  top_k: int = 250, top_k_text: int = 25, cfg_coef: float = 1.0, check: bool = False,
@@ -169,8 +198,13 @@ class LMGen:
                  support_out_of_sync: bool = False, cfg_is_masked_until=None, cfg_is_no_text: bool = False,
                  seed: int = 0):
         assert not lm_model.training, "generation shouldn't be used in training mode."
-        if cfg_coef != 1.0 or condition_tensors is not None or cfg_is_masked_until is not None or cfg_is_no_text:
-            raise NotImplementedError("CFG / conditioning are outside the Moshi-7B step (SURVEY.md 8f-3)")
+        if cfg_coef != 1.:                                # lm.py:600-603
+            if not cfg_is_no_text and not cfg_is_masked_until:
+                assert lm_model.fuser is not None, "Model has no fuser, cannot do CFG."
+                assert condition_tensors, "Missing condition tensors for CFG."
+        self.condition_tensors = condition_tensors
+        self.cfg_is_masked_until = cfg_is_masked_until
+        self.cfg_is_no_text = cfg_is_no_text
         if on_text_hook or on_text_logits_hook or on_audio_hook:
             raise NotImplementedError("per-step hooks are not supported by the fused step (use step_with_taps)")
         self.lm_model = lm_model
@@ -213,7 +247,31 @@ class LMGen:
         s.temp, s.temp_text = self.temp, self.temp_text
         s.top_k, s.top_k_text = self.top_k, self.top_k_text
         s.seed = self.seed
-        self._lib.check(self._lib.mmi_lm_streaming_start(self.lm_model._handle, int(batch_size), C.byref(s), self._stream()))
+        lm = self.lm_model
+        g = _capi.Guidance()
+        g.cfg_coef = float(self.cfg_coef)
+        g.cfg_is_no_text = 1 if self.cfg_is_no_text else 0
+        rows = int(batch_size) * (2 if self.cfg_coef != 1. else 1)
+        keep = []
+        if lm.fuser is None:                               # lm.py:616-628
+            assert not self.condition_tensors
+        else:
+            assert self.condition_tensors is not None
+            cs = lm.fuser.get_sum(self.condition_tensors)
+            if cs is not None:
+                assert cs.shape[0] == rows, "cfg requires 2x more conditions." if self.cfg_coef != 1. else "one condition row per session"
+                cs = cs.to(device=self.device, dtype=torch.bfloat16).contiguous().view(rows, lm.dim)
+                keep.append(cs)
+                g.condition_sum = cs.data_ptr()
+        if self.cfg_is_masked_until is not None and self.cfg_coef != 1.:
+            assert len(self.cfg_is_masked_until) == int(batch_size)
+            mu = (C.c_int64 * int(batch_size))(*[int(v) for v in self.cfg_is_masked_until])
+            keep.append(mu)
+            g.cfg_is_masked_until = C.cast(mu, C.c_void_p)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        self._lib.check(self._lib.mmi_lm_streaming_start_guided(lm._handle, int(batch_size), C.byref(s), C.byref(g), self._stream()))
+        del keep
         self._batch = int(batch_size)
 
     def _stop_streaming(self) -> None:
@@ -287,6 +345,19 @@ class LMGen:
             forced[:, 1:] = depformer_replace_tokens.to(self.device).squeeze(-1)
         out, _, _ = self._step(input_tokens, False, None, forced)
         return out
+
+    @torch.no_grad()
+    def step_with_extra_heads(self, input_tokens: torch.Tensor, depformer_replace_tokens: Optional[torch.Tensor] = None):
+        """lm.py:793-807: `step` plus softmax(extra_head(transformer_out)) for every extra head, each [model rows, 1, dim]."""
+        out = self.step(input_tokens, depformer_replace_tokens)
+        if out is None:
+            return None
+        cfg = self.lm_model.config
+        rows = int(self._lib.mmi_lm_model_rows(self.lm_model._handle))
+        probs = torch.empty(rows, max(cfg.extra_heads_num_heads, 1), cfg.extra_heads_dim, device=self.device, dtype=torch.float32)
+        self._lib.check(self._lib.mmi_lm_extra_heads(self.lm_model._handle, probs.data_ptr(), self._stream()))
+        heads = [probs[:, h][:, None].to(torch.bfloat16) for h in range(cfg.extra_heads_num_heads)]
+        return out, heads
 
     @torch.no_grad()
     def step_with_taps(self, input_tokens: torch.Tensor, noise: Optional[torch.Tensor] = None,

@@ -265,3 +265,49 @@ def check_cfg_scenario(g, cfg, name, start, step, heads=None):
                 if g["masks"][s, b]:
                     assert np.abs(pr[b] - g["d_heads"][s, b]).max() <= 0.02, f"extra heads step {s} row {b}"
                     assert np.abs(pr[b].sum(-1) - 1).max() < 0.02
+
+
+def check_cfg_engine(device, lib, name):
+    """Engine vs the reference's guided / conditioned runs (tests/golden/lm_cfg.npz), same checker as the oracle pin."""
+    from moshi_amd.lm import ConditionFuser
+    g, cfg, sd = load_cfg_golden()
+    sc = CFG_SCENARIOS[name]
+    if sc.get("heads"):
+        from dataclasses import replace
+        cfg = replace(cfg, extra_heads_num_heads=int(g["heads_w"].shape[0]), extra_heads_dim=int(g["heads_w"].shape[1]))
+    else:
+        sd = {k: v for k, v in sd.items() if not k.startswith("extra_heads.")}
+    B = g["masks"].shape[1]
+    rows = 2 * B if sc["cfg_coef"] != 1.0 else B
+    lm = LMModel(sd, cfg, device=device, max_batch=rows, lib=lib, fuser=ConditionFuser({"sum": ["c"]}) if sc.get("cond") else None)
+    state = {}
+
+    def start(cfg_coef, cfg_is_no_text, cfg_is_masked_until, condition_sum):
+        cond = None
+        if condition_sum is not None:
+            t = torch.from_numpy(np.asarray(condition_sum)).to(torch.bfloat16)[:, None]        # [rows, 1, dim]
+            cond = {"c": (t, torch.ones(t.shape[:2], dtype=torch.bool))}
+        gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, cfg_coef=cfg_coef, cfg_is_no_text=cfg_is_no_text,
+                    cfg_is_masked_until=cfg_is_masked_until, condition_tensors=cond)
+        gen.streaming_forever(B)
+        state["gen"] = gen
+
+    def step(codes, forced, mask, reset):
+        gen = state["gen"]
+        if reset is not None:
+            gen.reset_streaming(torch.from_numpy(reset).to(device))
+        gen.set_exec_mask(torch.from_numpy(mask).to(device))
+        out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+        return out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+
+    def heads():
+        gen = state["gen"]
+        rows_ = int(gen._lib.mmi_lm_model_rows(lm._handle))
+        probs = torch.empty(rows_, cfg.extra_heads_num_heads, cfg.extra_heads_dim, device=device, dtype=torch.float32)
+        gen._lib.check(gen._lib.mmi_lm_extra_heads(lm._handle, probs.data_ptr(), gen._stream()))
+        return probs.cpu().numpy()
+    try:
+        check_cfg_scenario(g, cfg, name, start, step, heads)
+    finally:
+        if "gen" in state:
+            state["gen"]._stop_streaming()

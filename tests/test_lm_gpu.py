@@ -67,6 +67,40 @@ def test_fp8_full_width_layers_match_oracle(gpu_lib):
     lm_cases.oracle_vs_engine(DEV, None, cfg, seed=10, B=3, S=3, use_masks=True, quantize="fp8")
 
 
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_guidance_conditioning_and_extra_heads_match_reference_golden(gpu_lib, name):
+    """SURVEY.md 8f-3 / 8f-4 on the GPU: classifier-free guidance (masked-until / no-text / condition tensors), a `sum`
+    condition and extra heads against the reference's own LMGen runs (tests/golden/lm_cfg.npz)."""
+    lm_cases.check_cfg_engine(DEV, None, name)
+
+
+def test_guided_full_width_matches_oracle(gpu_lib):
+    """Guidance at the 7B layer shapes (2 temporal layers): 2 x 3 model rows, masked-until + condition, vs the oracle."""
+    from moshi_amd.lm import ConditionFuser
+    from oracle.lm_oracle import LMOracle
+    cfg = LMConfig(num_layers=2, context=64)
+    sd = random_lm_state_dict(cfg, seed=12)
+    B, S = 3, 3
+    rng = np.random.default_rng(4)
+    cond = torch.from_numpy(0.5 * rng.standard_normal((2 * B, 1, cfg.dim)).astype(np.float32)).to(torch.bfloat16)
+    lm = LMModel(sd, cfg, device=DEV, max_batch=2 * B, fuser=ConditionFuser({"sum": ["c"]}))
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, cfg_coef=2.0, cfg_is_masked_until=[0, 1, 2],
+                condition_tensors={"c": (cond, None)})
+    orc = LMOracle(sd, cfg)
+    orc.streaming(B, cfg_coef=2.0, cfg_is_masked_until=[0, 1, 2], condition_sum=cond[:, 0].float().numpy())
+    with gen.streaming(B):
+        for s in range(S):
+            codes = rng.integers(0, cfg.card, (B, 8, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(DEV), forced_tokens=torch.from_numpy(forced).to(DEV))
+            assert np.array_equal(out.cpu().numpy(), oo)
+            for b in range(B):
+                assert lm_cases.logits_close(tl[b].cpu().numpy(), otl[b], lm_cases.GUIDED_WIDEN), f"step {s} row {b}: text logits"
+                for k in range(cfg.dep_q):
+                    assert lm_cases.logits_close(al[b, k].cpu().numpy(), oal[b, k], lm_cases.GUIDED_WIDEN), f"step {s} row {b} cb {k}"
+
+
 def test_full_width_layers_match_oracle(gpu_lib):
     """Moshi-7B layer shapes (dim 4096, 32 heads x 128, FFN 11264, text head 32000; depformer 1024 x 6 layers x 8 steps)
     with 2 temporal layers, so that the numpy oracle finishes in seconds: exercises every GEMM tile variant,

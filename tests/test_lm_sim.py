@@ -154,5 +154,20 @@ def test_none_during_delay_and_errors(sim_lib):
             gen.step(torch.zeros(3, 7, 1, dtype=torch.long))  # too few user codebooks (lm.py:683-686)
         out = gen.step(torch.zeros(3, 9, 1, dtype=torch.long))  # extra rows are ignored (lm.py:688-689)
         assert out.shape == (3, 9, 1) and out.dtype == torch.int64
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="no fuser"):   # lm.py:600-603
         lm_cases.LMGen(gen.lm_model, cfg_coef=2.0)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_guidance_conditioning_and_extra_heads_match_reference_golden(sim_lib, name):
+    """classifier-free guidance (a: masked-until, b: no-text, c: condition tensors), a `sum`
+    condition and extra heads (d), against the reference's own LMGen runs (tests/golden/lm_cfg.npz)."""
+    lm_cases.check_cfg_engine("cpu", sim_lib, name)
+
+
+def test_guided_batch_must_fit_twice(sim_lib):
+    cfg = tiny_lm_config()
+    lm = lm_cases.LMModel(random_lm_state_dict(cfg, seed=1), cfg, device="cpu", max_batch=3, lib=sim_lib)
+    gen = lm_cases.LMGen(lm, cfg_coef=2.0, cfg_is_no_text=True)
+    with pytest.raises(AssertionError, match="two model rows per session"):
+        gen.streaming_forever(2)
