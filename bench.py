@@ -30,7 +30,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm", "served"],
+                    help="served: the duplex step driven through the session batcher with HOST PCM in / PCM + tokens out "
+                         "(pinned staging, H2D + D2H and one synchronisation per step included): the PCIe-inclusive rate")
     ap.add_argument("--batch", type=int, default=32, help="sessions per GPU (BASELINE.json configs[3]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger", type=int, default=8, help="frames between session starts (SURVEY.md 8d C4)")
@@ -112,6 +114,53 @@ def cpu_baseline_mimi(cfg, sd, seconds=12.0):
             "sample": f"{n} Mimi encode+decode frames, B=1, numpy oracle (BLAS threads = host cores)"}
 
 
+def served_main(args, rank, world, dist, dev, mimi, mcfg, B):
+    """Every slot of a SessionBatcher holds a live channel that receives one 80 ms frame of host PCM per step; a step =
+    push x B, mmi_batcher_step (H2D, encode -> LMGen.step -> decode, D2H, sync), pop x B."""
+    from bench_lm import make_lm
+    from moshi_amd.batcher import SessionBatcher
+    lm = make_lm(dev, B, args, streaming=False)
+    batcher = SessionBatcher(mimi, lm, B, seed=1234 + rank)
+    rng = np.random.default_rng(1000 + rank)
+    frames = (0.1 * rng.standard_normal((B, mcfg.frame_size))).astype(np.float32)
+    chans = [batcher.open() for _ in range(B)]
+
+    def step():
+        for i, ch in enumerate(chans):
+            batcher.push(ch, frames[i])
+        n = batcher.step()
+        assert n == B
+        got = sum(batcher.pop(ch) is not None for ch in chans)
+        return got
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    played = 0
+    for _ in range(args.steps):
+        played += step()
+    torch.cuda.synchronize(dev)
+    dt = job_time(time.perf_counter() - t0, dist, dev)
+    if dist is not None:
+        dist.barrier()
+    st = batcher.stats()
+    out = {"metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B, host PCM in/out through the session batcher",
+           "value": job_value(world, B, args.steps, dt), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "device_ms_last_step": st["last_step_ms"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.quant == "none" else args.quant,
+           "data": "synthetic",
+           "config": {"workload": "full duplex through mmi_batcher_* (BASELINE configs[3] sessions, PCIe + host routing included)",
+                      "sessions_per_gpu": B, "frames_played": played, "parallelism": f"dp{world} (independent sessions, no collective)"}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    batcher.close_all()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank, local, world, dist = dist_setup(args.gpus)
@@ -129,6 +178,8 @@ def main():
     from moshi_amd.weights import mimi_state_spec
     msd = replicated_state_dict(lambda: random_mimi_state_dict(mcfg, seed=1234, device=dev), mimi_state_spec(mcfg), torch.float32, dev)
     mimi = MimiModel(msd, mcfg, device=dev, max_batch=B, num_codebooks=8)
+    if workload == "served":
+        return served_main(args, rank, world, dist, dev, mimi, mcfg, B)
     mimi.streaming_forever(B)
     lm_gen = None
     if workload in ("duplex", "lm"):

@@ -25,7 +25,7 @@ def replicated_state_dict(draw, spec, dtype, dev):
     return broadcast_state_dict(sd, spec, dtype, dev, src=0)
 
 
-def make_lm(dev, B, args):
+def make_lm(dev, B, args, streaming=True):
     from moshi_amd.config import LMConfig
     from moshi_amd.lm import LMGen, LMModel
     from moshi_amd.weights import lm_state_spec, random_lm_state_dict
@@ -42,6 +42,8 @@ def make_lm(dev, B, args):
     lm = LMModel(sd, cfg, device=dev, max_batch=B)
     del sd
     torch.cuda.empty_cache()
+    if not streaming:
+        return lm
     gen = LMGen(lm, use_sampling=True, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25, seed=1234 + int(os.environ.get("RANK", "0")))
     gen.streaming_forever(B)
     return gen

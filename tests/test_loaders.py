@@ -1,0 +1,106 @@
+"""Checkpoint loading: safetensors files with the reference's keys and config dictionaries -> engine models,
+quantised export.  Runs on the CPU kernel simulator."""
+import json
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import load_file, save_file
+
+from moshi_amd import loaders
+from moshi_amd.config import tiny_lm_config, tiny_mimi_config
+from moshi_amd.lm import LMGen
+from moshi_amd.weights import random_lm_state_dict, random_mimi_state_dict
+
+
+def tiny_lm_kwargs():
+    kw = tiny_lm_config().reference_kwargs()          # the dict the reference's LMModel(**kw) takes (== config.json layout)
+    kw["depformer_causal"] = True                     # deprecated key still present in released configs (loaders.py:394)
+    return kw
+
+
+def greedy_tokens(lm, steps=4, B=2):
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    rng = np.random.default_rng(0)
+    outs = []
+    with gen.streaming(B):
+        for _ in range(steps):
+            outs.append(gen.step(torch.from_numpy(rng.integers(0, lm.card, (B, 8, 1)))).numpy())
+    return np.stack(outs)
+
+
+def test_moshi_checkpoint_roundtrip_and_config_mapping(sim_lib, tmp_path):
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=8)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    lm = loaders.get_moshi_lm(tmp_path / "model.safetensors", tiny_lm_kwargs(), device="cpu", max_batch=2, lib=sim_lib)
+    assert lm.config == cfg
+    from moshi_amd.lm import LMModel
+    ref = greedy_tokens(LMModel(sd, cfg, device="cpu", max_batch=2, lib=sim_lib))
+    assert np.array_equal(greedy_tokens(lm), ref)
+    # torch.save layout of training checkpoints (loaders.py:424-426)
+    torch.save({"fsdp_best_state": {"model": sd}}, tmp_path / "model.pt")
+    lm2 = loaders.get_moshi_lm(tmp_path / "model.pt", tiny_lm_kwargs(), device="cpu", max_batch=2, lib=sim_lib)
+    assert np.array_equal(greedy_tokens(lm2), ref)
+
+
+def test_unsupported_options_are_refused_not_ignored():
+    kw = tiny_lm_kwargs()
+    with pytest.raises(ValueError, match="norm"):
+        loaders.lm_config_from_kwargs({**kw, "norm": "layer_norm"})
+    with pytest.raises(ValueError, match="depformer_weights_per_step"):
+        loaders.lm_config_from_kwargs({**kw, "depformer_weights_per_step": False})
+    with pytest.raises(NotImplementedError, match="LoRA"):
+        loaders.get_moshi_lm(None, {**kw, "lora": True}, device="cpu")
+    mc = tiny_mimi_config().reference_kwargs()
+    mc["seanet"]["pad_mode"] = "reflect"
+    with pytest.raises(ValueError, match="pad_mode"):
+        loaders.mimi_config_from_dict(mc)
+    with pytest.raises(RuntimeError, match="no network"):
+        loaders.CheckpointInfo.from_hf_repo("kyutai/moshiko-pytorch-bf16")
+
+
+def test_default_configs_are_the_released_models():
+    from moshi_amd.config import LMConfig, MimiConfig
+    assert loaders.lm_config_from_kwargs(LMConfig().reference_kwargs()) == LMConfig()
+    assert loaders.mimi_config_from_dict(MimiConfig().reference_kwargs()) == MimiConfig()
+    assert loaders.lm_config_from_kwargs(None) == LMConfig() and loaders.mimi_config_from_dict(None) == MimiConfig()
+
+
+@pytest.mark.parametrize("fmt,dtype,scale_key", [("int8", torch.int8, "_scb"), ("fp8", torch.float8_e4m3fn, "_scale")])
+def test_export_quantized_writes_the_storage_the_engine_loads(sim_lib, tmp_path, fmt, dtype, scale_key):
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=9)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    info = loaders.export_quantized(tmp_path / "model.safetensors", tmp_path / f"model.{fmt}.safetensors", fmt)
+    q = load_file(str(tmp_path / f"model.{fmt}.safetensors"))
+    k = "transformer.layers.0.self_attn.in_projs.0.weight"
+    assert q[k].dtype == dtype and q[k + scale_key].dtype == torch.float32 and q["emb.0.weight"].dtype == torch.bfloat16
+    assert info["quantized"] == sum(v.dtype == dtype for v in q.values()) > 0
+    lm = loaders.get_moshi_lm(tmp_path / f"model.{fmt}.safetensors", {**tiny_lm_kwargs(), "quantize": True}, device="cpu", max_batch=2,
+                              lib=sim_lib)
+    assert lm.quantized
+    from moshi_amd.lm import LMModel
+    ref = greedy_tokens(LMModel(sd, cfg, device="cpu", max_batch=2, lib=sim_lib, quantize=True if fmt == "int8" else "fp8"))
+    assert np.array_equal(greedy_tokens(lm), ref)
+
+
+def test_checkpoint_info_from_a_released_style_directory(sim_lib, tmp_path):
+    lcfg = tiny_lm_config()
+    mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.dep_q)
+    save_file(random_lm_state_dict(lcfg, seed=3), str(tmp_path / "model.safetensors"))
+    save_file(random_mimi_state_dict(mcfg, seed=4), str(tmp_path / "mimi.safetensors"))
+    conf = {**tiny_lm_kwargs(), "moshi_name": "model.safetensors", "mimi_name": "hf://kyutai/some-repo/mimi.safetensors",
+            "tokenizer_name": "tokenizer.model", "model_type": "hibiki", "lm_gen_config": {"temp": 0.7},
+            "mimi_config": mcfg.reference_kwargs(), "fuser": {"sum": ["description"], "cross": []}}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    info = loaders.CheckpointInfo.from_local(tmp_path)
+    assert info.model_type == "hibiki" and info.lm_gen_config == {"temp": 0.7} and info.mimi_weights == tmp_path / "mimi.safetensors"
+    mimi = info.get_mimi(device="cpu", max_batch=2, lib=sim_lib)
+    assert mimi.num_codebooks == 8 and mimi.frame_size == mcfg.frame_size and mimi.cardinality == lcfg.card
+    lm = info.get_moshi(device="cpu", max_batch=2, lib=sim_lib)
+    assert lm.fuser is not None and lm.fuser.fuse2cond["sum"] == ["description"]
+    x = torch.zeros(1, 1, mcfg.frame_size)
+    with mimi.streaming(1):
+        assert mimi.encode(x).shape == (1, 8, 1)
