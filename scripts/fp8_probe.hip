@@ -112,5 +112,31 @@ int main() {
         worst = fmax(worst, fabs(D[i * 16 + j] - ref) / (mag + 1e-30));
     }
     printf("mfma 16x16x32 fp8: worst |err| / sum|products| = %.3g\n", worst);
+    // ---- 3. are subnormal inputs honoured?  A = all subnormal codes (0x01..0x07), B = 1.0
+    for (int i = 0; i < 512; ++i) { A[i] = (uint8_t)(1 + i % 7); B[i] = 0x38; }
+    hipMemcpy(dA, A, 512, hipMemcpyHostToDevice); hipMemcpy(dB, B, 512, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_mfma32, 1, 64, 0, 0, dA, dB, dD);
+    hipMemcpy(D, dD, 1024 * 4, hipMemcpyDeviceToHost);
+    { double ref = 0; for (int k = 0; k < 16; ++k) ref += sw_dec(A[k]);
+      printf("subnormal A x 1.0: got %.9g expected %.9g (0 would mean flush-to-zero)\n", D[0], ref); }
+    // ---- 4. one large product + 15 small ones: how many bits below the largest product survive?
+    for (int sh = 4; sh <= 20; sh += 2) {
+        // A row 0: 448 (0x7e) at k=0, then 1.0 (0x38); B col 0: 1.0 at k=0, then 2^-sh/... use B = small value code
+        for (int i = 0; i < 512; ++i) { A[i] = 0x38; B[i] = 0x38; }
+        A[0] = 0x7e;                                   // 448
+        // small = 448 * 2^-sh  -> choose A[k]=x, B[k]=y with x*y = small: x = 2^-a, y = 2^-b
+        const int e_small = 8 - sh;                    // 448*2^-sh ~ 1.75 * 2^(8-sh)
+        int ea = e_small / 2, eb = e_small - ea;       // exponents of the two factors (1.0 * 2^e)
+        auto code = [](int e) { return (uint8_t)(((e + 7) << 3)); };
+        bool ok = ea + 7 >= 1 && eb + 7 >= 1 && ea + 7 <= 15 && eb + 7 <= 15;
+        if (!ok) continue;
+        for (int k = 1; k < 16; ++k) { A[k] = code(ea); B[k * 32] = code(eb); }
+        B[0] = 0x38;
+        hipMemcpy(dA, A, 512, hipMemcpyHostToDevice); hipMemcpy(dB, B, 512, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_mfma32, 1, 64, 0, 0, dA, dB, dD);
+        hipMemcpy(D, dD, 1024 * 4, hipMemcpyDeviceToHost);
+        const double small = ldexp(1.0, ea + eb), ref = 448.0 + 15 * small;
+        printf("448 + 15 x 2^%d: got %.9g expected %.9g (small part kept: %.3f)\n", ea + eb, D[0], ref, (D[0] - 448.0) / (15 * small));
+    }
     return 0;
 }
