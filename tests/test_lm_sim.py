@@ -71,6 +71,13 @@ def test_fp8_weights_on_the_fp8_mfma_match_the_fp8_oracle(sim_lib, B, input_scal
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=90 + B, B=B, S=3, quantize="fp8", input_scale=input_scale)
 
 
+def test_fp8_hardware_yardstick_runs_on_the_simulator(sim_lib):
+    """The check the GPU tests hold the fp8 engine to (tests/lm_cases.py "fp8 on hardware"): on the simulator, whose MFMA
+    accumulates exactly, the engine coincides with the exact oracle, far inside the yardstick."""
+    msg = lm_cases.fp8_engine_within_format_conditioning("cpu", sim_lib, tiny_lm_config(), seed=92, B=2, S=2)
+    assert msg.startswith("engine: max-rel 0.000/0.0")
+
+
 def test_fp8_without_norm_fusion_and_with_split_k(sim_lib, monkeypatch):
     monkeypatch.setenv("MMI_NO_NORM_FUSION", "1")
     monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
