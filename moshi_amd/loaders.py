@@ -110,7 +110,8 @@ def get_condition_fuser(cfg: dict) -> ConditionFuser:    # loaders.py:476-483
 
 def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]] = None, device: torch.device | str = "cuda",
                  dtype: torch.dtype = torch.bfloat16, lora_weights: str | Path | None = None, fuse_lora: bool = False,
-                 lm_kwargs_overrides: Optional[dict] = None, max_batch: int = 32, lib=None, state_patch=None) -> LMModel:
+                 lm_kwargs_overrides: Optional[dict] = None, max_batch: int = 32, lib=None, state_patch=None,
+                 quantize: Optional[bool | str] = None) -> LMModel:
     """loaders.get_moshi_lm (loaders.py:366-446): bf16 weights; `quantize` in the config (a `.q8` checkpoint carrying int8
     `weight` + `weight_scb`, or fp8 `weight` + `weight_scale`) is taken from the tensors themselves."""
     assert dtype == torch.bfloat16, "the engine computes the LM in bf16 (fp32 accumulation), like the reference's default"
@@ -126,7 +127,10 @@ def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]
                                       "output as LMGen(condition_tensors=...)")
     fuser = get_condition_fuser(kw) if kw is not None and kw.get("fuser") is not None else None
     cfg = lm_config_from_kwargs(kw)
-    quantize = bool(kw.get("quantize", False)) if kw is not None else False
+    if quantize is None:                                # True / "int8": the reference's int8 storage; "fp8": the fp8 MFMA path
+        quantize = bool(kw.get("quantize", False)) if kw is not None else False
+    if quantize == "int8":
+        quantize = True
     if filename is None:
         from .weights import random_lm_state_dict
         state = random_lm_state_dict(cfg, seed=0)
@@ -136,7 +140,7 @@ def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]
     if state_patch is not None:
         state_patch(state)
     already = any(v.dtype in (torch.int8, torch.float8_e4m3fn) for v in state.values())
-    return LMModel(state, cfg, device=device, max_batch=max_batch, lib=lib, quantize=quantize and not already, fuser=fuser)
+    return LMModel(state, cfg, device=device, max_batch=max_batch, lib=lib, quantize=False if already else quantize, fuser=fuser)
 
 
 def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8") -> Dict[str, int]:
