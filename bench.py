@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--stagger", type=int, default=8, help="frames between session starts (SURVEY.md 8d C4)")
     ap.add_argument("--quant", default="none", choices=["none", "q8", "fp8"],
                     help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears widened to bf16 in registers; fp8 = e4m3 linears on the fp8 MFMA")
+    ap.add_argument("--kv", default="bf16", choices=["bf16", "fp8"], help="KV ring of the temporal transformer: the reference's bf16, or e4m3 (half the attention stream)")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
     return ap.parse_args()
 
@@ -249,6 +250,7 @@ def main():
                    "sessions_per_gpu": B, "parallelism": f"dp{world} (independent sessions, no collective)",
                    "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model" + {"none": "", "q8": ", LM linears row-wise int8", "fp8": ", LM linears row-wise e4m3"}[args.quant],
                    "sampling": "temp .8/.7 top-k 250/25 (LMGen defaults), on-device RNG",
+                   "kv_cache": args.kv,
                    "session_stagger_frames": args.stagger if lm_gen is not None else 0,
                    "kv_positions_at_end": ([args.stagger * b + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
     }

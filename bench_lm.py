@@ -29,7 +29,7 @@ def make_lm(dev, B, args, streaming=True):
     from moshi_amd.config import LMConfig
     from moshi_amd.lm import LMGen, LMModel
     from moshi_amd.weights import lm_state_spec, random_lm_state_dict
-    cfg = LMConfig()
+    cfg = LMConfig(kv_cache_dtype=getattr(args, "kv", "bf16"))
     if args.lm_layers:
         cfg.num_layers = args.lm_layers
     sd = replicated_state_dict(lambda: random_lm_state_dict(cfg, seed=4242, device=dev), lm_state_spec(cfg), torch.bfloat16, dev)

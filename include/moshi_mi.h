@@ -165,6 +165,8 @@ typedef struct mmi_lm_cfg {
     int32_t existing_text_padding_id; /* 3 */
     int32_t extra_heads_num_heads;    /* 0: nn.Linear(dim, extra_heads_dim) heads on the transformer output (lm.py:101-102, 224-226) */
     int32_t extra_heads_dim;          /* 6 */
+    int32_t kv_cache_dtype;           /* 0 / MMI_BF16: the reference's bf16 ring (transformer.py:453-455); MMI_F8E4M3: e4m3 ring -
+                                         half the attention stream and half the per-session state (SURVEY.md 8d C5 "fp8 KV") */
 } mmi_lm_cfg;
 
 /* LMGen constructor arguments that change what step computes (lm.py:557-574). */

@@ -46,7 +46,7 @@ class LMCfg(C.Structure):
                 ("depformer_dim", C.c_int32), ("depformer_num_heads", C.c_int32),
                 ("depformer_num_layers", C.c_int32), ("depformer_ffn_hidden", C.c_int32),
                 ("delays", C.c_int32 * 64), ("existing_text_padding_id", C.c_int32),
-                ("extra_heads_num_heads", C.c_int32), ("extra_heads_dim", C.c_int32)]
+                ("extra_heads_num_heads", C.c_int32), ("extra_heads_dim", C.c_int32), ("kv_cache_dtype", C.c_int32)]
 
 
 class Sampling(C.Structure):

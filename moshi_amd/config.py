@@ -111,6 +111,7 @@ class LMConfig:
     delays: List[int] = field(default_factory=lambda: [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1])
     extra_heads_num_heads: int = 0      # lm.py:101-102: linear heads on the transformer output (step_with_extra_heads)
     extra_heads_dim: int = 6
+    kv_cache_dtype: str = "bf16"        # "fp8": e4m3 ring for the temporal transformer's keys / values (engine option)
 
     @staticmethod
     def _gating_hidden(dim: int, dim_feedforward: int) -> int:

@@ -439,8 +439,18 @@ int attn_splits(const mmi_lm_cfg& c, int B) {
     return want < chunks ? want : chunks;
 }
 
-int launch_attn_split(hipStream_t s, const LmAttnArgs& a) {
+int launch_attn_split(hipStream_t s, const LmAttnArgs& a, bool kv8) {
     dim3 grid(a.B * a.H, a.NS);
+    if (kv8) {
+        switch (a.Dh) {
+            case 128: MMI_LAUNCH((k_lm_attn_split<128, true>), grid, 256, 0, s, a); break;
+            case 64: MMI_LAUNCH((k_lm_attn_split<64, true>), grid, 256, 0, s, a); break;
+            case 32: MMI_LAUNCH((k_lm_attn_split<32, true>), grid, 256, 0, s, a); break;
+            default: return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be 32, 64 or 128");
+        }
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
     switch (a.Dh) {
         case 128: MMI_LAUNCH((k_lm_attn_split<128>), grid, 256, 0, s, a); break;
         case 64: MMI_LAUNCH((k_lm_attn_split<64>), grid, 256, 0, s, a); break;
@@ -487,7 +497,8 @@ int build_program(mmi_lm* lm) {
     }
     // ---- temporal transformer
     const int NS = attn_splits(c, B);
-    const size_t kv_layer = (size_t)B * H * c.context * Dh;
+    const bool kv8 = c.kv_cache_dtype == MMI_F8E4M3;
+    const size_t kv_layer = (size_t)B * H * c.context * Dh / (kv8 ? 2 : 1);     // in uint16 units: an fp8 ring is half as large
     int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
@@ -501,13 +512,13 @@ int build_program(mmi_lm* lm) {
             GemmArgs ga;
             memset(&ga, 0, sizeof(ga));
             ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
-            ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context;
+            ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context; ga.kv8 = kv8 ? 1 : 0;
             ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
             P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
         }
         P.add([=](hipStream_t s) {
-            int rc = launch_attn_split(s, a);
+            int rc = launch_attn_split(s, a, kv8);
             if (rc) return rc;
             if (a.NS > 1) MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, a);
             MMI_CHECK_LAUNCH();
@@ -569,6 +580,9 @@ int check_cfg(const mmi_lm_cfg& c) {
     const int Dh = c.dim / c.num_heads, Dhd = c.depformer_dim / c.depformer_num_heads;
     if (Dh != 32 && Dh != 64 && Dh != 128) return mmi_fail(MMI_ERR_UNSUPPORTED, "temporal head dim must be 32/64/128");
     if (Dhd > 64 || Dhd < 1) return mmi_fail(MMI_ERR_UNSUPPORTED, "depformer head dim must be <= 64");
+    if (c.kv_cache_dtype != 0 && c.kv_cache_dtype != MMI_BF16 && c.kv_cache_dtype != MMI_F8E4M3)
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "kv_cache_dtype must be MMI_BF16 or MMI_F8E4M3");
+    if (c.kv_cache_dtype == MMI_F8E4M3 && (c.dim / c.num_heads) % 16) return mmi_fail(MMI_ERR_UNSUPPORTED, "fp8 KV needs a head dim multiple of 16");
     if (c.card % 8 || c.text_card_out % 8 || c.card > 32768 || c.text_card_out > 32768)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "vocabulary sizes must be multiples of 8 and at most 32768");
     if (c.dep_q < 1 || c.dep_q > 16 || c.n_q < c.dep_q || c.n_q + 1 > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "bad n_q / dep_q");
@@ -741,7 +755,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     const int NS = attn_splits(c, B);
     auto fail = [&](int code) { lm->streaming = true; mmi_lm_streaming_stop(lm); return code; };
     MmiArena& A = lm->st;
-    const size_t kvn = (size_t)c.num_layers * B * H * c.context * Dh;
+    const size_t kvn = (size_t)c.num_layers * B * H * c.context * Dh / (c.kv_cache_dtype == MMI_F8E4M3 ? 2 : 1);   // uint16 units
     const size_t dkvn = (size_t)c.depformer_num_layers * B * Hd * c.dep_q * Dhd;
     bool ok = true;
     ok &= hipSuccess == A.alloc(&lm->exec, (size_t)G);

@@ -171,6 +171,7 @@ struct GemmArgs {
     int H, Dh, cap;
     float max_period;
     const float* rope;      // [B][Dh/2][2]: (cos, sin) of the new position's angles, filled once per step by k_lm_prepare
+    int kv8;                // the ring holds e4m3 bytes instead of bf16 (fp8 KV cache: half the attention stream)
     // k_gemm_xp_norm: RMSNorm of the input rows fused in front of the GEMM (xp holds the un-normalised rows)
     const uint16_t* alpha;  // [D]
     int D;                  // features of a row (the mean is over D, not the padded K)
@@ -306,6 +307,14 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                     v8[2 * j] = re * c - im * sn;
                     v8[2 * j + 1] = re * sn + im * c;
                 }
+            }
+            if (sec != 0 && a.kv8) {   // fp8 ring: the bf16 k / v values (k after RoPE, as the bf16 ring would hold them) -> e4m3
+                uint8_t* d8 = reinterpret_cast<uint8_t*>(sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.Dh + d0;
+                u32x2 o8;
+                o8[0] = mmi_cvt_fp8x4(mmi_round_bf16(v8[0]), mmi_round_bf16(v8[1]), mmi_round_bf16(v8[2]), mmi_round_bf16(v8[3]));
+                o8[1] = mmi_cvt_fp8x4(mmi_round_bf16(v8[4]), mmi_round_bf16(v8[5]), mmi_round_bf16(v8[6]), mmi_round_bf16(v8[7]));
+                *reinterpret_cast<u32x2*>(d8) = o8;
+                continue;
             }
             uint16_t* dst;
             if (sec == 0) dst = a.qrot + (long)b * HD + hn;
@@ -741,9 +750,13 @@ struct LmAttnArgs {
 // chunks y, y+NS, ... of the ring with an online softmax; each 16-byte load covers 8 dims of one key row, DH/8 lanes share
 // a row, so one wave instruction reads 64/(DH/8) consecutive rows = 1 KiB contiguous.  NS == 1 (enough (b,h) pairs to
 // fill the chip): the normalised output goes straight to out_proj's packed input; otherwise partials for the combine.
-template <int DH>
+// KV8: the ring holds e4m3 bytes (fp8 KV cache): a 16-byte load then covers 16 dims, DH/16 lanes share a row and one wave
+// instruction reads twice as many rows; the values are widened exactly (v_cvt_pk_f32_fp8) and everything else is unchanged.
+template <int DH, bool KV8 = false>
 __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
-    constexpr int LPR = DH / 8;        // lanes per row
+    constexpr int EPL = KV8 ? 16 : 8;  // elements per lane (16 bytes)
+    constexpr int ES = KV8 ? 1 : 2;    // bytes per element
+    constexpr int LPR = DH / EPL;      // lanes per row
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
     constexpr int CH = MMI_ATTN_CHUNK;
     const int bh = blockIdx.x, b = bh / a.H;
@@ -756,23 +769,37 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     MMI_SHARED float wred[8];
     MMI_SHARED float ored[4 * DH];
     const int seg = lane % LPR, rsub = lane / LPR;
-    float qv[8];
-    {
-        u32x4 qq = *reinterpret_cast<const u32x4*>(a.qrot + (long)bh * DH + seg * 8);
+    float qv[EPL];
+#pragma unroll
+    for (int v = 0; v < EPL / 8; ++v) {
+        u32x4 qq = *reinterpret_cast<const u32x4*>(a.qrot + (long)bh * DH + seg * EPL + v * 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            qv[2 * q] = mmi_bf16_to_f32((uint16_t)(qq[q] & 0xffffu));
-            qv[2 * q + 1] = mmi_bf16_to_f32((uint16_t)(qq[q] >> 16));
+            qv[v * 8 + 2 * q] = mmi_bf16_to_f32((uint16_t)(qq[q] & 0xffffu));
+            qv[v * 8 + 2 * q + 1] = mmi_bf16_to_f32((uint16_t)(qq[q] >> 16));
         }
     }
-    const uint16_t* kbase = a.kc + (long)bh * a.cap * DH;
-    const uint16_t* vbase = a.vc + (long)bh * a.cap * DH;
+    // 16 bytes of a ring row -> EPL fp32 values
+    auto widen = [](const u32x4& r, float* f) {
+        if constexpr (KV8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mmi_fp8x4_to_f32(r[q], f + 4 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f[2 * q] = mmi_bf16_to_f32((uint16_t)(r[q] & 0xffffu));
+                f[2 * q + 1] = mmi_bf16_to_f32((uint16_t)(r[q] >> 16));
+            }
+        }
+    };
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * DH * ES;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr int PER_WAVE = CH / 4;
     float m_run = -INFINITY, l_run = 0.f;
-    float acc[8];
+    float acc[EPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     for (int c0 = (int)blockIdx.y * CH; c0 < L; c0 += (int)gridDim.y * CH) {     // block-uniform trip count
         // ---- scores of this chunk: all of the wave's key rows are requested up front (unconditional loads from a clamped
         // slot; a load under `if (valid)` would be serialised behind s_waitcnt vmcnt(0)), then reduced
@@ -784,7 +811,7 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
-                kk[i] = *reinterpret_cast<const u32x4*>(kbase + (long)slot * DH + seg * 8);
+                kk[i] = *reinterpret_cast<const u32x4*>(kbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -798,11 +825,10 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
                     valid = pos >= 0 && dq >= 0 && dq < a.context;
                 }
                 float dot = 0.f;
+                float kf[EPL];
+                widen(kk[i], kf);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    dot += qv[2 * q] * mmi_bf16_to_f32((uint16_t)(kk[i][q] & 0xffffu));
-                    dot += qv[2 * q + 1] * mmi_bf16_to_f32((uint16_t)(kk[i][q] >> 16));
-                }
+                for (int e = 0; e < EPL; ++e) dot += qv[e] * kf[e];
 #pragma unroll
                 for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
                 if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
@@ -830,7 +856,7 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         l_run = l_run * resc + sum;
         m_run = m_new;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= resc;
+        for (int e = 0; e < EPL; ++e) acc[e] *= resc;
         // ---- P.V (value rows requested up front as well; rows past L carry p = 0 and finite ring contents)
 #pragma unroll 1
         for (int h0 = 0; h0 < NIT; h0 += NB) {
@@ -838,28 +864,27 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
-                vv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)slot * DH + seg * 8);
+                vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
                 const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
+                float vf[EPL];
+                widen(vv[i], vf);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[2 * q] += pr * mmi_bf16_to_f32((uint16_t)(vv[i][q] & 0xffffu));
-                    acc[2 * q + 1] += pr * mmi_bf16_to_f32((uint16_t)(vv[i][q] >> 16));
-                }
+                for (int e = 0; e < EPL; ++e) acc[e] += pr * vf[e];
             }
         }
         __syncthreads();     // sc / wred are rewritten by the next chunk
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < EPL; ++e)
 #pragma unroll
         for (int m = 32; m >= LPR; m >>= 1) acc[e] += mmi_shfl_xor(acc[e], m);
     if (rsub == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ored[wave * DH + seg * 8 + e] = acc[e];
+        for (int e = 0; e < EPL; ++e) ored[wave * DH + seg * EPL + e] = acc[e];
     }
     __syncthreads();
     if (tid < DH) {

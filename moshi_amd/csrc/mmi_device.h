@@ -81,6 +81,11 @@ __device__ __forceinline__ uint32_t mmi_cvt_fp8x4(float a, float b, float c, flo
     r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
     return (uint32_t)r;
 }
+// four fp8 bytes -> four fp32 (exact)
+__device__ __forceinline__ void mmi_fp8x4_to_f32(uint32_t w, float* o) {
+    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+}
 // D(32x32) += A(32x16) * B(16x32), fp8 in / fp32 acc.  Same element map as the bf16 32x32x16 form with one byte per
 // element: lane l: a[e] = A[l&31][8*(l>>5)+e], b[e] = B[8*(l>>5)+e][l&31] (8 bytes per operand per lane).
 __device__ __forceinline__ f32x16 mmi_mfma_fp8_32x32x16(u32x2 a, u32x2 b, f32x16 c) {

@@ -39,6 +39,9 @@ def _lm_cfg_struct(cfg: LMConfig) -> _capi.LMCfg:
     s.existing_text_padding_id = cfg.existing_text_padding_id
     s.extra_heads_num_heads = cfg.extra_heads_num_heads
     s.extra_heads_dim = cfg.extra_heads_dim
+    if cfg.kv_cache_dtype not in ("bf16", "fp8"):
+        raise ValueError("kv_cache_dtype must be 'bf16' or 'fp8'")
+    s.kv_cache_dtype = _capi.MMI_F8E4M3 if cfg.kv_cache_dtype == "fp8" else _capi.MMI_BF16
     return s
 
 
@@ -82,8 +85,11 @@ class LMModel:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[LMConfig] = None,
                  device: torch.device | str = "cuda", max_batch: int = 32, lib: Optional[_capi.Lib] = None,
-                 quantize: bool | str = False, fuser: Optional[ConditionFuser] = None):
+                 quantize: bool | str = False, fuser: Optional[ConditionFuser] = None, kv_cache: Optional[str] = None):
         self.config = config or LMConfig()
+        if kv_cache is not None:         # "fp8": e4m3 KV ring (half the attention stream); default: the config's (bf16)
+            from dataclasses import replace
+            self.config = replace(self.config, kv_cache_dtype=kv_cache)
         self.fuser = fuser
         self.device = torch.device(device)
         if lib is None:

@@ -275,8 +275,9 @@ class LMOracle:
             att = np.zeros((B, H, Dh), f32)
             for b in range(B):
                 slot = int(off[b] % cap)
-                cache[0, b, :, slot] = k[b]              # written unconditionally (transformer.py:243-250)
-                cache[1, b, :, slot] = v[b]
+                kq, vq = (e4m3r(k[b]), e4m3r(v[b])) if getattr(c, "kv_cache_dtype", "bf16") == "fp8" else (k[b], v[b])
+                cache[0, b, :, slot] = kq                # written unconditionally (transformer.py:243-250)
+                cache[1, b, :, slot] = vq
                 last = int(off[b])
                 end_new = last + 1 if exec_rows[b] else last
                 idx = np.arange(cap)

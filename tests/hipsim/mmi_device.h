@@ -193,6 +193,10 @@ inline uint32_t mmi_cvt_fp8x4(float a, float b, float c, float d) {
     return (uint32_t)f32_to_e4m3(a) | ((uint32_t)f32_to_e4m3(b) << 8) | ((uint32_t)f32_to_e4m3(c) << 16) | ((uint32_t)f32_to_e4m3(d) << 24);
 }
 
+inline void mmi_fp8x4_to_f32(uint32_t w, float* o) {
+    for (int i = 0; i < 4; ++i) o[i] = hipsim_detail::e4m3_to_f32((uint8_t)(w >> (8 * i)));
+}
+
 inline f32x16 mmi_mfma_fp8_32x32x16(u32x2 a, u32x2 b, f32x16 c) {
     using namespace hipsim_detail;
     hipsim::Slot* s = hipsim::wave_slots();

@@ -54,6 +54,41 @@ def test_int8_full_width_layers_match_oracle(gpu_lib):
     lm_cases.oracle_vs_engine(DEV, None, cfg, seed=9, B=3, S=3, use_masks=True, quantize=True)
 
 
+@pytest.mark.parametrize("B,S", [(2, 15), (18, 4), (40, 3)])
+def test_fp8_kv_ring_matches_the_oracle(gpu_lib, B, S):
+    """`kv_cache_dtype="fp8"`: e4m3 keys / values in the ring (written by in_proj's epilogue, widened exactly by the decode
+    attention), bf16 weights, all three batch tilings; S > context: the ring wraps."""
+    from dataclasses import replace
+    lm_cases.oracle_vs_engine(DEV, None, replace(tiny_lm_config(), kv_cache_dtype="fp8"), seed=120 + B, B=B, S=S)
+
+
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_long_ring_split_over_workgroups_matches_oracle(gpu_lib, kv):
+    """A ring longer than one 256-slot chunk with few (session, head) pairs: the decode attention splits the ring over
+    several workgroups and merges the partials (k_lm_attn_split NS > 1 + k_lm_attn_combine), 300 positions deep."""
+    from dataclasses import replace
+    from oracle.lm_oracle import LMOracle
+    cfg = replace(tiny_lm_config(), context=600, kv_cache_dtype=kv)
+    sd = random_lm_state_dict(cfg, seed=44)
+    gen = LMGen(LMModel(sd, cfg, device=DEV, max_batch=1), use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(1)
+    rng = np.random.default_rng(44)
+    with gen.streaming(1):
+        for s in range(300):
+            codes = rng.integers(0, cfg.card, (1, 8, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            if s % 20 and s < 290:       # the deep positions are what matters: skip the read-back on most steps
+                gen._step(torch.from_numpy(codes).to(DEV), False, None, torch.from_numpy(forced).to(DEV))
+                continue
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(DEV), forced_tokens=torch.from_numpy(forced).to(DEV))
+            assert np.array_equal(out.cpu().numpy(), oo), f"step {s}"
+            assert lm_cases.logits_close(tl[0].cpu().numpy(), otl[0]), f"step {s}: text logits"
+            for k in range(cfg.dep_q):
+                assert lm_cases.logits_close(al[0, k].cpu().numpy(), oal[0, k]), f"step {s} cb {k}"
+
+
 def test_fp8_hardware_primitives_match_their_definition(gpu_lib, tmp_path):
     """scripts/fp8_probe.hip on this GPU: v_cvt_pk_fp8_f32 bit-exact against the software e4m3 rounding the oracle uses
     (every bf16 value + ties), subnormal inputs honoured by the fp8 MFMA, and its dot product within 5e-4 of exact (it is

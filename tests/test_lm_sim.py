@@ -71,6 +71,14 @@ def test_fp8_weights_on_the_fp8_mfma_match_the_fp8_oracle(sim_lib, B, input_scal
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=90 + B, B=B, S=3, quantize="fp8", input_scale=input_scale)
 
 
+@pytest.mark.parametrize("B,S,quantize", [(2, 15, False), (18, 3, False), (3, 4, "fp8")])
+def test_fp8_kv_ring_matches_the_oracle(sim_lib, B, S, quantize):
+    """`kv_cache_dtype="fp8"` (SURVEY.md 8d C5 "fp8 KV"): keys (after RoPE) and values enter the ring as e4m3 bytes, the decode
+    attention widens them exactly; S > context: the ring wraps.  Oracle: the same e4m3 rounding at the ring write."""
+    from dataclasses import replace
+    lm_cases.oracle_vs_engine("cpu", sim_lib, replace(tiny_lm_config(), kv_cache_dtype="fp8"), seed=120 + B, B=B, S=S, quantize=quantize)
+
+
 def test_fp8_hardware_yardstick_runs_on_the_simulator(sim_lib):
     """The check the GPU tests hold the fp8 engine to (tests/lm_cases.py "fp8 on hardware"): on the simulator, whose MFMA
     accumulates exactly, the engine coincides with the exact oracle, far inside the yardstick."""
