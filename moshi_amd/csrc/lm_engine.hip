@@ -952,12 +952,13 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (bytes_per_launch) {
         const mmi_lm_cfg& c = lm->cfg;
         // algorithmic bytes of one FFN linear_in launch: packed weights + activations in + gated activations out
-        const int64_t wbytes = lm->q8 == 1 ? (int64_t)2 * c.ffn_hidden * c.dim + (int64_t)2 * c.ffn_hidden * 4 : (int64_t)2 * c.ffn_hidden * c.dim * 2;
+        const int64_t wbytes = lm->q8 >= 1 ? (int64_t)2 * c.ffn_hidden * c.dim + (int64_t)2 * c.ffn_hidden * 4 : (int64_t)2 * c.ffn_hidden * c.dim * 2;
         *bytes_per_launch = wbytes + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
     }
     if (kernel_name)
-        *kernel_name = lm->q8 == 1 ? "k_gemm_xp<32, 1, 1, 8, 2, true> (temporal FFN linear_in, int8 weights + SiLU gate)"
-                                   : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
+        *kernel_name = lm->q8 == 1   ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
+                       : lm->q8 == 2 ? "k_gemm_xp<32, 1, 1, 8, 2, 2> (temporal FFN linear_in, fp8 weights on the fp8 MFMA + SiLU gate)"
+                                     : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;
 }
