@@ -268,6 +268,9 @@ typedef struct mmi_batcher_cfg {
     int32_t reset_codec_after_first_frame;  /* server.py:135-141: the first input frame's encoder state is dropped  */
     int32_t max_buffered_frames;            /* per-channel cap on queued input frames and on un-popped output frames */
     mmi_sampling sampling;                  /* LMGen constructor arguments (lm.py:557-574)                          */
+    mmi_guidance guidance;                  /* cfg_coef = 0 or 1: none.  Otherwise as mmi_lm_streaming_start_guided, shared by
+                                               every channel (server.py:53-54: one condition for the model type); the LM
+                                               handle then needs max_batch >= 2 * slots                               */
 } mmi_batcher_cfg;
 
 typedef struct mmi_batcher_stats {

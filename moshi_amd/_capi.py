@@ -61,7 +61,7 @@ class Guidance(C.Structure):
 
 class BatcherCfg(C.Structure):
     _fields_ = [("slots", C.c_int32), ("reset_codec_after_first_frame", C.c_int32), ("max_buffered_frames", C.c_int32),
-                ("sampling", Sampling)]
+                ("sampling", Sampling), ("guidance", Guidance)]
 
 
 class BatcherStats(C.Structure):

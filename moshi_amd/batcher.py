@@ -28,7 +28,8 @@ from .mimi import MimiModel
 class SessionBatcher:
     def __init__(self, mimi: MimiModel, lm_model: LMModel, slots: int, use_sampling: bool = True, temp: float = 0.8,
                  temp_text: float = 0.7, top_k: int = 250, top_k_text: int = 25, seed: int = 0,
-                 reset_codec_after_first_frame: bool = True, max_buffered_frames: int = 250):
+                 reset_codec_after_first_frame: bool = True, max_buffered_frames: int = 250, cfg_coef: float = 1.0,
+                 cfg_is_no_text: bool = False, cfg_is_masked_until=None, condition_tensors=None):
         assert mimi._lib is lm_model._lib, "both models must live in the same engine library"
         assert not mimi.is_streaming, "the batcher puts the models into streaming mode itself"
         self.mimi, self.lm_model = mimi, lm_model
@@ -43,6 +44,24 @@ class SessionBatcher:
         cfg.sampling.temp, cfg.sampling.temp_text = temp, temp_text
         cfg.sampling.top_k, cfg.sampling.top_k_text = top_k, top_k_text
         cfg.sampling.seed = seed
+        # guidance / conditioning shared by every channel (server.py:53-54 builds ONE set of condition tensors per model type)
+        keep = []
+        rows = int(slots) * (2 if cfg_coef != 1.0 else 1)
+        cfg.guidance.cfg_coef = float(cfg_coef)
+        cfg.guidance.cfg_is_no_text = 1 if cfg_is_no_text else 0
+        if cfg_is_masked_until is not None and cfg_coef != 1.0:
+            mu = (C.c_int64 * int(slots))(*[int(v) for v in cfg_is_masked_until])
+            keep.append(mu)
+            cfg.guidance.cfg_is_masked_until = C.cast(mu, C.c_void_p)
+        if condition_tensors is not None:
+            assert lm_model.fuser is not None, "Model has no fuser"
+            cs = lm_model.fuser.get_sum(condition_tensors)
+            if cs is not None:
+                import torch
+                assert cs.shape[0] == rows, "one condition row per model row (2 per slot when guided)"
+                cs = cs.to(device=lm_model.device, dtype=torch.bfloat16).contiguous().view(rows, lm_model.dim)
+                keep.append(cs)
+                cfg.guidance.condition_sum = cs.data_ptr()
         self._handle = C.c_void_p()
         mimi._sync()
         self._lib.check(self._lib.mmi_batcher_create(mimi._handle, lm_model._handle, C.byref(cfg), C.byref(self._handle)))

@@ -19,22 +19,22 @@ from moshi_amd.mimi import MimiModel
 from moshi_amd.weights import random_lm_state_dict, random_mimi_state_dict
 
 
-def tiny_pair(device, lib, slots, seed=5):
+def tiny_pair(device, lib, slots, seed=5, lm_rows=None, fuser=None):
     lcfg = tiny_lm_config()
     mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.dep_q)
     msd = random_mimi_state_dict(mcfg, seed=seed)
     lsd = random_lm_state_dict(lcfg, seed=seed + 1)
     mimi = MimiModel(msd, mcfg, device=device, max_batch=slots, num_codebooks=lcfg.dep_q, lib=lib)
-    lm = LMModel(lsd, lcfg, device=device, max_batch=slots, lib=lib)
+    lm = LMModel(lsd, lcfg, device=device, max_batch=lm_rows or slots, lib=lib, fuser=fuser)
     return mimi, lm, mcfg, lcfg
 
 
 class ManualLoop:
     """The batcher's schedule written against the reference's Python API, row by row."""
 
-    def __init__(self, mimi: MimiModel, lm: LMModel, slots: int, reset_codec_after_first_frame=True):
+    def __init__(self, mimi: MimiModel, lm: LMModel, slots: int, reset_codec_after_first_frame=True, **gen_kwargs):
         self.mimi, self.lm = mimi, lm
-        self.gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+        self.gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, **gen_kwargs)
         self.B = slots
         self.first_quirk = reset_codec_after_first_frame
         mimi.streaming_forever(slots)                       # server.py:59-60
@@ -200,3 +200,27 @@ def check_slots_and_buffers(device, lib):
             assert b.step() == 1                            # one frame per channel per step, like the reference loop
         assert b.step() == 0
         assert b.stats()["frames"] == 3
+
+
+def check_batcher_with_guidance(device, lib):
+    """Guided sessions (cfg_coef 2, masked-until, one shared `sum` condition: two model rows per slot) through the batcher ==
+    the same schedule by hand through a guided LMGen."""
+    from moshi_amd.lm import ConditionFuser
+    slots = 2
+    lcfg = tiny_lm_config()
+    rng = np.random.default_rng(3)
+    cond = torch.from_numpy(0.5 * rng.standard_normal((2 * slots, 1, lcfg.dim)).astype(np.float32)).to(torch.bfloat16)
+    kw = dict(cfg_coef=2.0, cfg_is_masked_until=[1, 2], condition_tensors={"c": (cond, None)})
+    fuser = ConditionFuser({"sum": ["c"]})
+    mimi_a, lm_a, mcfg, _ = tiny_pair(device, lib, slots, lm_rows=2 * slots, fuser=fuser)
+    mimi_b, lm_b, _, _ = tiny_pair(device, lib, slots, lm_rows=2 * slots, fuser=fuser)
+    manual = ManualLoop(mimi_b, lm_b, slots, **kw)
+    script = [(0, "open", "x"), (1, "open", "y"), (3, "skip", "x"), (4, "close", "y"), (5, "open", "z")]
+    with SessionBatcher(mimi_a, lm_a, slots, use_sampling=False, **kw) as batcher:
+        res, ref = scripted_run(batcher, manual, mcfg.frame_size, script=script, n_steps=8)
+    manual.stop()
+    assert sum(len(v) for v in res.values()) > 8
+    for s in res:
+        assert len(res[s]) == len(ref[s])
+        for (pa, ta), (pb, tb) in zip(res[s], ref[s]):
+            assert np.array_equal(ta, tb) and np.array_equal(pa, pb)

@@ -12,3 +12,7 @@ def test_session_is_independent_of_its_neighbours(sim_lib):
 
 def test_slots_and_buffer_limits(sim_lib):
     batcher_cases.check_slots_and_buffers("cpu", sim_lib)
+
+
+def test_guided_sessions_through_the_batcher(sim_lib):
+    batcher_cases.check_batcher_with_guidance("cpu", sim_lib)
