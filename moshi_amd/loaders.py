@@ -143,7 +143,7 @@ def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]
     return LMModel(state, cfg, device=device, max_batch=max_batch, lib=lib, quantize=False if already else quantize, fuser=fuser)
 
 
-def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8") -> Dict[str, int]:
+def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8", lm_kwargs: Optional[dict] = None) -> Dict[str, int]:
     """scripts/export_quantized.py:38-64 without the hub: read a bf16 Moshi checkpoint, convert the linears
     (`replace_linear_with_qlinear`: temporal + depth transformers, depformer_in, linears, text_linear) to the reference's int8
     storage (`weight` int8 + `weight_scb`) or to fp8 (`weight` e4m3fn + `weight_scale`), and write a safetensors file."""
@@ -151,6 +151,9 @@ def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8") -> Dic
 
     from .weights import normalize_lm_state_dict, quantize_lm_state_dict, quantize_lm_state_dict_fp8
     state = _load_state(src, ("fsdp_best_state", "model"))
+    # released checkpoints fuse the per-step attention projections (`self_attn.in_proj_weight`): split them first, as the
+    # reference's load hook does before `replace_linear_with_qlinear` sees the modules (transformer.py:422-446)
+    state = normalize_lm_state_dict(state, lm_config_from_kwargs(lm_kwargs))
     if fmt == "int8":
         out = quantize_lm_state_dict(state)
     elif fmt == "fp8":

@@ -73,7 +73,14 @@ def test_export_quantized_writes_the_storage_the_engine_loads(sim_lib, tmp_path,
     cfg = tiny_lm_config()
     sd = random_lm_state_dict(cfg, seed=9)
     save_file(sd, str(tmp_path / "model.safetensors"))
-    info = loaders.export_quantized(tmp_path / "model.safetensors", tmp_path / f"model.{fmt}.safetensors", fmt)
+    # stored the way released checkpoints store the attention projections: fused over the depformer's steps
+    fused = dict(sd)
+    for l in range(cfg.depformer_num_layers):
+        pre = f"depformer.layers.{l}.self_attn."
+        fused[pre + "in_proj_weight"] = torch.cat([fused.pop(pre + f"in_projs.{k}.weight") for k in range(cfg.dep_q)])
+        fused[pre + "out_proj.weight"] = torch.cat([fused.pop(pre + f"out_projs.{k}.weight") for k in range(cfg.dep_q)])
+    save_file(fused, str(tmp_path / "model.safetensors"))
+    info = loaders.export_quantized(tmp_path / "model.safetensors", tmp_path / f"model.{fmt}.safetensors", fmt, tiny_lm_kwargs())
     q = load_file(str(tmp_path / f"model.{fmt}.safetensors"))
     k = "transformer.layers.0.self_attn.in_projs.0.weight"
     assert q[k].dtype == dtype and q[k + scale_key].dtype == torch.float32 and q["emb.0.weight"].dtype == torch.bfloat16
