@@ -16,7 +16,6 @@ import argparse
 import json
 import sys
 import time
-from collections import deque
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -49,61 +48,65 @@ class InferenceState:
         self.mimi.streaming_forever(batch_size)
         self.lm_gen.streaming_forever(batch_size)
 
+    def _user_codes(self, in_pcms: torch.Tensor, finished):
+        """The user-side code stream: one [B, K, 1] tensor per whole input frame; for Hibiki, after the audio, one
+        end-of-stream frame (every codebook = cardinality) and then encoded silence for as long as `finished()` is false
+        (run_inference.py:137-155).  The second element tells whether the input audio is exhausted."""
+        F, B = self.frame_size, self.batch_size
+        n_whole = in_pcms.shape[-1] // F                       # a ragged tail is dropped (run_inference.py:128-134)
+        for f in range(n_whole):
+            yield self.mimi.encode(in_pcms[..., f * F:(f + 1) * F].to(self.device)), False
+        if self.model_type != "hibiki":
+            return
+        yield torch.full((B, self.mimi.num_codebooks, 1), self.mimi.cardinality, device=self.device, dtype=torch.long), True
+        silence = torch.zeros(B, self.mimi.channels, F, device=self.device)
+        while not finished():
+            yield self.mimi.encode(silence), True
+
     def run(self, in_pcms: torch.Tensor, max_steps: Optional[int] = None) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         """in_pcms float [B, channels, T] -> per item (text tokens [n], pcm [channels, n * frame_size]).  `max_steps` bounds the
         Hibiki wait-for-EOS loop (not in the reference, which trusts the model to emit EOS)."""
-        B = self.batch_size
-        out_pcms: List[List[torch.Tensor]] = [[] for _ in range(B)]
-        out_text: List[List[torch.Tensor]] = [[] for _ in range(B)]
-        eos_reached = [False] * B
-        need_eos_input = True
-        lm = self.lm_gen.lm_model
+        B, lm = self.batch_size, self.lm_gen.lm_model
+        texts: List[List[torch.Tensor]] = [[] for _ in range(B)]
+        audio: List[List[torch.Tensor]] = [[] for _ in range(B)]
+        done = [False] * B
+        eos_id = self.text_tokenizer.eos_id() if self.text_tokenizer is not None else -1
         log("info", f"starting inference, sampling: {self.lm_gen.use_sampling}, audio temp: {self.lm_gen.temp}, "
                     f"text temp: {self.lm_gen.temp_text}")
-        start, ntokens, first_frame = time.time(), 0, True
-        chunks = deque(c for c in in_pcms.split(self.frame_size, dim=2) if c.shape[-1] == self.frame_size)   # whole frames only
-        eos_id = self.text_tokenizer.eos_id() if self.text_tokenizer is not None else -1
-        while not all(eos_reached):
-            if chunks:
-                codes = self.mimi.encode(chunks.popleft().to(self.device))
-            elif self.model_type == "hibiki":
-                if need_eos_input:           # first frame after the end of the file: a code full of `cardinality` = end of stream
-                    need_eos_input = False
-                    codes = torch.full((B, self.mimi.num_codebooks, 1), self.mimi.cardinality, device=self.device, dtype=torch.long)
-                else:
-                    codes = self.mimi.encode(torch.zeros(B, self.mimi.channels, self.frame_size, device=self.device))
-            else:
-                break                        # other models stop at the end of the audio
-            if first_frame:                  # run_inference.py:160-166
-                tokens = self.lm_gen.step(codes)
-                if max(lm.delays) > 0:
-                    assert tokens is None
-                first_frame = False
+        t0, steps = time.time(), 0
+        for n, (codes, input_over) in enumerate(self._user_codes(in_pcms, lambda: all(done))):
+            if n == 0:
+                # the first slice of codes is stepped twice, otherwise the transformer only ever sees the initial tokens in
+                # its place (run_inference.py:160-166)
+                primed = self.lm_gen.step(codes)
+                assert primed is None or max(lm.delays) == 0
             tokens = self.lm_gen.step(codes)
             if tokens is None:
                 continue
             assert tokens.shape[1] == lm.dep_q + 1
-            out_pcm = self.mimi.decode(tokens[:, 1:]).cpu()
-            for b, (one_text, one_pcm) in enumerate(zip(tokens[:, 0].cpu(), out_pcm)):
-                if eos_reached[b]:
+            pcm = self.mimi.decode(tokens[:, 1:]).cpu()
+            text = tokens[:, 0].cpu()
+            first_live = not done[0]
+            for b in range(B):
+                if done[b]:
                     continue
-                if one_text.item() == eos_id:
-                    if need_eos_input:
-                        log("warning", "EOS sampled too early.")
+                if int(text[b]) == eos_id:                      # run_inference.py:178-186
+                    if input_over:
+                        done[b] = True
                     else:
-                        eos_reached[b] = True
-                out_text[b].append(one_text)
-                out_pcms[b].append(one_pcm)
-                if b == 0 and one_text.item() not in (0, 3) and self.text_tokenizer is not None:
-                    self.on_token(self.text_tokenizer.id_to_piece(one_text.item()).replace("▁", " "))
-            ntokens += 1
-            if max_steps is not None and ntokens >= max_steps:
+                        log("warning", "EOS sampled too early.")
+                texts[b].append(text[b])
+                audio[b].append(pcm[b])
+            if first_live and self.text_tokenizer is not None and int(text[0]) not in (0, 3):
+                self.on_token(self.text_tokenizer.id_to_piece(int(text[0])).replace("\u2581", " "))
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
                 break
-        dt = time.time() - start
-        if ntokens:
-            log("info", f"processed {ntokens} steps in {dt:.0f}s, {1000 * dt / ntokens:.2f}ms/step")
+        if steps:
+            dt = time.time() - t0
+            log("info", f"processed {steps} steps in {dt:.0f}s, {1000 * dt / steps:.2f}ms/step")
         return [(torch.cat(t, dim=0) if t else torch.zeros(0, dtype=torch.long),
-                 torch.cat(p, dim=1) if p else torch.zeros(self.mimi.channels, 0)) for t, p in zip(out_text, out_pcms)]
+                 torch.cat(a, dim=1) if a else torch.zeros(self.mimi.channels, 0)) for t, a in zip(texts, audio)]
 
 
 def read_wav(path: str, sample_rate: int) -> np.ndarray:
