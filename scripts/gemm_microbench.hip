@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     const int ksplit = argc > 2 ? atoi(argv[2]) : 1;   // > 1: the residual GEMMs run split-K with fp32 partial output
     const bool quick = argc > 3;                       // any 3rd argument: only the FFN linear_in shape with the production plan
                                                        // (for rocprofv3 --pmc passes, where every dispatch is serialised)
-    const int T = B <= 16 ? 16 : 32;
+    const int T = getenv("MB_T") ? atoi(getenv("MB_T")) : (B <= 16 ? 16 : 32);   // MB_T=16 with B=32: 16-row weight tiles, two batch tiles
     const int MT = (B + T - 1) / T;
     const Shape shapes[] = {
         {"ffn_in  22528x4096 (gate)", 11264, 4096, 1}, {"in_proj 12288x4096", 12288, 4096, 0},
@@ -97,6 +97,7 @@ int main(int argc, char** argv) {
         V(32, 2, 1, 4, 4), V(32, 2, 1, 8, 4), V(32, 2, 2, 4, 4), V(32, 2, 2, 4, 2), V(32, 2, 1, 8, 2),
         V(16, 1, 1, 4, 4), V(16, 1, 1, 8, 4), V(16, 1, 1, 16, 4), V(16, 1, 2, 4, 4), V(16, 1, 2, 8, 4),
         V(16, 1, 1, 4, 8), V(16, 1, 1, 8, 8), V(16, 1, 4, 4, 2), V(16, 1, 4, 8, 2),
+        V(16, 2, 1, 4, 4), V(16, 2, 1, 8, 4), V(16, 2, 1, 8, 2), V(16, 2, 2, 4, 4),
     };
     hipStream_t s;
     CK(hipStreamCreate(&s));
