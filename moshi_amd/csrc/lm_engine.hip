@@ -220,6 +220,9 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     // registers -> 3 workgroups per CU -> all 704 resident at once; 36.8 vs 39.3 us in the microbenchmark), else 4
     p.u = (g.gate && g.NT >= 512 && p.waves == 8) ? 2 : 4;
     if (g.scale) p.u = 2;            // int8 entries carry two k-steps each
+    // (two n-tiles per workgroup for the 384-tile temporal in_proj look 3.5 us faster in the microbenchmark - 22.5 against
+    // 26.0 us, profiles/r01_logs/gemm_microbench_b32_v10.txt - and make no difference in the step: 8.176 / 8.186 ms against
+    // 8.190 / 8.176 ms in a same-box A/B, profiles/r01_logs/ab_in_proj_ntw2.txt; not adopted)
     const char* e = getenv("MMI_GEMM_WAVES");
     if (e && atoi(e) > 0) p.waves = atoi(e);
     e = getenv("MMI_GEMM_NTW");

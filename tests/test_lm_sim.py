@@ -47,6 +47,15 @@ def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=78, B=3, S=3)
 
 
+def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
+    """Two n-tiles per workgroup (`MMI_GEMM_NTW=2`, the variant the 64-session experiments use), forced onto the tiny shapes,
+    with one and two batch tiles."""
+    monkeypatch.setenv("MMI_GEMM_NTW", "2")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=71, B=18, S=3)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=72, B=34, S=2)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=73, B=3, S=3)
+
+
 def test_depformer_in_per_step_launches(sim_lib, monkeypatch):
     """The engine normally runs the dep_q `depformer_in` linears as one grouped GEMM and lets each sampler add its token's
     embedding row; depth widths that are not whole n-tiles fall back to one GEMM per micro-step with the embedding in its
