@@ -6,7 +6,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from moshi_amd.config import tiny_lm_config  # noqa: E402
 from moshi_amd.lm import LMGen, LMModel  # noqa: E402
 from moshi_amd.weights import quantize_lm_state_dict, quantize_lm_state_dict_fp8, random_lm_state_dict  # noqa: E402
