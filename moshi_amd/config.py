@@ -150,7 +150,18 @@ class LMConfig:
             "depformer_layer_scale": None, "depformer_multi_linear": True, "depformer_context": self.dep_q,
             "depformer_max_period": 10000, "depformer_gating": "silu", "depformer_pos_emb": "none",
             "depformer_weights_per_step": True, "delays": list(self.delays),
+            **({"extra_heads_num_heads": self.extra_heads_num_heads, "extra_heads_dim": self.extra_heads_dim}
+               if self.extra_heads_num_heads else {}),
         }
+
+
+def tiny_stt_config() -> LMConfig:
+    """An ASR-style model at oracle size (the reference's kyutai/stt-* family): every audio codebook is input, no depformer
+    (`dep_q = 0`, lm.py:218-221), the text stream runs `delays[0]` steps behind the audio, extra heads on the transformer
+    output (lm.py:224-226) read with `step_with_extra_heads`."""
+    return LMConfig(dim=128, num_heads=4, num_layers=2, hidden_scale=4.125, context=12, n_q=8, dep_q=0, card=64, text_card=96,
+                    depformer_dim=64, depformer_dim_feedforward=int(4.125 * 64), depformer_num_heads=2, depformer_num_layers=2,
+                    delays=[2] + [0] * 8, extra_heads_num_heads=2, extra_heads_dim=6)
 
 
 def tiny_lm_config() -> LMConfig:

@@ -588,7 +588,7 @@ int check_cfg(const mmi_lm_cfg& c) {
     if (c.kv_cache_dtype == MMI_F8E4M3 && (c.dim / c.num_heads) % 16) return mmi_fail(MMI_ERR_UNSUPPORTED, "fp8 KV needs a head dim multiple of 16");
     if (c.card % 8 || c.text_card_out % 8 || c.card > 32768 || c.text_card_out > 32768)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "vocabulary sizes must be multiples of 8 and at most 32768");
-    if (c.dep_q < 1 || c.dep_q > 16 || c.n_q < c.dep_q || c.n_q + 1 > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "bad n_q / dep_q");
+    if (c.dep_q < 0 || c.dep_q > 16 || c.n_q < c.dep_q || c.n_q + 1 > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "bad n_q / dep_q");
     if (c.dim > 8 * 1024 * MMI_NORM_MAXP || c.depformer_dim > 8 * 1024 * MMI_NORM_MAXP)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "model width above the RMSNorm kernel's register budget");
     if (c.dim % 8 || c.depformer_dim % 8 || c.ffn_hidden % 8 || c.depformer_ffn_hidden % 8)
@@ -605,10 +605,15 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
                              mmi_lm** out) {
     if (!cfg || !weights || !out || max_batch <= 0) return mmi_fail(MMI_ERR_INVALID, "mmi_lm_create: bad argument");
     if (max_batch > 64) return mmi_fail(MMI_ERR_UNSUPPORTED, "max_batch > 64 sessions per GPU is not supported yet");
-    int rc = check_cfg(*cfg);
+    mmi_lm_cfg norm_cfg = *cfg;
+    if (norm_cfg.dep_q == 0) {   // "No-Depformer --- e.g., an ASR model" (lm.py:218-221): text stream only; the depth-transformer
+        norm_cfg.depformer_num_layers = 0;   // fields are then unused, give them inert values so that the sizing code stays generic
+        norm_cfg.depformer_dim = 8; norm_cfg.depformer_num_heads = 1; norm_cfg.depformer_ffn_hidden = 8;
+    }
+    int rc = check_cfg(norm_cfg);
     if (rc) return rc;
     mmi_lm* lm = new mmi_lm();
-    lm->cfg = *cfg;
+    lm->cfg = norm_cfg;
     lm->max_batch = max_batch;
     lm->T = max_batch <= 16 ? 16 : 32;
     lm->use_graph = mmi_graphs_enabled();
@@ -628,7 +633,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
             if ((rc = load_copy(lm, W, "emb." + std::to_string(i) + ".weight", 2, per, nullptr, lm->emb + per * i))) return fail(rc);
         if ((rc = load_copy(lm, W, "text_emb.weight", 2, (size_t)(c.text_card + 1) * d, &lm->text_emb))) return fail(rc);
         lm->dep_emb.resize(c.dep_q);
-        if ((rc = load_copy(lm, W, "depformer_text_emb.weight", 2, (size_t)(c.text_card + 1) * dd, &lm->dep_emb[0]))) return fail(rc);
+        if (c.dep_q > 0 && (rc = load_copy(lm, W, "depformer_text_emb.weight", 2, (size_t)(c.text_card + 1) * dd, &lm->dep_emb[0]))) return fail(rc);
         for (int k = 1; k < c.dep_q; ++k)
             if ((rc = load_copy(lm, W, "depformer_emb." + std::to_string(k - 1) + ".weight", 2, (size_t)(c.card + 1) * dd, &lm->dep_emb[k]))) return fail(rc);
     }
@@ -659,7 +664,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     {
         // depformer_in[k] all read transformer_out, so they are packed back to back and run as ONE GEMM with
         // dep_q * depformer_dim output features ahead of the micro-step loop (build_program).  Needs whole n-tiles per step.
-        const bool group = dd % lm->T == 0 && !getenv("MMI_NO_DEP_IN_GROUP");
+        const bool group = c.dep_q > 0 && dd % lm->T == 0 && !getenv("MMI_NO_DEP_IN_GROUP");
         uint8_t* wp_all = nullptr;
         float* scale_all = nullptr;
         size_t per = 0;

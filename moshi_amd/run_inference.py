@@ -84,8 +84,15 @@ class InferenceState:
             if tokens is None:
                 continue
             assert tokens.shape[1] == lm.dep_q + 1
-            pcm = self.mimi.decode(tokens[:, 1:]).cpu()
             text = tokens[:, 0].cpu()
+            if lm.dep_q == 0:                                   # ASR-style model: text only (run_inference.py:199-204)
+                if self.text_tokenizer is not None and int(text[0]) not in (0, 3):
+                    self.on_token(self.text_tokenizer.id_to_piece(int(text[0])).replace("\u2581", " "))
+                for b in range(B):
+                    texts[b].append(text[b])
+                steps += 1
+                continue
+            pcm = self.mimi.decode(tokens[:, 1:]).cpu()
             first_live = not done[0]
             for b in range(B):
                 if done[b]:

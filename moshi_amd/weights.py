@@ -110,8 +110,9 @@ def lm_state_spec(cfg: LMConfig) -> Spec:
         spec.append((f"depformer_in.{k}.weight", (dd, d), f"fan:{d}"))
     for k in range(cfg.dep_q - 1):
         spec.append((f"depformer_emb.{k}.weight", (cfg.card + 1, dd), f"emb:{dd}"))
-    spec.append(("depformer_text_emb.weight", (cfg.text_card + 1, dd), f"emb:{dd}"))
-    for l in range(cfg.depformer_num_layers):
+    if cfg.dep_q > 0:                      # "No-Depformer --- e.g., an ASR model" (lm.py:187-221): none of the depth weights exist
+        spec.append(("depformer_text_emb.weight", (cfg.text_card + 1, dd), f"emb:{dd}"))
+    for l in range(cfg.depformer_num_layers if cfg.dep_q > 0 else 0):
         p = f"depformer.layers.{l}"
         for k in range(cfg.dep_q):
             spec.append((p + f".self_attn.in_projs.{k}.weight", (3 * dd, dd), f"fan:{dd}"))
@@ -123,6 +124,8 @@ def lm_state_spec(cfg: LMConfig) -> Spec:
             spec.append((p + f".gating.{k}.linear_out.weight", (dd, dh), f"fan:{dh}"))
     for k in range(cfg.dep_q):
         spec.append((f"linears.{k}.weight", (cfg.card, dd), f"fan:{dd}"))
+    for i in range(cfg.extra_heads_num_heads):          # lm.py:224-226
+        spec.append((f"extra_heads.{i}.weight", (cfg.extra_heads_dim, d), f"fan:{d}"))
     return spec
 
 

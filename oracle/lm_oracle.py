@@ -181,9 +181,9 @@ class LMOracle:
                                     n1=sd[p + ".norm1.alpha"].reshape(-1), n2=sd[p + ".norm2.alpha"].reshape(-1),
                                     w_in=sd[p + ".gating.linear_in.weight"], w_out=sd[p + ".gating.linear_out.weight"]))
         self.dep_in = [sd[f"depformer_in.{k}.weight"] for k in range(c.dep_q)]
-        self.dep_emb = [sd["depformer_text_emb.weight"]] + [sd[f"depformer_emb.{k}.weight"] for k in range(c.dep_q - 1)]
+        self.dep_emb = ([sd["depformer_text_emb.weight"]] + [sd[f"depformer_emb.{k}.weight"] for k in range(c.dep_q - 1)]) if c.dep_q > 0 else []
         self.dep_layers = []
-        for l in range(c.depformer_num_layers):
+        for l in range(c.depformer_num_layers if c.dep_q > 0 else 0):      # dep_q == 0: an ASR model without depformer (lm.py:218-221)
             p = f"depformer.layers.{l}"
             self.dep_layers.append(dict(
                 in_proj=[sd[p + f".self_attn.in_projs.{k}.weight"] for k in range(c.dep_q)],
@@ -331,6 +331,8 @@ class LMOracle:
                 tok = np.where(forced[:, 1 + k] >= 0, forced[:, 1 + k], tok)
             tokens.append(tok); logits_all.append(lg)
             prev = self._model_rows(tok)
+        if not tokens:
+            return np.zeros((self.gen_B, 0), np.int64), np.zeros((self.gen_B, 0, c.card), f32)
         return np.stack(tokens, 1), np.stack(logits_all, 1)
 
     # ---- LMGen._step (lm.py:668-783) ---------------------------------------------

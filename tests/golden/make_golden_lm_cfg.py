@@ -7,6 +7,8 @@ lm_cfg.npz - tiny Moshi LM (moshi_amd.config.tiny_lm_config), bf16, seeded weigh
   b_  cfg_coef 1.5, cfg_is_no_text                                   (lm.py:724-725, 731-732)
   c_  cfg_coef 3.0 + a `sum` condition [2B, 1, dim] through a ConditionFuser (lm.py:621-628, 399-400)
   d_  no CFG, a `sum` condition [B, 1, dim], and two extra heads read with `step_with_extra_heads` (lm.py:793-807)
+lm_stt.npz - an ASR-style model (moshi_amd.config.tiny_stt_config: dep_q = 0, all 8 codebooks are input, text delayed by 2,
+two extra heads), same schedule: tokens [B, 1, 1], text logits, extra-head probabilities.
 For every step: the tokens returned, the logits every token was sampled from (recorded at `sample_token`, i.e. AFTER the
 guidance combination), the sampled tokens, and for d_ the extra-head probabilities.
 """
@@ -103,6 +105,43 @@ def main():
         out.update({f"{p}_{k}": v for k, v in r.items()})
     np.savez_compressed(HERE / "lm_cfg.npz", **out)
     print("lm_cfg.npz", {k: v.shape for k, v in out.items()})
+
+    # ---- ASR-style model: no depformer
+    from moshi_amd.config import tiny_stt_config
+    scfg = tiny_stt_config()
+    ssd = random_lm_state_dict(scfg, seed=37)
+    lm = LMModel(**scfg.reference_kwargs(), device="cpu", dtype=torch.bfloat16)
+    lm.load_state_dict(ssd, strict=True)
+    lm.eval()
+    assert lm.depformer is None
+    codes8 = torch.randint(0, scfg.card, (S, B, scfg.n_q, 1), generator=g).numpy()
+    import moshi.models.lm as lm_mod
+    rec = []
+    orig = lm_mod.sample_token
+
+    def sample_token(logits, *a, **k):
+        tok = orig(logits, *a, **k)
+        rec.append((logits.float().numpy().reshape(logits.shape[0], -1).copy(), tok.numpy().reshape(-1).copy()))
+        return tok
+    lm_mod.sample_token = sample_token
+    st = {"tokens": [], "text_logits": [], "text_tok": [], "heads": []}
+    gen = LMGen(lm, **common)
+    try:
+        with torch.no_grad(), gen.streaming(B):
+            for s_ in range(S):
+                rec.clear()
+                if s_ in reset_before:
+                    gen.reset_streaming(torch.from_numpy(reset_before[s_]))
+                gen.set_exec_mask(torch.from_numpy(masks[s_]))
+                o, heads = gen.step_with_extra_heads(torch.from_numpy(codes8[s_]))
+                st["tokens"].append(o.numpy().copy()); st["text_logits"].append(rec[0][0]); st["text_tok"].append(rec[0][1])
+                st["heads"].append(np.stack([h.float().numpy()[:, 0] for h in heads], 1))
+    finally:
+        lm_mod.sample_token = orig
+    sout = {"seed": np.array([37]), "codes": codes8, "masks": masks, "reset_step": np.array([4]), "reset_mask": reset_before[4]}
+    sout.update({k: np.stack(v) for k, v in st.items()})
+    np.savez_compressed(HERE / "lm_stt.npz", **sout)
+    print("lm_stt.npz", {k: v.shape for k, v in sout.items()})
 
 
 if __name__ == "__main__":

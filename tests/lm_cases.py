@@ -362,3 +362,53 @@ def fp8_engine_within_format_conditioning(device, lib, cfg, seed, B, S, input_sc
     a, r = st["engine_vs_bf16"], st["oracle_vs_bf16"]
     assert a[2] <= 1.5 * r[2] + 0.005 and a[3] <= 1.75 * r[3] + 0.01, "fp8 engine less accurate against the bf16 model than the fp8 oracle: " + msg
     return msg
+
+
+# ---- ASR-style models: dep_q = 0, no depformer (lm.py:218-221), text delayed behind the audio, extra heads --------------------------
+def check_stt_golden(start, step, heads):
+    """tests/golden/lm_stt.npz (reference run of moshi_amd.config.tiny_stt_config).  start() opens a stream of B sessions;
+    step(codes [B, 8, 1], forced [B, 1], mask, reset_or_None) -> (tokens [B, 1, 1], text logits [B, V]); heads() -> [B, 2, 6]."""
+    g = np.load(GOLDEN / "lm_stt.npz")
+    S, B = g["masks"].shape
+    start()
+    for s in range(S):
+        reset = g["reset_mask"] if s == int(g["reset_step"][0]) else None
+        out, tl = step(g["codes"][s], g["text_tok"][s][:, None], g["masks"][s], reset)
+        pr = heads()
+        for b in range(B):
+            if not g["masks"][s, b]:
+                continue
+            assert np.array_equal(out[b], g["tokens"][s, b]), f"step {s} row {b}: ring output differs"
+            assert logits_close(tl[b], g["text_logits"][s, b]), f"step {s} row {b}: text logits"
+            assert np.abs(pr[b] - g["heads"][s, b]).max() <= 0.02, f"step {s} row {b}: extra heads"
+
+
+def check_stt_engine(device, lib):
+    from moshi_amd.config import tiny_stt_config
+    g = np.load(GOLDEN / "lm_stt.npz")
+    cfg = tiny_stt_config()
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+    B = g["masks"].shape[1]
+    lm = LMModel(sd, cfg, device=device, max_batch=B, lib=lib)
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    assert lm.dep_q == 0
+
+    def step(codes, forced, mask, reset):
+        if reset is not None:
+            gen.reset_streaming(torch.from_numpy(reset).to(device))
+        gen.set_exec_mask(torch.from_numpy(mask).to(device))
+        out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+        assert out.shape == (B, 1, 1) and al.shape == (B, 0, cfg.card)
+        return out.cpu().numpy(), tl.cpu().numpy()
+
+    def heads():
+        probs = torch.empty(B, cfg.extra_heads_num_heads, cfg.extra_heads_dim, device=device, dtype=torch.float32)
+        gen._lib.check(gen._lib.mmi_lm_extra_heads(lm._handle, probs.data_ptr(), gen._stream()))
+        return probs.cpu().numpy()
+    try:
+        check_stt_golden(lambda: gen.streaming_forever(B), step, heads)
+        # the public call: tokens + one probability tensor per head
+        out, hs = gen.step_with_extra_heads(torch.from_numpy(g["codes"][0]).to(device))
+        assert out.shape == (B, 1, 1) and len(hs) == 2 and hs[0].shape == (B, 1, cfg.extra_heads_dim)
+    finally:
+        gen._stop_streaming()

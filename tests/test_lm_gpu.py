@@ -129,6 +129,10 @@ def test_guidance_conditioning_and_extra_heads_match_reference_golden(gpu_lib, n
     lm_cases.check_cfg_engine(DEV, None, name)
 
 
+def test_asr_style_model_without_depformer_matches_reference_golden(gpu_lib):
+    lm_cases.check_stt_engine(DEV, None)
+
+
 def test_guided_full_width_matches_oracle(gpu_lib):
     """Guidance at the 7B layer shapes (2 temporal layers): 2 x 3 model rows, masked-until + condition, vs the oracle."""
     from moshi_amd.lm import ConditionFuser

@@ -189,6 +189,12 @@ def test_guidance_conditioning_and_extra_heads_match_reference_golden(sim_lib, n
     lm_cases.check_cfg_engine("cpu", sim_lib, name)
 
 
+def test_asr_style_model_without_depformer_matches_reference_golden(sim_lib):
+    """dep_q = 0 (the reference's stt models: lm.py:218-221): the step ends at the text sampler, tokens are [B, 1, 1], the
+    extra heads read the transformer output; against the reference's own run (tests/golden/lm_stt.npz)."""
+    lm_cases.check_stt_engine("cpu", sim_lib)
+
+
 def test_guided_batch_must_fit_twice(sim_lib):
     cfg = tiny_lm_config()
     lm = lm_cases.LMModel(random_lm_state_dict(cfg, seed=1), cfg, device="cpu", max_batch=3, lib=sim_lib)

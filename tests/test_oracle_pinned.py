@@ -122,3 +122,23 @@ def test_lm_oracle_guidance_conditioning_and_extra_heads_match_reference(name):
         out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
         return out, tl, al
     lm_cases.check_cfg_scenario(g, cfg, name, lambda **kw: o.streaming(B, **kw), step, o.extra_head_probs)
+
+
+def test_lm_oracle_matches_reference_for_an_asr_style_model():
+    """dep_q = 0 (no depformer), text delayed behind 8 input codebooks, two extra heads: tests/golden/lm_stt.npz."""
+    from moshi_amd.config import tiny_stt_config
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle
+    from tests import lm_cases
+    g = np.load(GOLDEN / "lm_stt.npz")
+    cfg = tiny_stt_config()
+    o = LMOracle(random_lm_state_dict(cfg, seed=int(g["seed"][0])), cfg)
+    B = g["masks"].shape[1]
+
+    def step(codes, forced, mask, reset):
+        if reset is not None:
+            o.reset_streaming(reset)
+        o.set_exec_mask(mask)
+        out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+        return out, tl
+    lm_cases.check_stt_golden(lambda: o.streaming(B), step, lambda: o.extra_head_probs())

@@ -102,3 +102,27 @@ def test_wav_roundtrip_and_cli(sim_lib, tmp_path, monkeypatch):
                         str(tmp_path / "in.wav"), str(tmp_path / "out.wav")])
     out = run_inference.read_wav(str(tmp_path / "out.wav"), mcfg.sample_rate)
     assert out.shape[0] == 4 * mcfg.frame_size and np.isfinite(out).all()
+
+
+def test_asr_style_model_prints_text_only(sim_lib, tmp_path):
+    """dep_q = 0: every codebook of the codec is input, nothing is decoded, the text stream is what comes out."""
+    from moshi_amd.config import tiny_stt_config
+    lcfg = tiny_stt_config()
+    mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.n_q)
+    save_file(random_lm_state_dict(lcfg, seed=3), str(tmp_path / "model.safetensors"))
+    save_file(random_mimi_state_dict(mcfg, seed=4), str(tmp_path / "mimi.safetensors"))
+    conf = {**lcfg.reference_kwargs(), "moshi_name": "model.safetensors", "mimi_name": "mimi.safetensors", "model_type": "stt",
+            "mimi_config": mcfg.reference_kwargs()}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    info = loaders.CheckpointInfo.from_local(tmp_path)
+    mimi = info.get_mimi("cpu", max_batch=1, lib=sim_lib)
+    assert mimi.num_codebooks == lcfg.n_q                       # loaders.py:282-291: max(dep_q, n_q - dep_q)
+    lm = info.get_moshi("cpu", max_batch=1, lib=sim_lib)
+    assert lm.config.dep_q == 0 and lm.config.extra_heads_num_heads == 2
+    said = []
+    st = run_inference.InferenceState(info, mimi, StubTokenizer(), lm, 1, device="cpu", use_sampling=False, on_token=said.append)
+    n = 6
+    pcm = torch.from_numpy((0.3 * np.random.default_rng(2).standard_normal((1, 1, n * mcfg.frame_size))).astype(np.float32))
+    (text, audio), = st.run(pcm)
+    assert audio.numel() == 0 and len(text) == n + 1 - lcfg.max_delay      # n frames + the doubled first step - the text delay
+    assert len(said) == sum(int(t) not in (0, 3) for t in text)
