@@ -296,6 +296,7 @@ int mmi_batcher_push_pcm(mmi_batcher* b, int64_t channel_id, const float* pcm, i
 /* One iteration of the model loop.  n_active (host) = rows that had a frame; 0 means nothing was run. */
 int mmi_batcher_step(mmi_batcher* b, int32_t* n_active);
 /* Next un-popped output frame of a channel: pcm f32[frame_size], tokens i64[1 + dep_q] (text, audio...), got = 0/1.
+ * With an ASR-style LM (dep_q = 0, the batched_asr.rs case proper) nothing is decoded: tokens = the text token, pcm is zeros.
  * Frames produced while the LM's delay ring was still filling (tokens -2, lm.py:781-782) are never queued, exactly
  * like the reference server skips `None` (server.py:144-146). */
 int mmi_batcher_pop(mmi_batcher* b, int64_t channel_id, float* pcm, int64_t* tokens, int32_t* got);

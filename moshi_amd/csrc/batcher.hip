@@ -69,16 +69,16 @@ void carve(Staging* st, unsigned char* up, unsigned char* down, int B, int F, in
 // exactly where the reference indexes them unchecked (vq.py:144-146).
 __global__ void k_batcher_route(const long* __restrict__ tokens, const uint8_t* __restrict__ exec, uint8_t* __restrict__ played,
                                 long* __restrict__ codes, int B, int dep_q, int card) {
-    const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (gid >= B * dep_q) return;
-    const int b = gid / dep_q, k = gid % dep_q;
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= B) return;
     const long* row = tokens + (long)b * (1 + dep_q);
     bool ok = exec[b] != 0;
     for (int j = 0; j <= dep_q; ++j) ok = ok && row[j] >= 0;
-    long c = row[1 + k];
-    c = c < 0 ? 0 : (c >= card ? card - 1 : c);
-    codes[gid] = c;
-    if (k == 0) played[b] = ok ? 1 : 0;
+    for (int k = 0; k < dep_q; ++k) {
+        long c = row[1 + k];
+        codes[(long)b * dep_q + k] = c < 0 ? 0 : (c >= card ? card - 1 : c);
+    }
+    played[b] = ok ? 1 : 0;
 }
 
 }  // namespace
@@ -139,7 +139,7 @@ int create_impl(mmi_batcher* b) {
     b->NTOK = 1 + lc.dep_q;
     if (b->K < lc.n_q - lc.dep_q)
         return mmi_fail(MMI_ERR_SHAPE, "the codec produces fewer codebooks than the LM expects from the user stream");   // lm.py:683-686
-    if (b->K != lc.dep_q) return mmi_fail(MMI_ERR_SHAPE, "the codec must decode exactly the dep_q codebooks the LM generates");
+    if (lc.dep_q > 0 && b->K != lc.dep_q) return mmi_fail(MMI_ERR_SHAPE, "the codec must decode exactly the dep_q codebooks the LM generates");
     if (mc.q_bins != lc.card) return mmi_fail(MMI_ERR_SHAPE, "codec cardinality != LM card");
     const int B = b->B;
     MMI_HIP_CHECK(hipStreamCreate(&b->stream));
@@ -158,10 +158,11 @@ int create_impl(mmi_batcher* b) {
     b->dev.down = dd;
     carve(&b->host, hu, hd, B, b->F, b->NTOK);
     carve(&b->dev, du, dd, B, b->F, b->NTOK);
+    MMI_HIP_CHECK(hipMemset(dd, 0, probe.d2h_bytes));   // rows (or, for an ASR model, the whole PCM block) nobody writes read as zero
     memset(hu, 0, probe.h2d_bytes);
     memset(hd, 0, probe.d2h_bytes);
     MMI_HIP_CHECK(hipMalloc((void**)&b->d_codes, (size_t)B * b->K * sizeof(int64_t)));
-    MMI_HIP_CHECK(hipMalloc((void**)&b->d_dec_codes, (size_t)B * b->dep_q * sizeof(int64_t)));
+    MMI_HIP_CHECK(hipMalloc((void**)&b->d_dec_codes, (size_t)B * (b->dep_q > 0 ? b->dep_q : 1) * sizeof(int64_t)));
     // streaming_forever(batch) on both models (server.py:59-60)
     if ((rc = mmi_mimi_streaming_start(b->mimi, B, b->stream))) return rc;
     b->models_streaming = true;
@@ -291,11 +292,13 @@ extern "C" int mmi_batcher_step(mmi_batcher* b, int32_t* n_active) {
     if (firsts && (rc = mmi_mimi_reset(b->mimi, d.first, s))) return rc;   // server.py:135-141
     int valid = 0;
     if ((rc = mmi_lm_step(b->lm, b->d_codes, b->K, d.tokens, nullptr, nullptr, nullptr, B, &valid, s))) return rc;
-    MMI_LAUNCH(k_batcher_route, mmi_cdiv(B * b->dep_q, 128), 128, 0, s, (const long*)d.tokens, (const uint8_t*)d.exec, d.played,
+    MMI_LAUNCH(k_batcher_route, mmi_cdiv(B, 64), 64, 0, s, (const long*)d.tokens, (const uint8_t*)d.exec, d.played,
                (long*)b->d_dec_codes, B, b->dep_q, b->card);
     MMI_CHECK_LAUNCH();
-    if ((rc = mmi_mimi_set_exec_mask(b->mimi, d.played, s))) return rc;   // rows still inside the LM delay do not touch the decoder
-    if ((rc = mmi_mimi_decode_step(b->mimi, b->d_dec_codes, d.pcm_out, B, b->dep_q, 1, s))) return rc;
+    if (b->dep_q > 0) {   // an ASR-style model (dep_q = 0) generates no audio: the step ends at the text token
+        if ((rc = mmi_mimi_set_exec_mask(b->mimi, d.played, s))) return rc;   // rows still inside the LM delay do not touch the decoder
+        if ((rc = mmi_mimi_decode_step(b->mimi, b->d_dec_codes, d.pcm_out, B, b->dep_q, 1, s))) return rc;
+    }
     MMI_HIP_CHECK(hipMemcpyAsync(h.down, d.down, h.d2h_bytes, hipMemcpyDeviceToHost, s));
     MMI_HIP_CHECK(hipEventRecord(b->ev_end, s));
     MMI_HIP_CHECK(hipEventSynchronize(b->ev_end));

@@ -224,3 +224,46 @@ def check_batcher_with_guidance(device, lib):
         assert len(res[s]) == len(ref[s])
         for (pa, ta), (pb, tb) in zip(res[s], ref[s]):
             assert np.array_equal(ta, tb) and np.array_equal(pa, pb)
+
+
+def check_asr_batcher(device, lib):
+    """The reference's batched ASR server proper (batched_asr.rs): channels of PCM in, text tokens out, no decoder; against the
+    same schedule by hand through MimiModel.encode + LMGen.step."""
+    from moshi_amd.config import tiny_stt_config
+    slots = 2
+    lcfg = tiny_stt_config()
+    mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.n_q)
+
+    def pair():
+        mimi = MimiModel(random_mimi_state_dict(mcfg, seed=5), mcfg, device=device, max_batch=slots, num_codebooks=lcfg.n_q, lib=lib)
+        return mimi, LMModel(random_lm_state_dict(lcfg, seed=6), lcfg, device=device, max_batch=slots, lib=lib)
+    mimi_a, lm_a = pair()
+    mimi_b, lm_b = pair()
+    gen = LMGen(lm_b, use_sampling=False, support_out_of_sync=True)
+    mimi_b.streaming_forever(slots); gen.streaming_forever(slots)
+    rng = np.random.default_rng(9)
+    F = mcfg.frame_size
+    with SessionBatcher(mimi_a, lm_a, slots, use_sampling=False, reset_codec_after_first_frame=False) as b:
+        chans = [b.open(), b.open()]
+        got = [[], []]
+        ref = [[], []]
+        for s in range(7):
+            x = (0.3 * rng.standard_normal((slots, F))).astype(np.float32)
+            active = [True, s != 3]                                  # channel 1 has no audio at step 3
+            for i, ch in enumerate(chans):
+                if active[i]:
+                    b.push(ch, x[i])
+            assert b.step() == sum(active)
+            for i, ch in enumerate(chans):
+                while (fr := b.pop(ch)) is not None:
+                    got[i].append(int(fr[1][0]))
+                    assert fr[1].shape == (1,)
+            ex = torch.tensor(active, device=device)
+            mimi_b.set_exec_mask(ex); gen.set_exec_mask(ex)
+            pcm = torch.from_numpy(np.where(np.array(active)[:, None], x, 0.0).astype(np.float32))[:, None].to(device)
+            tokens = gen.step(mimi_b.encode(pcm))
+            for i in range(slots):
+                if active[i] and int(tokens[i, 0, 0]) >= 0:
+                    ref[i].append(int(tokens[i, 0, 0]))
+    mimi_b._stop_streaming(); gen._stop_streaming()
+    assert got == ref and len(got[0]) == 7 - lcfg.max_delay and len(got[1]) == 6 - lcfg.max_delay

@@ -26,6 +26,10 @@ def test_guided_sessions_through_the_batcher(gpu_lib):
     batcher_cases.check_batcher_with_guidance(DEV, None)
 
 
+def test_batched_asr_text_only(gpu_lib):
+    batcher_cases.check_asr_batcher(DEV, None)
+
+
 def test_full_size_codec_with_moshi_width_lm(gpu_lib):
     """Real Mimi (24 kHz, 1920-sample frames, 2048-entry codebooks) + an LM at Moshi-7B's widths (2 temporal layers):
     18 slots, channels joining every other step; every played frame is finite audio and in-range tokens, and a channel's

@@ -18,6 +18,10 @@ def test_guided_sessions_through_the_batcher(sim_lib):
     batcher_cases.check_batcher_with_guidance("cpu", sim_lib)
 
 
+def test_batched_asr_text_only(sim_lib):
+    batcher_cases.check_asr_batcher("cpu", sim_lib)
+
+
 def test_io_threads_push_and_pop_while_the_loop_steps(sim_lib):
     """open / push / pop / close from I/O threads while one thread runs the model loop (the deployment shape: websocket
     handlers + batched_asr.rs's model_loop thread): nothing is lost, every channel gets its frames in order."""
