@@ -116,6 +116,13 @@ int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream);
 /* StreamingModule.reset_streaming (streaming.py:139-156): mask = device uint8[batch] or NULL (= all rows). */
 int mmi_mimi_reset(mmi_mimi* m, const uint8_t* mask_or_null, mmi_stream stream);
 
+/* StreamingModule.get_streaming_state / set_streaming_state (streaming.py:158-181): the complete streaming state of the
+ * current stream as one opaque device buffer of mmi_mimi_state_bytes() bytes (conv histories, conv-transpose partials, KV
+ * rings, offsets, masks).  A snapshot can be loaded back into the same handle while it streams with the same batch. */
+int64_t mmi_mimi_state_bytes(const mmi_mimi* m);
+int mmi_mimi_state_save(mmi_mimi* m, void* dst, int64_t bytes, mmi_stream stream);
+int mmi_mimi_state_load(mmi_mimi* m, const void* src, int64_t bytes, mmi_stream stream);
+
 /* MimiModel.encode in streaming mode (compression.py:376-388, 338-374):
  * pcm f32 [batch,1,n_frames*frame_size] -> codes i64 [batch,num_codebooks,n_frames]. */
 int mmi_mimi_encode_step(mmi_mimi* m, const float* pcm, int64_t* codes, int32_t batch, int32_t n_frames,
@@ -213,6 +220,11 @@ int mmi_lm_model_rows(const mmi_lm* lm);   /* rows the model runs for the curren
 /* LMGen.step_with_extra_heads (lm.py:793-807): softmax(extra_head(transformer_out)) of the LAST step for every head:
  * probs f32 [model rows, extra_heads_num_heads, extra_heads_dim]. */
 int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream);
+/* get / set_streaming_state of LMGen (streaming.py:158-181; _LMGenState lm.py:520-547): KV rings, token ring, offsets, masks,
+ * RNG counter as one opaque device buffer; host_word carries the host-side step counter (`offset_cpu`). */
+int64_t mmi_lm_state_bytes(const mmi_lm* lm);
+int mmi_lm_state_save(mmi_lm* lm, void* dst, int64_t bytes, int64_t* host_word, mmi_stream stream);
+int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int64_t host_word, mmi_stream stream);
 int mmi_lm_streaming_stop(mmi_lm* lm);
 int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream);        /* lm.py:544-547 */
 int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask_or_null, mmi_stream stream);        /* lm.py:537-542 */

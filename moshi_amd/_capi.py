@@ -93,6 +93,12 @@ SIGNATURES = {
     "mmi_lm_streaming_start_guided": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), C.POINTER(Guidance), _P]),
     "mmi_lm_model_rows": (C.c_int, [_P]),
     "mmi_lm_extra_heads": (C.c_int, [_P, _P, _P]),
+    "mmi_lm_state_bytes": (C.c_int64, [_P]),
+    "mmi_lm_state_save": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
+    "mmi_lm_state_load": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "mmi_mimi_state_bytes": (C.c_int64, [_P]),
+    "mmi_mimi_state_save": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mmi_mimi_state_load": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mmi_lm_streaming_stop": (C.c_int, [_P]),
     "mmi_lm_set_exec_mask": (C.c_int, [_P, _P, _P]),
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),

@@ -923,6 +923,27 @@ extern "C" int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_s
     return MMI_OK;
 }
 
+extern "C" int64_t mmi_lm_state_bytes(const mmi_lm* lm) { return lm && lm->streaming ? (int64_t)lm->st.bytes : 0; }
+
+extern "C" int mmi_lm_state_save(mmi_lm* lm, void* dst, int64_t bytes, int64_t* host_word, mmi_stream stream) {
+    if (!lm || !dst || !host_word) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot buffer has the wrong size");
+    MMI_HIP_CHECK(lm->st.save(dst, (hipStream_t)stream));
+    *host_word = lm->offset_cpu;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int64_t host_word, mmi_stream stream) {
+    if (!lm || !src) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch / guidance)");
+    MMI_HIP_CHECK(lm->st.load(src, (hipStream_t)stream));
+    lm->offset_cpu = (long)host_word;
+    lm->forced_armed = false;
+    return MMI_OK;
+}
+
 extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
     if (!lm || !probs) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");

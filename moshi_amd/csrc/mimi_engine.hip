@@ -919,6 +919,24 @@ extern "C" int mmi_mimi_streaming_stop(mmi_mimi* m) {
     return MMI_OK;
 }
 
+extern "C" int64_t mmi_mimi_state_bytes(const mmi_mimi* m) { return m && m->streaming ? (int64_t)m->st.bytes : 0; }
+
+extern "C" int mmi_mimi_state_save(mmi_mimi* m, void* dst, int64_t bytes, mmi_stream stream) {
+    if (!m || !dst) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    if (bytes != (int64_t)m->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot buffer has the wrong size");
+    MMI_HIP_CHECK(m->st.save(dst, (hipStream_t)stream));
+    return MMI_OK;
+}
+
+extern "C" int mmi_mimi_state_load(mmi_mimi* m, const void* src, int64_t bytes, mmi_stream stream) {
+    if (!m || !src) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    if (bytes != (int64_t)m->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch)");
+    MMI_HIP_CHECK(m->st.load(src, (hipStream_t)stream));
+    return MMI_OK;
+}
+
 extern "C" int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream) {
     if (!m || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");

@@ -63,6 +63,7 @@ struct MmiWeights {
 // device allocation bookkeeping: every engine frees what it allocated
 struct MmiArena {
     std::vector<void*> ptrs;
+    std::vector<size_t> sizes;
     size_t bytes = 0;
     template <class T>
     hipError_t alloc(T** p, size_t count) {
@@ -72,6 +73,7 @@ struct MmiArena {
         hipError_t e = hipMalloc(&q, nb);
         if (e != hipSuccess) return e;
         ptrs.push_back(q);
+        sizes.push_back(nb);
         bytes += nb;
         *p = (T*)q;
         return hipSuccess;
@@ -79,6 +81,26 @@ struct MmiArena {
     void release() {
         for (void* p : ptrs) hipFree(p);
         ptrs.clear();
+        sizes.clear();
         bytes = 0;
+    }
+    // snapshot / restore of every allocation, back to back (StreamingModule.get/set_streaming_state, streaming.py:158-181)
+    hipError_t save(void* dst, hipStream_t s) const {
+        size_t at = 0;
+        for (size_t i = 0; i < ptrs.size(); ++i) {
+            hipError_t e = hipMemcpyAsync((char*)dst + at, ptrs[i], sizes[i], hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+            at += sizes[i];
+        }
+        return hipSuccess;
+    }
+    hipError_t load(const void* src, hipStream_t s) {
+        size_t at = 0;
+        for (size_t i = 0; i < ptrs.size(); ++i) {
+            hipError_t e = hipMemcpyAsync(ptrs[i], (const char*)src + at, sizes[i], hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+            at += sizes[i];
+        }
+        return hipSuccess;
     }
 };

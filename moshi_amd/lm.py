@@ -299,6 +299,24 @@ class LMGen:
         keep, ptr = self._mask_ptr(reset_mask)
         self._lib.check(self._lib.mmi_lm_reset(self.lm_model._handle, ptr, self._stream()))
 
+    def get_streaming_state(self) -> dict:
+        """streaming.py:158-166: the complete streaming state (a copy: one opaque device tensor + the host step counter)."""
+        assert self.is_streaming
+        h = self.lm_model._handle
+        n = int(self._lib.mmi_lm_state_bytes(h))
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        word = C.c_int64(0)
+        self._lib.check(self._lib.mmi_lm_state_save(h, buf.data_ptr(), n, C.byref(word), self._stream()))
+        return {"lm_gen": buf, "offset_cpu": int(word.value), "batch_size": self._batch}
+
+    def set_streaming_state(self, state: dict) -> None:
+        """streaming.py:168-181."""
+        assert self.is_streaming
+        if "lm_gen" not in state:
+            raise RuntimeError("Expected to find a streaming state for lm_gen.")
+        buf = state["lm_gen"]
+        self._lib.check(self._lib.mmi_lm_state_load(self.lm_model._handle, buf.data_ptr(), buf.numel(), int(state["offset_cpu"]), self._stream()))
+
     def set_exec_mask(self, exec_mask: torch.Tensor) -> None:
         assert self.is_streaming
         keep, ptr = self._mask_ptr(exec_mask)

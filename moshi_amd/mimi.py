@@ -174,6 +174,22 @@ class MimiModel:
         keep, ptr = self._mask_arg(exec_mask)
         self._lib.check(self._lib.mmi_mimi_set_exec_mask(self._handle, ptr, self._stream()))
 
+    def get_streaming_state(self) -> dict:
+        """streaming.py:158-166: the complete streaming state (a copy: one opaque device tensor)."""
+        assert self.is_streaming
+        n = int(self._lib.mmi_mimi_state_bytes(self._handle))
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._lib.check(self._lib.mmi_mimi_state_save(self._handle, buf.data_ptr(), n, self._stream()))
+        return {"mimi": buf, "batch_size": self._batch}
+
+    def set_streaming_state(self, state: dict) -> None:
+        """streaming.py:168-181."""
+        assert self.is_streaming
+        if "mimi" not in state:
+            raise RuntimeError("Expected to find a streaming state for mimi.")
+        buf = state["mimi"]
+        self._lib.check(self._lib.mmi_mimi_state_load(self._handle, buf.data_ptr(), buf.numel(), self._stream()))
+
     # ---- encode / decode (compression.py:338-433) ------------------------------------------------
     def _check_audio(self, x: torch.Tensor) -> torch.Tensor:
         assert x.dim() == 3, f"expects audio of shape [B, C, T] but got {tuple(x.shape)}"

@@ -412,3 +412,35 @@ def check_stt_engine(device, lib):
         assert out.shape == (B, 1, 1) and len(hs) == 2 and hs[0].shape == (B, 1, cfg.extra_heads_dim)
     finally:
         gen._stop_streaming()
+
+
+def check_streaming_state_snapshot(device, lib):
+    """StreamingModule.get_streaming_state / set_streaming_state (streaming.py:158-181): a snapshot taken mid-dialogue and
+    loaded back reproduces the continuation bit for bit (codec and LM; greedy)."""
+    from tests import batcher_cases
+    B = 2
+    mimi, lm, mcfg, lcfg = batcher_cases.tiny_pair(device, lib, B)
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    rng = np.random.default_rng(5)
+    frames = [torch.from_numpy((0.3 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32)).to(device) for _ in range(7)]
+
+    def run(fs):
+        out = []
+        for x in fs:
+            tokens = gen.step(mimi.encode(x))
+            out.append((tokens.clone(), mimi.decode(tokens[:, 1:].clamp(min=0)).clone()))
+        return out
+    with mimi.streaming(B), gen.streaming(B):
+        run(frames[:3])
+        snap_m, snap_l = mimi.get_streaming_state(), gen.get_streaming_state()
+        first = run(frames[3:])
+        run(frames[:2])                                     # wander off
+        mimi.set_streaming_state(snap_m); gen.set_streaming_state(snap_l)
+        again = run(frames[3:])
+        try:
+            gen.set_streaming_state({})
+            raise AssertionError("an empty state must be refused")
+        except RuntimeError as e:
+            assert "streaming state" in str(e)
+    for (ta, pa), (tb, pb) in zip(first, again):
+        assert torch.equal(ta, tb) and torch.equal(pa, pb)

@@ -129,6 +129,10 @@ def test_guidance_conditioning_and_extra_heads_match_reference_golden(gpu_lib, n
     lm_cases.check_cfg_engine(DEV, None, name)
 
 
+def test_get_and_set_streaming_state_resume_a_dialogue(gpu_lib):
+    lm_cases.check_streaming_state_snapshot(DEV, None)
+
+
 def test_asr_style_model_without_depformer_matches_reference_golden(gpu_lib):
     lm_cases.check_stt_engine(DEV, None)
 

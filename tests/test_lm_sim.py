@@ -201,3 +201,7 @@ def test_guided_batch_must_fit_twice(sim_lib):
     gen = lm_cases.LMGen(lm, cfg_coef=2.0, cfg_is_no_text=True)
     with pytest.raises(AssertionError, match="two model rows per session"):
         gen.streaming_forever(2)
+
+
+def test_get_and_set_streaming_state_resume_a_dialogue(sim_lib):
+    lm_cases.check_streaming_state_snapshot("cpu", sim_lib)
