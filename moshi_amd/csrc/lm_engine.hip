@@ -418,7 +418,7 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
     sa.k = text ? lm->samp.top_k_text : lm->samp.top_k;
     sa.temp = text ? lm->samp.temp_text : lm->samp.temp;
     sa.use_sampling = lm->samp.use_sampling;
-    if (sa.k <= 0) sa.k = V;   // top_k == 0: plain multinomial over the whole vocabulary is not implemented -> see below
+    if (sa.k >= V) sa.k = 0;   // top_k == 0 (or the whole vocabulary): plain multinomial, k_sample's a.k <= 0 branch
     sa.noise = lm->noise + (size_t)site * lm->kmax;
     sa.noise_ld = (1 + lm->cfg.dep_q) * lm->kmax;
     sa.use_noise = lm->use_noise; sa.rng = lm->rng; sa.site = site; sa.out = out; sa.out_stride = out_stride;
@@ -744,8 +744,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     if (batch <= 0 || rows > lm->max_batch)
         return mmi_fail(MMI_ERR_SHAPE, guided ? "guidance runs two model rows per session: 2 * batch exceeds max_batch" : "batch exceeds max_batch");
     if (sampling->top_k > 256 || sampling->top_k_text > 256) return mmi_fail(MMI_ERR_UNSUPPORTED, "top_k > 256");
-    if (sampling->use_sampling && (sampling->top_k <= 0 || sampling->top_k_text <= 0))
-        return mmi_fail(MMI_ERR_UNSUPPORTED, "sampling without top-k is not implemented");
+    if (sampling->top_k < 0 || sampling->top_k_text < 0) return mmi_fail(MMI_ERR_INVALID, "top_k must be >= 0 (0 = no top-k)");
     hipStream_t s = (hipStream_t)stream;
     const mmi_lm_cfg& c = lm->cfg;
     lm->batch = rows;
@@ -882,6 +881,8 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
     MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(B * need_user, 256), 256, 0, s, (const long*)user_codes, (long)n_user, lm->user_i32, B, need_user);
+    if (opt_noise && lm->samp.use_sampling && (lm->samp.top_k == 0 || lm->samp.top_k_text == 0))
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "supplied noise is indexed by rank in the top-k: not available with top_k = 0");
     if (opt_noise) {
         MMI_HIP_CHECK(hipMemcpyAsync(lm->noise, opt_noise, (size_t)B * (1 + c.dep_q) * lm->kmax * sizeof(float), hipMemcpyDeviceToDevice, s));
         MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 1, 1, s));

@@ -1195,6 +1195,39 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     for (int w = 0; w < NT / 64; ++w) sum += redf[w];
     __syncthreads();
 
+    if (a.k <= 0) {
+        // top_k = 0: `multinomial(probs)` over the whole vocabulary (sampling.py:98-106 without top-k/top-p): the reference
+        // draws one Exp(1) per VOCABULARY ENTRY and takes argmax(p / q) (sampling.py:40-47); here the draw of entry i is the
+        // counter RNG at (site, session, i).  Supplied noise (the parity taps) only exists for the top-k form.
+        float score = -INFINITY;
+        int tok = 0x7fffffff;
+        MMI_S_FOREACH({
+            const float pr = expf(mmi_bf16_to_f32(bits) / a.temp - mx) / sum;
+            const float sc_ = pr / mmi_exp_noise(a.rng[0], a.rng[1], (unsigned)(a.site * a.B + b), (unsigned)i);
+            if (sc_ > score || (sc_ == score && i < tok)) { score = sc_; tok = i; }
+        })
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float os = mmi_shfl_xor(score, m);
+            const int ot = mmi_shfl_xor(tok, m);
+            if (os > score || (os == score && ot < tok)) { score = os; tok = ot; }
+        }
+        if (lane == 0) { redf[wave] = score; redi[wave] = tok; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NT / 64; ++w)
+                if (redf[w] > score || (redf[w] == score && redi[w] < tok)) { score = redf[w]; tok = redi[w]; }
+            tok = mmi_apply_forced(a, b, tok);
+            a.out[(long)b * a.out_stride] = tok;
+            redi[0] = tok;
+        }
+        if (a.nx_out) {
+            __syncthreads();
+            mmi_sample_next_input(a, b, redi[0]);
+        }
+        return;
+    }
+
     // ---- radix select of the k-th largest key: high byte, then low byte
     const int k = a.k < V ? a.k : V;
     int want = k;

@@ -444,3 +444,49 @@ def check_streaming_state_snapshot(device, lib):
             assert "streaming state" in str(e)
     for (ta, pa), (tb, pb) in zip(first, again):
         assert torch.equal(ta, tb) and torch.equal(pa, pb)
+
+
+# ---- top_k = 0: multinomial over the whole vocabulary, one Exp(1) per entry from the engine's counter RNG ----------------------------
+def philox_exp_noise(seed: int, step: int, a: int, idx: np.ndarray) -> np.ndarray:
+    """lm_kernels.h mmi_exp_noise: Philox4x32-10 with counter (step lo, step hi, a, idx), key = seed -> -log(u)."""
+    M = np.uint64(0xFFFFFFFF)
+    c0 = np.full(idx.shape, step & 0xFFFFFFFF, np.uint64); c1 = np.full(idx.shape, (step >> 32) & 0xFFFFFFFF, np.uint64)
+    c2 = np.full(idx.shape, a, np.uint64); c3 = idx.astype(np.uint64)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    u = ((c0 >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return (-np.log(u)).astype(np.float32)
+
+
+def check_full_multinomial(device, lib, steps=4, B=3, seed=77):
+    """LMGen(top_k=0, top_k_text=0): every sampled token equals argmax(softmax(logits / temp) / q) over the WHOLE vocabulary with
+    q the engine's own per-entry draws (sampling.py:40-47, 98-106), recomputed here from the logits taps."""
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=21)
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=True, temp=0.9, temp_text=0.8, top_k=0, top_k_text=0, seed=seed,
+                      support_out_of_sync=True)
+    rng = np.random.default_rng(1)
+
+    def pick(logits, temp, step, site):
+        out = np.zeros(B, np.int64)
+        for b in range(B):
+            x = (logits[b] / np.float32(temp)).astype(np.float32)
+            pr = np.exp(x - x.max()).astype(np.float32)
+            pr = pr / pr.sum(dtype=np.float32)
+            out[b] = int(np.argmax(pr / philox_exp_noise(seed, step, site * B + b, np.arange(logits.shape[1]))))
+        return out
+    prev = None
+    with gen.streaming(B):
+        for s in range(steps):
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device))
+            out, tl, al = out.cpu().numpy()[:, :, 0], tl.cpu().numpy(), al.cpu().numpy()
+            text = pick(tl, 0.8, s, 0)
+            audio = np.stack([pick(al[:, k], 0.9, s, 1 + k) for k in range(cfg.dep_q)], 1)
+            if prev is not None:      # the ring returns text and codebook 0 one step late (delays 0), the others at once (delays 1)
+                assert np.array_equal(out[:, 0], prev[0]) and np.array_equal(out[:, 1], prev[1][:, 0]), f"step {s}"
+                assert np.array_equal(out[:, 2:], audio[:, 1:]), f"step {s}"
+            prev = (text, audio)

@@ -129,6 +129,10 @@ def test_guidance_conditioning_and_extra_heads_match_reference_golden(gpu_lib, n
     lm_cases.check_cfg_engine(DEV, None, name)
 
 
+def test_sampling_without_top_k_is_a_multinomial_over_the_whole_vocabulary(gpu_lib):
+    lm_cases.check_full_multinomial(DEV, None, steps=6, B=5)
+
+
 def test_get_and_set_streaming_state_resume_a_dialogue(gpu_lib):
     lm_cases.check_streaming_state_snapshot(DEV, None)
 

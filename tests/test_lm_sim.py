@@ -20,6 +20,10 @@ def test_in_kernel_sampler_follows_the_reference_rule(sim_lib):
     lm_cases.engine_sampling_matches_oracle_rule("cpu", sim_lib)
 
 
+def test_sampling_without_top_k_is_a_multinomial_over_the_whole_vocabulary(sim_lib):
+    lm_cases.check_full_multinomial("cpu", sim_lib)
+
+
 def test_sampler_large_vocabulary_variants(sim_lib):
     """Vocabularies above 2048 / 8192 entries take the wider / uncached sampler kernels (lm_kernels.h k_sample)."""
     from dataclasses import replace
