@@ -422,7 +422,7 @@ def check_streaming_state_snapshot(device, lib):
     mimi, lm, mcfg, lcfg = batcher_cases.tiny_pair(device, lib, B)
     gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
     rng = np.random.default_rng(5)
-    frames = [torch.from_numpy((0.3 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32)).to(device) for _ in range(7)]
+    frames = [torch.from_numpy((0.3 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32)).to(device) for _ in range(5)]
 
     def run(fs):
         out = []
@@ -431,12 +431,12 @@ def check_streaming_state_snapshot(device, lib):
             out.append((tokens.clone(), mimi.decode(tokens[:, 1:].clamp(min=0)).clone()))
         return out
     with mimi.streaming(B), gen.streaming(B):
-        run(frames[:3])
+        run(frames[:2])
         snap_m, snap_l = mimi.get_streaming_state(), gen.get_streaming_state()
-        first = run(frames[3:])
-        run(frames[:2])                                     # wander off
+        first = run(frames[2:])
+        run(frames[:1])                                     # wander off
         mimi.set_streaming_state(snap_m); gen.set_streaming_state(snap_l)
-        again = run(frames[3:])
+        again = run(frames[2:])
         try:
             gen.set_streaming_state({})
             raise AssertionError("an empty state must be refused")

@@ -75,10 +75,10 @@ def test_hibiki_feeds_end_of_stream_and_waits_for_eos(sim_lib, tmp_path):
         return run_inference.InferenceState(info, info.get_mimi("cpu", max_batch=1, lib=sim_lib), StubTokenizer(eos),
                                             info.get_moshi("cpu", max_batch=1, lib=sim_lib), 1, device="cpu", use_sampling=False,
                                             on_token=lambda t: None)
-    probe = state(-1).run(pcm, max_steps=n + 6)[0][0]              # never sees EOS: bounded by max_steps
-    assert len(probe) == n + 6
+    probe = state(-1).run(pcm, max_steps=n + 4)[0][0]              # never sees EOS: bounded by max_steps
+    assert len(probe) == n + 4
     # text tokens emitted after the end-of-stream code went in: make the 3rd of them the EOS id
-    eos = int(probe[n + 2])
+    eos = int(probe[n + 1])
     first = next(i for i in range(n, len(probe)) if int(probe[i]) == eos)
     text, audio = state(eos).run(pcm, max_steps=50)[0]
     assert len(text) == first + 1 and int(text[-1]) == eos          # stops AT the first EOS after the input ended
