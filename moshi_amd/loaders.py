@@ -119,12 +119,20 @@ def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]
     if kw is not None:
         kw.update(lm_kwargs_overrides or {})
         kw.pop("depformer_causal", None)                 # deprecated (loaders.py:394)
-        if kw.pop("lora", False) or lora_weights is not None:
-            raise NotImplementedError("LoRA adapters must be fused into the checkpoint first (loaders.py:486-520 fuse_lora)")
-        kw.pop("lora_rank", None); kw.pop("lora_scaling", None)
+        lora = kw.pop("lora", False)
+        kw.pop("lora_rank", None)
+        lora_scaling = kw.pop("lora_scaling", 2.0)
+        if lora_weights is not None and not lora:
+            raise AssertionError("`lora` is False, but received some lora_weights to load.")     # loaders.py:442-445
+        if lora and kw.get("quantize"):
+            raise AssertionError("LoRA and quantization are incompatible for now.")              # loaders.py:429-431
         if "conditioners" in kw and kw["conditioners"]:
             raise NotImplementedError("condition providers (text / tensor conditioners) run outside the engine: pass their "
                                       "output as LMGen(condition_tensors=...)")
+    if kw is None:
+        lora, lora_scaling = False, 2.0
+        if lora_weights is not None:
+            raise AssertionError("`lora` is False, but received some lora_weights to load.")
     fuser = get_condition_fuser(kw) if kw is not None and kw.get("fuser") is not None else None
     cfg = lm_config_from_kwargs(kw)
     if quantize is None:                                # True / "int8": the reference's int8 storage; "fp8": the fp8 MFMA path
@@ -137,6 +145,11 @@ def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]
     else:
         state = _load_state(filename, ("fsdp_best_state", "model"))
         state = {k: v for k, v in state.items() if not (k.startswith("condition_provider.") or k.startswith("fuser."))}
+    if kw is not None and lora and lora_weights is not None:
+        # loaders.py:486-516: the adapter is merged into the base weights (the engine has no unfused LoRA path)
+        assert _is_safetensors(lora_weights), "LoRA weights must be a safetensors file."
+        from .weights import fuse_lora_state_dict, normalize_lm_state_dict
+        state = fuse_lora_state_dict(normalize_lm_state_dict(state, cfg), _load_state(lora_weights), float(lora_scaling))
     if state_patch is not None:
         state_patch(state)
     already = any(v.dtype in (torch.int8, torch.float8_e4m3fn) for v in state.values())

@@ -267,3 +267,34 @@ def quantize_lm_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tenso
         out[key] = torch.round(w16 * scale[:, None]).clamp_(-127, 127).to(torch.int8)
         out[key + "_scb"] = absmax.to(torch.float32)
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# LoRA adapters (modules/lora.py): merged into the base weights at load
+# --------------------------------------------------------------------------------------------------------------------
+def fuse_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], scaling: float) -> Dict[str, torch.Tensor]:
+    """`replace_lora_with_linear` (modules/lora.py:26-43): W' = W + scaling * (B @ A) for every linear that has
+    `<linear>.lora_A.weight` [rank, in] and `<linear>.lora_B.weight` [out, rank] in `lora_sd`, evaluated like the reference in
+    the weights' own dtype (bf16 matmul, scale, add).  The engine always runs the merged weights (the reference can also keep
+    the adapter unfused, W x + scaling * B (A x): the same function up to rounding).  Unknown adapter keys are an error."""
+    out = dict(sd)
+    used = set()
+    for key in list(lora_sd):
+        if not key.endswith(".lora_A.weight"):
+            continue
+        stem = key[: -len(".lora_A.weight")]
+        kb, kw = stem + ".lora_B.weight", stem + ".weight"
+        if kb not in lora_sd:
+            raise RuntimeError(f"LoRA weights carry {key} without {kb}")
+        if kw not in out:
+            raise RuntimeError(f"unexpected_keys in the lora weights: {[key, kb]}")     # loaders.py:508-511
+        w = out[kw]
+        a, b = lora_sd[key].to(w.dtype), lora_sd[kb].to(w.dtype)
+        if a.shape[1] != w.shape[1] or b.shape[0] != w.shape[0] or a.shape[0] != b.shape[1]:
+            raise RuntimeError(f"LoRA shapes {tuple(b.shape)} x {tuple(a.shape)} do not fit {kw} {tuple(w.shape)}")
+        out[kw] = w + scaling * (b @ a)
+        used.update((key, kb))
+    extra = [k for k in lora_sd if k not in used and not k.endswith(".frozen_W.weight")]
+    if extra:
+        raise RuntimeError(f"unexpected_keys in the lora weights: {extra}")
+    return out

@@ -51,8 +51,8 @@ def test_unsupported_options_are_refused_not_ignored():
         loaders.lm_config_from_kwargs({**kw, "norm": "layer_norm"})
     with pytest.raises(ValueError, match="depformer_weights_per_step"):
         loaders.lm_config_from_kwargs({**kw, "depformer_weights_per_step": False})
-    with pytest.raises(NotImplementedError, match="LoRA"):
-        loaders.get_moshi_lm(None, {**kw, "lora": True}, device="cpu")
+    with pytest.raises(AssertionError, match="lora"):
+        loaders.get_moshi_lm(None, kw, device="cpu", lora_weights="adapter.safetensors")
     mc = tiny_mimi_config().reference_kwargs()
     mc["seanet"]["pad_mode"] = "reflect"
     with pytest.raises(ValueError, match="pad_mode"):
@@ -111,3 +111,31 @@ def test_checkpoint_info_from_a_released_style_directory(sim_lib, tmp_path):
     x = torch.zeros(1, 1, mcfg.frame_size)
     with mimi.streaming(1):
         assert mimi.encode(x).shape == (1, 8, 1)
+
+
+def test_lora_adapter_is_merged_like_the_reference(sim_lib, tmp_path):
+    """loaders.get_lora_moshi with fuse_lora (modules/lora.py:26-43): W' = W + scaling * B @ A in the weights' dtype."""
+    from moshi_amd.lm import LMModel
+    from moshi_amd.weights import fuse_lora_state_dict
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=12)
+    g = torch.Generator().manual_seed(0)
+    rank, scaling = 4, 2.0
+    lora = {}
+    for stem in ("transformer.layers.0.self_attn.in_projs.0", "transformer.layers.1.gating.linear_out",
+                 "depformer.layers.0.gating.3.linear_in", "text_linear", "linears.2"):
+        w = sd[stem + ".weight"]
+        lora[stem + ".lora_A.weight"] = (0.3 * torch.randn(rank, w.shape[1], generator=g)).to(torch.bfloat16)
+        lora[stem + ".lora_B.weight"] = (0.3 * torch.randn(w.shape[0], rank, generator=g)).to(torch.bfloat16)
+    merged = fuse_lora_state_dict(sd, lora, scaling)
+    k = "text_linear.weight"
+    want = sd[k] + scaling * (lora["text_linear.lora_B.weight"] @ lora["text_linear.lora_A.weight"])
+    assert torch.equal(merged[k], want) and not torch.equal(merged[k], sd[k])
+    assert torch.equal(merged["emb.0.weight"], sd["emb.0.weight"])
+    with pytest.raises(RuntimeError, match="unexpected_keys"):
+        fuse_lora_state_dict(sd, {"nope.lora_A.weight": lora["text_linear.lora_A.weight"], "nope.lora_B.weight": lora["text_linear.lora_B.weight"]}, 2.0)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    save_file(lora, str(tmp_path / "lora.safetensors"))
+    lm = loaders.get_moshi_lm(tmp_path / "model.safetensors", {**tiny_lm_kwargs(), "lora": True, "lora_rank": rank, "lora_scaling": scaling},
+                              device="cpu", max_batch=2, lib=sim_lib, lora_weights=tmp_path / "lora.safetensors", fuse_lora=True)
+    assert np.array_equal(greedy_tokens(lm), greedy_tokens(LMModel(merged, cfg, device="cpu", max_batch=2, lib=sim_lib)))
