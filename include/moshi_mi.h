@@ -216,7 +216,10 @@ typedef struct mmi_guidance {
 } mmi_guidance;
 int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide_or_null,
                                   mmi_stream stream);
-int mmi_lm_model_rows(const mmi_lm* lm);   /* rows the model runs for the current stream: batch, or 2 * batch when guided */
+int mmi_lm_model_rows(const mmi_lm* lm);
+/* Engine counters for tests / diagnostics.  which = 0: GEMM launches (or captured graph nodes) that took the LDS-resident
+ * kernel (k_gemm_xlds, enabled with MMI_GEMM_LDS=1). */
+int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which);   /* rows the model runs for the current stream: batch, or 2 * batch when guided */
 /* LMGen.step_with_extra_heads (lm.py:793-807): softmax(extra_head(transformer_out)) of the LAST step for every head:
  * probs f32 [model rows, extra_heads_num_heads, extra_heads_dim]. */
 int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream);

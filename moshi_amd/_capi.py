@@ -92,6 +92,7 @@ SIGNATURES = {
     "mmi_lm_streaming_start": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), _P]),
     "mmi_lm_streaming_start_guided": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), C.POINTER(Guidance), _P]),
     "mmi_lm_model_rows": (C.c_int, [_P]),
+    "mmi_lm_stat": (C.c_int64, [_P, C.c_int32]),
     "mmi_lm_extra_heads": (C.c_int, [_P, _P, _P]),
     "mmi_lm_state_bytes": (C.c_int64, [_P]),
     "mmi_lm_state_save": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),

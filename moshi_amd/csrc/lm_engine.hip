@@ -91,6 +91,7 @@ struct mmi_lm {
     bool forced_armed = false;
     unsigned long long* rng = nullptr;
     long offset_cpu = 0;
+    long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
     MmiProgram prog;
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
@@ -273,12 +274,48 @@ int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmAr
     return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
 }
 
+// k_gemm_xlds (activations resident in LDS, one workgroup per CU): which GEMMs take it, and how.  Off unless MMI_GEMM_LDS=1:
+// built and checked on the simulator and in the microbenchmark this round, not yet validated in the step on hardware.
+struct XldsPlan { bool on; int kc, grid; size_t smem; };
+XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) {
+    XldsPlan p{false, 0, 0, 0};
+    const char* en = getenv("MMI_GEMM_LDS");
+    const bool enabled = en && en[0] && en[0] != '0';
+    if (!enabled || lm->T != 32 || g.wq != 0 || mt > 2) return p;
+    if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
+    int cus = 256;                                             // MI355X: 256 CUs
+    if (const char* e = getenv("MMI_GEMM_LDS_GRID")) cus = atoi(e) > 0 ? atoi(e) : cus;   // test hook
+    const int big = 64 / mt;
+    if (g.KSTEPS % big == 0 && g.NT >= 128) p.kc = big;       // the large temporal GEMMs
+    else if (getenv("MMI_GEMM_LDS_GRID") && g.KSTEPS % 8 == 0) p.kc = 8;   // tiny shapes of the tests
+    else return p;
+    p.grid = g.NT < cus ? g.NT : cus;
+    if (mmi_cdiv(g.NT, p.grid) > 3) return p;
+    const size_t chunks = (size_t)2 * mt * p.kc * 1024, red = mt == 1 ? 40960 : 65536;   // the epilogue's reduction scratch (8 waves x 64 lanes x LS floats per batch tile)
+    p.smem = chunks > red ? chunks : red;
+    p.on = true;
+    return p;
+}
+
+template <int MT, int KC>
+int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
+    }
+    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3>), p.grid, 512, p.smem, s, a);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
+    const XldsPlan xl = plan_xlds(lm, g, a, mt);
     EvPair* ev = nullptr;
     if (lm->profiling && is_dominant) {
         if (lm->ev_used == lm->ev_pool.size()) {
@@ -291,7 +328,14 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
         lm->prof_stream = s;
         MMI_HIP_CHECK(hipEventRecord(ev->a, s));
     }
-    int rc = lm->T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
+    int rc;
+    if (xl.on) {
+        lm->xlds_launches += 1;
+        if (mt == 1) rc = xl.kc == 64 ? launch_xlds<1, 64>(s, xl, a) : launch_xlds<1, 8>(s, xl, a);
+        else rc = xl.kc == 32 ? launch_xlds<2, 32>(s, xl, a) : launch_xlds<2, 8>(s, xl, a);
+    } else {
+        rc = lm->T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
+    }
     if (rc) return rc;
     if (ev) MMI_HIP_CHECK(hipEventRecord(ev->b, s));
     return MMI_OK;
@@ -957,6 +1001,11 @@ extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
 }
 
 extern "C" int mmi_lm_model_rows(const mmi_lm* lm) { return lm ? lm->batch : 0; }
+
+extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
+    if (!lm) return -1;
+    return which == 0 ? (int64_t)lm->xlds_launches : -1;
+}
 
 extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");

@@ -206,16 +206,24 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 
 // Split-K reduction across the workgroup's waves (fixed order -> deterministic) and the epilogue shared by the GEMM
 // kernels: one task = 8 consecutive output features of one session, written as one 16-byte vector.
-template <int TN, int MT, int NTW, int WAVES>
+// EXT: the reduction scratch is handed in (`red_ext`, WAVES * NTW * MT * 64 * LS floats) instead of a static LDS array - for
+// kernels that own all of the LDS themselves (k_gemm_xlds).
+template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
-                                                  int nt0, u32x4 pre) {
+                                                  int nt0, u32x4 pre, float* red_ext = nullptr) {
     constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic).  LDS layout [wave][tile][lane][LS]:
     // a lane's accumulators are contiguous, so they go out and come back as 16-byte vectors; LS = 20 floats (80 B)
     // spreads the 8 lanes of a ds_*_b128 group over all 32 banks.
     constexpr int LS = R == 4 ? 4 : ((WAVES * NTW * MT * 64 * 20 * 4 <= 65536) ? 20 : 16);
     constexpr int NE = NTW * MT * 64 * LS;
-    MMI_SHARED __attribute__((aligned(16))) float red[WAVES * NE];
+    float* red;
+    if constexpr (EXT) {
+        red = red_ext;
+    } else {
+        MMI_SHARED __attribute__((aligned(16))) float red_static[WAVES * NE];
+        red = red_static;
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -624,6 +632,108 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
     mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u});
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-streaming GEMM with the activations resident in LDS
+// ------------------------------------------------------------------------------------------------
+// k_gemm_xp re-reads the whole activation matrix from L2 in every workgroup (one per n-tile): at 32 sessions that is as many
+// L2 bytes as the weights themselves, at 64 twice as many, and the L2 (about 10-11 TB/s of 128-byte requests) - not HBM -
+// becomes the bound (profiles/r01_pmc_sq_tcc_ffn_in_b32_b64.csv).  Here ONE workgroup per CU walks a contiguous
+// range of up to NTMAX n-tiles.  K is cut into chunks of KC k-steps whose activation fragments (MT x KC KiB) are staged in LDS,
+// double-buffered, so every activation byte leaves the L2 once per workgroup; the 8 waves split a chunk's k-steps, stream their
+// KPW weight fragments per (chunk, tile) segment from HBM one segment ahead of the MFMAs (register double buffer) and read
+// the activation fragments with ds_read_b128.  The tiles' accumulators stay in registers across the chunks; at the end each
+// tile goes through the common split-K reduction + epilogue, with the reduction scratch laid over the (then idle) chunk buffers.
+// Prototype in scripts/gemm_microbench.hip (main loop only): 31.7 us against 34.8 us at 32 sessions, 37.4 against 51 us at 64.
+// bf16 weights, 32-row tiles.  Dynamic LDS = max(2 * MT * KC KiB, reduction scratch); a.KSTEPS % KC == 0.
+template <int MT, int KC, int NTMAX = 3>
+__global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    constexpr int KPW = KC / 8;                 // k-steps per wave per chunk
+    constexpr int XE = MT * KC * 64;            // 16-byte activation pieces per chunk
+    constexpr int XPT = (XE + 511) / 512;       // ... per thread
+    static_assert(KC % 8 == 0, "a chunk is split over 8 waves");
+    MMI_DYN_SHARED(u32x4, xs);                  // [2][XE], later the reduction scratch
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int t0 = (int)((long)bid * a.NT / G), t1 = (int)((long)(bid + 1) * a.NT / G);
+    const int ntiles = t1 - t0;                 // <= NTMAX (the launcher sizes the grid)
+    const int nchunks = a.KSTEPS / KC;
+    acc_t acc[NTMAX][MT];
+#pragma unroll
+    for (int t = 0; t < NTMAX; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+    // chunk c of the packed activations Xp[m][ks][lane] -> xs[buf][(m * KC + k) * 64 + lane]
+    auto xsrc = [&](int c, int e) {
+        const int m = e / (KC * 64), rest = e - m * (KC * 64);
+        return a.xp + ((long)m * a.KSTEPS + (long)c * KC) * 64 + rest;
+    };
+    u32x4 xpre[XPT];
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+        const int e = min(j * 512 + tid, XE - 1);
+        xpre[j] = *xsrc(0, e);
+    }
+#pragma unroll
+    for (int j = 0; j < XPT; ++j)
+        if (j * 512 + tid < XE) xs[j * 512 + tid] = xpre[j];
+    auto wsrc = [&](int c, int t) { return a.wp + ((long)min(t0 + t, a.NT - 1) * a.KSTEPS + (long)c * KC + wave * KPW) * 64 + lane; };
+    u32x4 cur[KPW], nxt[KPW];
+    {
+        const u32x4* wp = wsrc(0, 0);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) cur[i] = mmi_load_nt(wp + i * 64);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                        // chunk c is in xs[c & 1]; nobody reads xs[(c + 1) & 1] any more
+        const int cn = min(c + 1, nchunks - 1); // unconditional prefetch of the next chunk (the last one re-reads itself)
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            const int e = min(j * 512 + tid, XE - 1);
+            xpre[j] = *xsrc(cn, e);
+        }
+        const u32x4* xb = xs + (c & 1) * XE + wave * KPW * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NTMAX; ++t) {
+            if (t < ntiles) {
+                // the weights of the NEXT segment - (chunk c, tile t + 1), or (chunk c + 1, first tile) - are requested first
+                const bool last_tile = t == ntiles - 1;
+                const int nc = min(last_tile ? c + 1 : c, nchunks - 1), nt = last_tile ? 0 : t + 1;
+                const u32x4* wp = wsrc(nc, nt);
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) nxt[i] = mmi_load_nt(wp + i * 64);
+#pragma unroll
+                for (int i = 0; i < KPW; ++i)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[t][m] = mmi_mfma_bf16_32x32x16(cur[i], xb[(m * KC + i) * 64], acc[t][m]);
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
+            }
+        }
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j)
+                if (j * 512 + tid < XE) xs[((c + 1) & 1) * XE + j * 512 + tid] = xpre[j];
+        }
+    }
+    // ---- per tile: split-K reduction over the 8 waves + the common epilogue; the scratch overlays the chunk buffers
+    float* red = reinterpret_cast<float*>(xs);
+#pragma unroll
+    for (int t = 0; t < NTMAX; ++t) {
+        if (t < ntiles) {
+            __syncthreads();                    // the chunk buffers / the previous tile's scratch are no longer read
+            float accv[1][MT][16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
+            mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,6 +9,9 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
 
 #define CK(x)                                                                              \
     do {                                                                                   \
@@ -64,6 +67,95 @@ __global__ __launch_bounds__(WAVES * 64) void k_probe_xcost(const u32x4* __restr
     float t = 0.f;
     for (int r = 0; r < 16; ++r) t += acc[r];
     if (t == 12345.678f) sink[threadIdx.x] = t;
+}
+
+
+// ---- prototype: activations resident in LDS ----------------------------------------------------------------------
+// One workgroup per CU walks a contiguous range of n-tiles.  K is cut into chunks of KC k-steps whose activation fragments
+// (MT x KC KiB = 64 KiB) are staged in LDS, double-buffered: every activation byte leaves the L2 ONCE per workgroup instead
+// of once per n-tile.  The 8 waves split each chunk's k-steps; per (chunk, tile) segment a wave streams its KPW weight
+// fragments from HBM one segment ahead of the MFMAs (register double buffer) and reads the activation fragments from LDS
+// (ds_read_b128).  Accumulators of the up-to-3 tiles stay in registers across the chunks.  Epilogue: the per-wave partial tiles
+// go out raw (the host sums the 8 waves for the check) - this measures the main loop, like k_probe_xcost.
+template <int MT>
+__global__ __launch_bounds__(512) void k_probe_lds(const u32x4* __restrict__ wpk, const u32x4* __restrict__ xpk, int KSTEPS, int NT,
+                                                   float* __restrict__ out /* [NT][MT][8][64][16] or null */) {
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    constexpr int KC = 64 / MT;                 // k-steps per chunk
+    constexpr int KPW = KC / 8;                 // k-steps per wave per chunk
+    constexpr int XPT = MT * KC * 64 / 512;     // 16-byte activation pieces per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);          // [2][MT*KC*64]
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int t0 = (int)((long)bid * NT / G), t1 = (int)((long)(bid + 1) * NT / G);
+    const int ntiles = t1 - t0;                 // <= 3 (checked by the launcher)
+    const int nchunks = KSTEPS / KC;
+    acc_t acc[3][MT];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+    // activation chunk c lives at xpk[(m*KSTEPS + c*KC + k)*64 + lane]; LDS copy at xs[buf][(m*KC + k)*64 + lane]
+    auto xsrc = [&](int c, int j) {             // j-th piece of this thread
+        const int e = j * 512 + tid;            // 0 .. MT*KC*64
+        const int m = e / (KC * 64), rest = e - m * (KC * 64);
+        return xpk + ((long)m * KSTEPS + (long)c * KC) * 64 + rest;
+    };
+    u32x4 xpre[XPT];
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) xpre[j] = *xsrc(0, j);
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) xs[j * 512 + tid] = xpre[j];
+    auto wsrc = [&](int c, int t) { return wpk + ((long)(t0 + t) * KSTEPS + (long)c * KC + wave * KPW) * 64 + lane; };
+    u32x4 cur[KPW], nxt[KPW];
+    {
+        const u32x4* wp = wsrc(0, 0);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) cur[i] = mmi_load_nt(wp + i * 64);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                        // chunk c is in xs[c & 1]; nobody reads xs[(c + 1) & 1] any more
+        const bool more = c + 1 < nchunks;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j) xpre[j] = *xsrc(c + 1, j);
+        }
+        const u32x4* xb = xs + (c & 1) * (MT * KC * 64) + wave * KPW * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (t < ntiles) {
+                const bool last_tile = t == ntiles - 1;
+                const int nc = last_tile ? c + 1 : c, nt = last_tile ? 0 : t + 1;
+                if (nc < nchunks) {
+                    const u32x4* wp = wsrc(nc, nt);
+#pragma unroll
+                    for (int i = 0; i < KPW; ++i) nxt[i] = mmi_load_nt(wp + i * 64);
+                }
+#pragma unroll
+                for (int i = 0; i < KPW; ++i)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[t][m] = mmi_mfma_bf16_32x32x16(cur[i], xb[(m * KC + i) * 64], acc[t][m]);
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j) xs[((c + 1) & 1) * (MT * KC * 64) + j * 512 + tid] = xpre[j];
+        }
+    }
+    if (out) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < ntiles)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[((((long)(t0 + t) * MT + m) * 8 + wave) * 64 + lane) * 16 + r] = acc[t][m][r];
+    }
 }
 
 struct Shape { const char* name; int N, K, gate; };
@@ -165,6 +257,60 @@ int main(int argc, char** argv) {
                 const double us = 1e3 * ms / (reps * nbuf);
                 printf("   main loop only, %-24s %8.2f us  %7.0f GB/s\n", mode == 0 ? "operand fragments from L2" : "no operand loads", us, wbytes / us / 1e3);
             }
+        }
+        if (T == 32 && MT <= 2 && KS % 64 == 0 && NT <= 3 * 256 && getenv("MB_LDS")) {   // the LDS-resident prototype
+            const int G = 256;
+            float* pout;
+            const size_t pout_elems = (size_t)NT * MT * 8 * 64 * 16;
+            CK(hipMalloc(&pout, pout_elems * sizeof(float)));
+            auto launch = [&](const u32x4* wv, float* o) {
+                if (MT == 1) hipLaunchKernelGGL((k_probe_lds<1>), dim3(G), dim3(512), 131072, s, wv, (const u32x4*)x, KS, NT, o);
+                else hipLaunchKernelGGL((k_probe_lds<2>), dim3(G), dim3(512), 131072, s, wv, (const u32x4*)x, KS, NT, o);
+            };
+            CK(hipFuncSetAttribute((const void*)k_probe_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            CK(hipFuncSetAttribute((const void*)k_probe_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            launch((const u32x4*)w, pout);
+            CK(hipStreamSynchronize(s));
+            CK(hipGetLastError());
+            {   // check a few tiles against the packed operands on the host
+                std::vector<float> ho(pout_elems);
+                std::vector<uint16_t> hw((size_t)NT * KS * 512), hx((size_t)MT * KS * 512);
+                CK(hipMemcpy(ho.data(), pout, pout_elems * sizeof(float), hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hw.data(), w, hw.size() * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hx.data(), x, hx.size() * 2, hipMemcpyDeviceToHost));
+                auto bf = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+                double worst = 0;
+                for (int nt : {0, 1, NT / 2, NT - 1})
+                    for (int m = 0; m < MT; ++m)
+                        for (int i : {0, 5, 31})
+                            for (int j : {0, 17, 31}) {
+                                double ref = 0;
+                                for (int ks = 0; ks < KS; ++ks)
+                                    for (int kq = 0; kq < 2; ++kq)
+                                        for (int e = 0; e < 8; ++e)
+                                            ref += (double)bf(hw[(((size_t)nt * KS + ks) * 64 + kq * 32 + i) * 8 + e]) *
+                                                   bf(hx[(((size_t)m * KS + ks) * 64 + kq * 32 + j) * 8 + e]);
+                                // D[i][j] lives in lane j + 32*((i>>2)&1), register (i&3) + 4*(i>>3)
+                                const int ln = j + 32 * ((i >> 2) & 1), rg = (i & 3) + 4 * (i >> 3);
+                                double got = 0;
+                                for (int wv = 0; wv < 8; ++wv) got += ho[((((size_t)nt * MT + m) * 8 + wv) * 64 + ln) * 16 + rg];
+                                worst = fmax(worst, fabs(got - ref) / (fabs(ref) + 1e-3));
+                            }
+                printf("   LDS-resident prototype: worst relative error on sampled outputs %.2e\n", worst);
+            }
+            const int reps = wbytes > 50e6 ? 3 : 10;
+            for (int i = 0; i < nbuf; ++i) launch((const u32x4*)(w + welems * i), nullptr);
+            CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r) for (int i = 0; i < nbuf; ++i) launch((const u32x4*)(w + welems * i), nullptr);
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / (reps * nbuf);
+            printf("   LDS-resident prototype, 256 workgroups   %8.2f us  %7.0f GB/s   (main loop only)\n", us, wbytes / us / 1e3);
+            CK(hipFree(pout));
         }
         for (const Variant& v : variants) {
             if (v.TN != T || v.MT != MT) continue;

@@ -78,5 +78,7 @@ hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, si
 hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipGetDevice(int* d);
 hipError_t hipSetDevice(int d);

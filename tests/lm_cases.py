@@ -173,7 +173,7 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
             prev_tt, prev_a0 = tt, toks[0]
 
 
-def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0):
+def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0, stats=None):
     sd = random_lm_state_dict(cfg, seed=seed)
     if quantize == "fp8":   # e4m3fn linears on the fp8 MFMA (BASELINE configs[4]); engine and oracle get the same fp8 tensors
         from moshi_amd.weights import quantize_lm_state_dict_fp8
@@ -210,6 +210,8 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
                     assert logits_close(al[b, k], oal[b, k]), f"step {s} row {b} cb {k}: {np.abs(al[b,k]-oal[b,k]).max()}"
                     a_e, a_o = int(al[b, k].argmax()), int(oat[b, k])
                     assert a_e == a_o or near_tie(oal[b, k], a_e, a_o)
+        if stats is not None:
+            stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
 
 
 def smoke_lm(dev):

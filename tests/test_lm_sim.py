@@ -59,6 +59,19 @@ def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=72, B=34, S=2)
 
 
+@pytest.mark.parametrize("B,grid", [(18, 8), (34, 8), (20, 64)])
+def test_gemm_with_activations_resident_in_lds(sim_lib, monkeypatch, B, grid):
+    """k_gemm_xlds (one workgroup walking several n-tiles with the activation chunks staged in LDS) on the tiny
+    shapes: gated FFN input, in_proj with RoPE / ring write and the row-major heads, one and two batch tiles, 1..3 tiles per
+    workgroup (grid 8: 22 / 12 tiles -> 2-3 / 1-2 per workgroup; grid 64 > tiles: one tile each)."""
+    monkeypatch.setenv("MMI_GEMM_LDS", "1")
+    monkeypatch.setenv("MMI_GEMM_LDS_GRID", str(grid))
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=140 + B, B=B, S=3, stats=st)
+    # per step: 2 temporal layers x (in_proj + gated linear_in) + the text head + 8 audio heads take the kernel
+    assert st["xlds_launches"] >= 3 * (2 * 2 + 1)
+
+
 def test_depformer_in_per_step_launches(sim_lib, monkeypatch):
     """The engine normally runs the dep_q `depformer_in` linears as one grouped GEMM and lets each sampler add its token's
     embedding row; depth widths that are not whole n-tiles fall back to one GEMM per micro-step with the embedding in its
