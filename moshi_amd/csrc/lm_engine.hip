@@ -276,9 +276,9 @@ int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmAr
 
 // k_gemm_xlds (activations resident in LDS, one workgroup per CU): which GEMMs take it, and how.  Off unless MMI_GEMM_LDS=1:
 // built and checked on the simulator and in the microbenchmark this round, not yet validated in the step on hardware.
-struct XldsPlan { bool on; int kc, grid; size_t smem; };
+struct XldsPlan { bool on; int kc, grid; size_t smem; bool stagger; };
 XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) {
-    XldsPlan p{false, 0, 0, 0};
+    XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
     const bool enabled = en && en[0] && en[0] != '0';
     if (!enabled || lm->T != 32 || g.wq != 0 || mt > 2) return p;
@@ -292,21 +292,27 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     p.grid = g.NT < cus ? g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
     const size_t chunks = (size_t)2 * mt * p.kc * 1024, red = mt == 1 ? 40960 : 65536;   // the epilogue's reduction scratch (8 waves x 64 lanes x LS floats per batch tile)
+    p.stagger = en[0] == '2';                                 // MMI_GEMM_LDS=2: per-tile epilogues under the last chunk's stream
     p.smem = chunks > red ? chunks : red;
+    if (p.stagger && p.kc < 32) p.smem = chunks + red;       // test chunks: the scratch sits behind both buffers
     p.on = true;
     return p;
 }
 
-template <int MT, int KC>
-int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+template <int MT, int KC, bool STAGGER>
+int launch_xlds_v(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_set = true;
     }
-    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3>), p.grid, 512, p.smem, s, a);
+    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3, STAGGER>), p.grid, 512, p.smem, s, a);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
+}
+template <int MT, int KC>
+int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+    return p.stagger ? launch_xlds_v<MT, KC, true>(s, p, a) : launch_xlds_v<MT, KC, false>(s, p, a);
 }
 
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {

@@ -647,7 +647,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 // tile goes through the common split-K reduction + epilogue, with the reduction scratch laid over the (then idle) chunk buffers.
 // Prototype in scripts/gemm_microbench.hip (main loop only): 31.7 us against 34.8 us at 32 sessions, 37.4 against 51 us at 64.
 // bf16 weights, 32-row tiles.  Dynamic LDS = max(2 * MT * KC KiB, reduction scratch); a.KSTEPS % KC == 0.
-template <int MT, int KC, int NTMAX = 3>
+// STAGGER (MMI_GEMM_LDS=2, not yet measured on hardware): in the LAST chunk each tile's reduction + epilogue runs right after
+// its MFMAs, on the chunk buffer that is idle by then, while the next tile's weights (requested before those MFMAs) are still
+// streaming - instead of all the tiles' epilogues one after the other behind a finished weight stream.
+template <int MT, int KC, int NTMAX = 3, bool STAGGER = false>
 __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(16)));
     constexpr int KPW = KC / 8;                 // k-steps per wave per chunk
@@ -712,6 +715,20 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                     for (int m = 0; m < MT; ++m) acc[t][m] = mmi_mfma_bf16_32x32x16(cur[i], xb[(m * KC + i) * 64], acc[t][m]);
 #pragma unroll
                 for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
+                if constexpr (STAGGER) {
+                    if (c == nchunks - 1) {
+                        // scratch: the other chunk buffer (last read before this chunk's opening barrier, not refilled any more);
+                        // the small test chunks are smaller than the scratch, which then sits behind both buffers
+                        float* red = reinterpret_cast<float*>(KC >= 32 ? xs + (nchunks & 1) * XE : xs + 2 * XE);
+                        __syncthreads();        // the previous tile's output tasks are done with the scratch
+                        float accv[1][MT][16];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
+                        mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
+                    }
+                }
             }
         }
         if (c + 1 < nchunks) {
@@ -720,6 +737,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                 if (j * 512 + tid < XE) xs[((c + 1) & 1) * XE + j * 512 + tid] = xpre[j];
         }
     }
+    if constexpr (STAGGER) return;
     // ---- per tile: split-K reduction over the 8 waves + the common epilogue; the scratch overlays the chunk buffers
     float* red = reinterpret_cast<float*>(xs);
 #pragma unroll
