@@ -650,6 +650,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 // STAGGER (MMI_GEMM_LDS=2, not yet measured on hardware): in the LAST chunk each tile's reduction + epilogue runs right after
 // its MFMAs, on the chunk buffer that is idle by then, while the next tile's weights (requested before those MFMAs) are still
 // streaming - instead of all the tiles' epilogues one after the other behind a finished weight stream.
+struct MmiTrue { static constexpr bool value = true; };
+struct MmiFalse { static constexpr bool value = false; };
 template <int MT, int KC, int NTMAX = 3, bool STAGGER = false>
 __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(16)));
@@ -691,13 +693,16 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < KPW; ++i) cur[i] = mmi_load_nt(wp + i * 64);
     }
-    for (int c = 0; c < nchunks; ++c) {
+    // one chunk: LAST = the final chunk (nothing to prefetch; with STAGGER each tile's epilogue follows its MFMAs at once)
+    auto run_chunk = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         __syncthreads();                        // chunk c is in xs[c & 1]; nobody reads xs[(c + 1) & 1] any more
-        const int cn = min(c + 1, nchunks - 1); // unconditional prefetch of the next chunk (the last one re-reads itself)
+        if constexpr (!LAST) {
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            const int e = min(j * 512 + tid, XE - 1);
-            xpre[j] = *xsrc(cn, e);
+            for (int j = 0; j < XPT; ++j) {
+                const int e = min(j * 512 + tid, XE - 1);
+                xpre[j] = *xsrc(c + 1, e);
+            }
         }
         const u32x4* xb = xs + (c & 1) * XE + wave * KPW * 64 + lane;
 #pragma unroll
@@ -715,28 +720,28 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                     for (int m = 0; m < MT; ++m) acc[t][m] = mmi_mfma_bf16_32x32x16(cur[i], xb[(m * KC + i) * 64], acc[t][m]);
 #pragma unroll
                 for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
-                if constexpr (STAGGER) {
-                    if (c == nchunks - 1) {
-                        // scratch: the other chunk buffer (last read before this chunk's opening barrier, not refilled any more);
-                        // the small test chunks are smaller than the scratch, which then sits behind both buffers
-                        float* red = reinterpret_cast<float*>(KC >= 32 ? xs + (nchunks & 1) * XE : xs + 2 * XE);
-                        __syncthreads();        // the previous tile's output tasks are done with the scratch
-                        float accv[1][MT][16];
+                if constexpr (STAGGER && LAST) {
+                    // scratch: the other chunk buffer (last read before this chunk's opening barrier, not refilled any more);
+                    // the small test chunks are smaller than the scratch, which then sits behind both buffers
+                    float* red = reinterpret_cast<float*>(KC >= 32 ? xs + (nchunks & 1) * XE : xs + 2 * XE);
+                    __syncthreads();            // the previous tile's output tasks are done with the scratch
+                    float accv[1][MT][16];
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
-                        mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
-                    }
+                        for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
+                    mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
                 }
             }
         }
-        if (c + 1 < nchunks) {
+        if constexpr (!LAST) {
 #pragma unroll
             for (int j = 0; j < XPT; ++j)
                 if (j * 512 + tid < XE) xs[((c + 1) & 1) * XE + j * 512 + tid] = xpre[j];
         }
-    }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) run_chunk(c, MmiFalse{});
+    run_chunk(nchunks - 1, MmiTrue{});
     if constexpr (STAGGER) return;
     // ---- per tile: split-K reduction over the 8 waves + the common epilogue; the scratch overlays the chunk buffers
     float* red = reinterpret_cast<float*>(xs);

@@ -129,16 +129,6 @@ def test_guidance_conditioning_and_extra_heads_match_reference_golden(gpu_lib, n
     lm_cases.check_cfg_engine(DEV, None, name)
 
 
-@pytest.mark.parametrize("B", [18, 40])
-def test_lds_resident_gemm_full_width_matches_oracle(gpu_lib, monkeypatch, B):
-    """MMI_GEMM_LDS=1: the temporal in_proj / gated linear_in and the grouped depformer_in run on k_gemm_xlds (activations
-    staged in LDS, one workgroup per CU walking 1-3 n-tiles) at the 7B layer shapes, one and two batch tiles, vs the oracle."""
-    monkeypatch.setenv("MMI_GEMM_LDS", "1")
-    st = {}
-    lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=15, B=B, S=2, use_masks=False, stats=st)
-    assert st["xlds_launches"] >= 2 * 2 + 1
-
-
 def test_sampling_without_top_k_is_a_multinomial_over_the_whole_vocabulary(gpu_lib):
     lm_cases.check_full_multinomial(DEV, None, steps=6, B=5)
 
