@@ -258,7 +258,7 @@ int main(int argc, char** argv) {
                 printf("   main loop only, %-24s %8.2f us  %7.0f GB/s\n", mode == 0 ? "operand fragments from L2" : "no operand loads", us, wbytes / us / 1e3);
             }
         }
-        if (T == 32 && MT <= 2 && KS % 64 == 0 && NT <= 3 * 256 && getenv("MB_LDS")) {   // the LDS-resident prototype
+        if (T == 32 && MT <= 2 && KS % 64 == 0 && NT <= 3 * 256 && NT >= 128 && getenv("MB_LDS")) {   // the LDS-resident prototype
             const int G = 256;
             float* pout;
             const size_t pout_elems = (size_t)NT * MT * 8 * 64 * 16;
@@ -311,6 +311,36 @@ int main(int argc, char** argv) {
             const double us = 1e3 * ms / (reps * nbuf);
             printf("   LDS-resident prototype, 256 workgroups   %8.2f us  %7.0f GB/s   (main loop only)\n", us, wbytes / us / 1e3);
             CK(hipFree(pout));
+            // the product kernel (k_gemm_xlds: the same loop + the common epilogue), plain and staggered tails
+            for (int stagger = 0; stagger < 2; ++stagger) {
+                GemmArgs a;
+                memset(&a, 0, sizeof(a));
+                a.xp = (const u32x4*)x; a.out = out; a.B = B; a.N = sh.N; a.KSTEPS = KS; a.NT = NT;
+                a.out_mode = MMI_OUT_PACKED; a.out_ld = sh.N; a.out_ksteps = out_ks;
+                a.epi = sh.gate ? MMI_EPI_GATE : MMI_EPI_STORE;
+                a.gate_rows = sh.gate ? sh.N : 0;
+                auto go = [&](const u32x4* wv) {
+                    a.wp = wv;
+                    if (MT == 1 && !stagger) hipLaunchKernelGGL((k_gemm_xlds<1, 64, 3, false>), dim3(G), dim3(512), 131072, s, a);
+                    else if (MT == 1) hipLaunchKernelGGL((k_gemm_xlds<1, 64, 3, true>), dim3(G), dim3(512), 131072, s, a);
+                    else if (!stagger) hipLaunchKernelGGL((k_gemm_xlds<2, 32, 3, false>), dim3(G), dim3(512), 131072, s, a);
+                    else hipLaunchKernelGGL((k_gemm_xlds<2, 32, 3, true>), dim3(G), dim3(512), 131072, s, a);
+                };
+                CK(hipFuncSetAttribute((const void*)k_gemm_xlds<1, 64, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+                CK(hipFuncSetAttribute((const void*)k_gemm_xlds<1, 64, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+                CK(hipFuncSetAttribute((const void*)k_gemm_xlds<2, 32, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+                CK(hipFuncSetAttribute((const void*)k_gemm_xlds<2, 32, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+                for (int i = 0; i < nbuf; ++i) go((const u32x4*)(w + welems * i));
+                CK(hipStreamSynchronize(s));
+                CK(hipGetLastError());
+                CK(hipEventRecord(e0, s));
+                for (int r = 0; r < reps; ++r) for (int i = 0; i < nbuf; ++i) go((const u32x4*)(w + welems * i));
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double us2 = 1e3 * ms / (reps * nbuf);
+                printf("   k_gemm_xlds %-28s %8.2f us  %7.0f GB/s   (whole kernel)\n", stagger ? "(staggered epilogues)" : "(epilogues at the end)", us2, wbytes / us2 / 1e3);
+            }
         }
         for (const Variant& v : variants) {
             if (v.TN != T || v.MT != MT) continue;
