@@ -6,16 +6,7 @@ mkdir -p gpurun_out
 O=$GRAFT_REPO_ROOT/gpurun_out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -Imoshi_amd/csrc scripts/gemm_microbench.hip moshi_amd/csrc/api_common.hip -o /tmp/gemm_microbench > $O/mb_build.log 2>&1 || cat $O/mb_build.log
 for B in 32 64; do MB_LDS=1 timeout 200 /tmp/gemm_microbench $B 1 > $O/next_mb_lds_b$B.txt 2>&1; done
-MMI_GEMM_LDS=2 timeout 300 python - > $O/next_xlds_mode2_parity.log 2>&1 <<'PY'
-import sys
-sys.path.insert(0, ".")
-from moshi_amd.config import LMConfig
-from tests import lm_cases
-for B in (18, 40):
-    st = {}
-    lm_cases.oracle_vs_engine("cuda", None, LMConfig(num_layers=2, context=64), seed=15, B=B, S=2, use_masks=False, stats=st)
-    print("mode 2 parity ok at", B, "sessions,", st["xlds_launches"], "launches")
-PY
+MMI_TEST_XLDS_MODES=1,2 timeout 400 python -m pytest tests/test_zz_experimental_gpu.py -m gpu -q --timeout=300 > $O/next_xlds_mode2_parity.log 2>&1
 for mode in 0 1 2 0 1 2; do
   MMI_GEMM_LDS=$mode timeout 200 python bench.py --no-cpu-baseline > $O/next_bench_lds$mode.log 2>&1
   echo "MMI_GEMM_LDS=$mode $(grep '"metric"' $O/next_bench_lds$mode.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms/step %.3f  dominant kernel %.2f us' % (d['ms_per_step'], 1e3*d['roofline']['avg_launch_ms']))")"

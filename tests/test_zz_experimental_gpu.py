@@ -10,8 +10,14 @@ DEV = "cuda"
 
 
 # mode "2" (each tile's epilogue under the last chunk's weight stream) has only run on the simulator so far
-# (tests/test_lm_sim.py); it joins this list once it has been timed and checked on hardware
-@pytest.mark.parametrize("B,mode", [(18, "1"), (40, "1")])
+# (tests/test_lm_sim.py); it joins the default list once it has been timed and checked on hardware:
+# MMI_TEST_XLDS_MODES=1,2 python -m pytest tests/test_zz_experimental_gpu.py -m gpu   (scripts/gpu_next_xlds.sh)
+import os
+
+_MODES = os.environ.get("MMI_TEST_XLDS_MODES", "1").split(",")
+
+
+@pytest.mark.parametrize("B,mode", [(B, m) for m in _MODES for B in (18, 40)])
 def test_lds_resident_gemm_full_width_matches_oracle(gpu_lib, monkeypatch, B, mode):
     """MMI_GEMM_LDS=1: the temporal in_proj / gated linear_in and the grouped depformer_in run on k_gemm_xlds (activations
     staged in LDS, one workgroup per CU walking 1-3 n-tiles) at the 7B layer shapes, one and two batch tiles, vs the oracle;
