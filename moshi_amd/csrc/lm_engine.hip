@@ -281,38 +281,52 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
     const bool enabled = en && en[0] && en[0] != '0';
-    if (!enabled || lm->T != 32 || g.wq != 0 || mt > 2) return p;
+    if (!enabled || lm->T != 32 || mt > 2) return p;
     if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
-    if (const char* e = getenv("MMI_GEMM_LDS_GRID")) cus = atoi(e) > 0 ? atoi(e) : cus;   // test hook
-    const int big = 64 / mt;
+    const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
+    if (tg && atoi(tg) > 0) cus = atoi(tg);
+    const int xs = g.wq ? 2 : 1;                               // activation fragments per weight entry
+    const int big = (g.wq ? 32 : 64) / mt;                     // 64 KiB of activations per chunk buffer
     if (g.KSTEPS % big == 0 && g.NT >= 128) p.kc = big;       // the large temporal GEMMs
-    else if (getenv("MMI_GEMM_LDS_GRID") && g.KSTEPS % 8 == 0) p.kc = 8;   // tiny shapes of the tests
+    else if (tg && g.KSTEPS % 8 == 0) p.kc = 8;
+    else if (tg && g.KSTEPS % 4 == 0) p.kc = 4;
     else return p;
     p.grid = g.NT < cus ? g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
-    const size_t chunks = (size_t)2 * mt * p.kc * 1024, red = mt == 1 ? 40960 : 65536;   // the epilogue's reduction scratch (8 waves x 64 lanes x LS floats per batch tile)
-    p.stagger = en[0] == '2';                                 // MMI_GEMM_LDS=2: per-tile epilogues under the last chunk's stream
+    p.stagger = en[0] == '2' && g.wq == 0;                    // MMI_GEMM_LDS=2: per-tile epilogues under the last chunk's stream (bf16)
+    const size_t chunks = (size_t)2 * mt * p.kc * xs * 1024, red = mt == 1 ? 40960 : 65536;   // red: the epilogue's reduction scratch
     p.smem = chunks > red ? chunks : red;
-    if (p.stagger && p.kc < 32) p.smem = chunks + red;       // test chunks: the scratch sits behind both buffers
+    if (p.stagger && chunks < 131072) p.smem = chunks + red; // short test chunks: the scratch sits behind both buffers
     p.on = true;
     return p;
 }
 
-template <int MT, int KC, bool STAGGER>
+template <int MT, int KC, bool STAGGER, int WQ>
 int launch_xlds_v(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3, STAGGER, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_set = true;
     }
-    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3, STAGGER>), p.grid, 512, p.smem, s, a);
+    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3, STAGGER, WQ>), p.grid, 512, p.smem, s, a);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
-template <int MT, int KC>
+// production chunk (64 / MT k-steps, or 32 / MT two-step entries) or one of the short test chunks
+template <int MT, bool STAGGER, int WQ>
+int launch_xlds_kc(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+    constexpr int BIG = (WQ ? 32 : 64) / MT;
+    if (p.kc == BIG) return launch_xlds_v<MT, BIG, STAGGER, WQ>(s, p, a);
+    if (p.kc == 8) return launch_xlds_v<MT, 8, STAGGER, WQ>(s, p, a);
+    if (p.kc == 4) return launch_xlds_v<MT, 4, STAGGER, WQ>(s, p, a);
+    return mmi_fail(MMI_ERR_UNSUPPORTED, "k_gemm_xlds: unsupported chunk");
+}
+template <int MT>
 int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
-    return p.stagger ? launch_xlds_v<MT, KC, true>(s, p, a) : launch_xlds_v<MT, KC, false>(s, p, a);
+    if (a.wq == 1) return launch_xlds_kc<MT, false, 1>(s, p, a);
+    if (a.wq == 2) return launch_xlds_kc<MT, false, 2>(s, p, a);
+    return p.stagger ? launch_xlds_kc<MT, true, 0>(s, p, a) : launch_xlds_kc<MT, false, 0>(s, p, a);
 }
 
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
@@ -337,8 +351,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     int rc;
     if (xl.on) {
         lm->xlds_launches += 1;
-        if (mt == 1) rc = xl.kc == 64 ? launch_xlds<1, 64>(s, xl, a) : launch_xlds<1, 8>(s, xl, a);
-        else rc = xl.kc == 32 ? launch_xlds<2, 32>(s, xl, a) : launch_xlds<2, 8>(s, xl, a);
+        rc = mt == 1 ? launch_xlds<1>(s, xl, a) : launch_xlds<2>(s, xl, a);
     } else {
         rc = lm->T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
     }

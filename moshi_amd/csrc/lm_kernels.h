@@ -652,15 +652,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 // streaming - instead of all the tiles' epilogues one after the other behind a finished weight stream.
 struct MmiTrue { static constexpr bool value = true; };
 struct MmiFalse { static constexpr bool value = false; };
-template <int MT, int KC, int NTMAX = 3, bool STAGGER = false>
+// WQ = 1 / 2: int8 / fp8 weight entries (two k-steps per 16-byte entry, see k_gemm_xp): KC and a.KSTEPS count ENTRIES and every
+// entry meets XS = 2 activation fragments, so the production chunk is 32 / MT entries (the same 64 KiB of activations).
+// Chunks shorter than 8 entries (the tiny shapes of the tests) leave the upper waves without k-steps: they keep zero
+// accumulators and only take part in the barriers and the epilogue.
+template <int MT, int KC, int NTMAX = 3, bool STAGGER = false, int WQ = 0>
 __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(16)));
-    constexpr int KPW = KC / 8;                 // k-steps per wave per chunk
-    constexpr int XE = MT * KC * 64;            // 16-byte activation pieces per chunk
+    constexpr int XS = WQ ? 2 : 1;              // activation fragments per weight entry
+    constexpr int KPW = KC >= 8 ? KC / 8 : 1;   // entries per wave per chunk
+    constexpr int ACTIVE = KC / KPW;            // waves that own k-steps
+    constexpr int XE = MT * KC * XS * 64;       // 16-byte activation pieces per chunk
     constexpr int XPT = (XE + 511) / 512;       // ... per thread
-    static_assert(KC % 8 == 0, "a chunk is split over 8 waves");
+    static_assert(KC % KPW == 0 && ACTIVE <= 8, "a chunk is split over at most 8 waves");
     MMI_DYN_SHARED(u32x4, xs);                  // [2][XE], later the reduction scratch
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool active = ACTIVE == 8 || wave < ACTIVE;
+    const int wk = active ? wave : 0;           // idle waves point at valid addresses and never load
     const int G = (int)gridDim.x, bid = (int)blockIdx.x;
     const int t0 = (int)((long)bid * a.NT / G), t1 = (int)((long)(bid + 1) * a.NT / G);
     const int ntiles = t1 - t0;                 // <= NTMAX (the launcher sizes the grid)
@@ -672,10 +680,10 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
-    // chunk c of the packed activations Xp[m][ks][lane] -> xs[buf][(m * KC + k) * 64 + lane]
+    // chunk c of the packed activations Xp[m][ks][lane] (XS fragments per entry) -> xs[buf][((m * KC + k) * XS + x) * 64 + lane]
     auto xsrc = [&](int c, int e) {
-        const int m = e / (KC * 64), rest = e - m * (KC * 64);
-        return a.xp + ((long)m * a.KSTEPS + (long)c * KC) * 64 + rest;
+        const int m = e / (KC * XS * 64), rest = e - m * (KC * XS * 64);
+        return a.xp + ((long)m * a.KSTEPS + (long)c * KC) * XS * 64 + rest;
     };
     u32x4 xpre[XPT];
 #pragma unroll
@@ -686,13 +694,35 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < XPT; ++j)
         if (j * 512 + tid < XE) xs[j * 512 + tid] = xpre[j];
-    auto wsrc = [&](int c, int t) { return a.wp + ((long)min(t0 + t, a.NT - 1) * a.KSTEPS + (long)c * KC + wave * KPW) * 64 + lane; };
+    auto wsrc = [&](int c, int t) { return a.wp + ((long)min(t0 + t, a.NT - 1) * a.KSTEPS + (long)c * KC + wk * KPW) * 64 + lane; };
     u32x4 cur[KPW], nxt[KPW];
-    {
+    if (active) {
         const u32x4* wp = wsrc(0, 0);
 #pragma unroll
         for (int i = 0; i < KPW; ++i) cur[i] = mmi_load_nt(wp + i * 64);
     }
+    // one weight entry against the resident activations
+    auto mma = [&](const u32x4& w, const u32x4* xe, acc_t (&ac)[MT]) {
+        if constexpr (WQ == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ac[m] = mmi_mfma_bf16_32x32x16(w, xe[m * KC * XS * 64], ac[m]);
+        } else if constexpr (WQ == 1) {
+            u32x4 lo, hi;
+            mmi_i8x16_to_bf16(w, lo, hi);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ac[m] = mmi_mfma_bf16_32x32x16(lo, xe[m * KC * XS * 64], ac[m]);
+                ac[m] = mmi_mfma_bf16_32x32x16(hi, xe[m * KC * XS * 64 + 64], ac[m]);
+            }
+        } else {
+            const u32x2 w0 = {w[0], w[1]}, w1 = {w[2], w[3]};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ac[m] = mmi_mfma_fp8_32x32x16(w0, mmi_bf16x8_to_fp8(xe[m * KC * XS * 64], a.xinv), ac[m]);
+                ac[m] = mmi_mfma_fp8_32x32x16(w1, mmi_bf16x8_to_fp8(xe[m * KC * XS * 64 + 64], a.xinv), ac[m]);
+            }
+        }
+    };
     // one chunk: LAST = the final chunk (nothing to prefetch; with STAGGER each tile's epilogue follows its MFMAs at once)
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -704,26 +734,26 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                 xpre[j] = *xsrc(c + 1, e);
             }
         }
-        const u32x4* xb = xs + (c & 1) * XE + wave * KPW * 64 + lane;
+        const u32x4* xb = xs + (c & 1) * XE + wk * KPW * XS * 64 + lane;
 #pragma unroll
         for (int t = 0; t < NTMAX; ++t) {
             if (t < ntiles) {
-                // the weights of the NEXT segment - (chunk c, tile t + 1), or (chunk c + 1, first tile) - are requested first
-                const bool last_tile = t == ntiles - 1;
-                const int nc = min(last_tile ? c + 1 : c, nchunks - 1), nt = last_tile ? 0 : t + 1;
-                const u32x4* wp = wsrc(nc, nt);
+                if (active) {
+                    // the weights of the NEXT segment - (chunk c, tile t + 1), or (chunk c + 1, first tile) - are requested first
+                    const bool last_tile = t == ntiles - 1;
+                    const int nc = min(last_tile ? c + 1 : c, nchunks - 1), nt = last_tile ? 0 : t + 1;
+                    const u32x4* wp = wsrc(nc, nt);
 #pragma unroll
-                for (int i = 0; i < KPW; ++i) nxt[i] = mmi_load_nt(wp + i * 64);
+                    for (int i = 0; i < KPW; ++i) nxt[i] = mmi_load_nt(wp + i * 64);
 #pragma unroll
-                for (int i = 0; i < KPW; ++i)
+                    for (int i = 0; i < KPW; ++i) mma(cur[i], xb + i * XS * 64, acc[t]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[t][m] = mmi_mfma_bf16_32x32x16(cur[i], xb[(m * KC + i) * 64], acc[t][m]);
-#pragma unroll
-                for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
+                    for (int i = 0; i < KPW; ++i) cur[i] = nxt[i];
+                }
                 if constexpr (STAGGER && LAST) {
                     // scratch: the other chunk buffer (last read before this chunk's opening barrier, not refilled any more);
                     // the small test chunks are smaller than the scratch, which then sits behind both buffers
-                    float* red = reinterpret_cast<float*>(KC >= 32 ? xs + (nchunks & 1) * XE : xs + 2 * XE);
+                    float* red = reinterpret_cast<float*>(XE * 16 >= 65536 ? xs + (nchunks & 1) * XE : xs + 2 * XE);
                     __syncthreads();            // the previous tile's output tasks are done with the scratch
                     float accv[1][MT][16];
 #pragma unroll

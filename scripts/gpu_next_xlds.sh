@@ -11,5 +11,9 @@ for mode in 0 1 2 0 1 2; do
   MMI_GEMM_LDS=$mode timeout 200 python bench.py --no-cpu-baseline > $O/next_bench_lds$mode.log 2>&1
   echo "MMI_GEMM_LDS=$mode $(grep '"metric"' $O/next_bench_lds$mode.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms/step %.3f  dominant kernel %.2f us' % (d['ms_per_step'], 1e3*d['roofline']['avg_launch_ms']))")"
 done
+for qn in q8 fp8; do for mode in 0 1; do
+  MMI_GEMM_LDS=$mode timeout 200 python bench.py --batch 64 --quant $qn --no-cpu-baseline > $O/next_bench_b64_${qn}_lds$mode.log 2>&1
+  echo "64 sessions $qn MMI_GEMM_LDS=$mode $(grep '"metric"' $O/next_bench_b64_${qn}_lds$mode.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms/step %.3f' % d['ms_per_step'])")"
+done; done
 grep -E "^==|k_gemm_xlds|prototype|main loop|32x[12] ntw1 w8 u[24]" $O/next_mb_lds_b32.txt $O/next_mb_lds_b64.txt | cut -c1-140
 cat $O/next_xlds_mode2_parity.log | tail -3

@@ -72,6 +72,17 @@ def test_gemm_with_activations_resident_in_lds(sim_lib, monkeypatch, B, grid, mo
     assert st["xlds_launches"] >= 3 * (2 * 2 + 1)
 
 
+@pytest.mark.parametrize("B,quantize", [(18, True), (34, True), (18, "fp8"), (34, "fp8")])
+def test_gemm_with_activations_resident_in_lds_quantised_weights(sim_lib, monkeypatch, B, quantize):
+    """k_gemm_xlds on int8 / fp8 weight entries (two k-steps per entry, two activation fragments from LDS per entry); the tiny
+    shapes give chunks of 4 entries: only 4 of the 8 waves own k-steps, the others just join the barriers and the epilogue."""
+    monkeypatch.setenv("MMI_GEMM_LDS", "1")
+    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "8")
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=150 + B, B=B, S=2, quantize=quantize, stats=st)
+    assert st["xlds_launches"] >= 2 * (2 * 2 + 1)
+
+
 def test_depformer_in_per_step_launches(sim_lib, monkeypatch):
     """The engine normally runs the dep_q `depformer_in` linears as one grouped GEMM and lets each sampler add its token's
     embedding row; depth widths that are not whole n-tiles fall back to one GEMM per micro-step with the embedding in its
