@@ -5,5 +5,8 @@ include/moshi_mi.h); this package is the thin host mirror of the reference's Pyt
 """
 from .config import LMConfig, MimiConfig, tiny_lm_config, tiny_mimi_config  # noqa: F401
 from .mimi import MimiModel  # noqa: F401
+from .lm import ConditionFuser, LMGen, LMModel  # noqa: F401
+from .batcher import SessionBatcher  # noqa: F401
 
-__all__ = ["MimiConfig", "LMConfig", "MimiModel", "tiny_mimi_config", "tiny_lm_config"]
+__all__ = ["MimiConfig", "LMConfig", "MimiModel", "LMModel", "LMGen", "ConditionFuser", "SessionBatcher",
+           "tiny_mimi_config", "tiny_lm_config"]
