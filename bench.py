@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm", "served"],
+    ap.add_argument("--workload", default="auto", choices=["auto", "duplex", "mimi", "lm", "served", "launchcheck"],
                     help="served: the duplex step driven through the session batcher with HOST PCM in / PCM + tokens out "
                          "(pinned staging, H2D + D2H and one synchronisation per step included): the PCIe-inclusive rate")
     ap.add_argument("--batch", type=int, default=32, help="sessions per GPU (BASELINE.json configs[3]: 32)")
@@ -43,12 +43,41 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: the benchmark spawns its own N ranks (one process
+    per GPU, the deployment of the reference: N single-GPU replicas, swarm-config.yml:57-63) by re-executing itself under
+    `torch.distributed.run` on 127.0.0.1.  Returns None when this process is already a rank (or N == 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    backend = os.environ.get("MMI_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run "
+                             f"a smaller job under that label\n")
+            return 2
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call(cmd)
+
+
 def dist_setup(n, backend="nccl"):
     """One process per GPU (launched by torch.distributed.run): sessions shard data-parallel, no data-path collective.
     `backend="gloo"` is the CPU stand-in used by tests/test_bench_dist.py."""
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(n, 1):
+        raise SystemExit(f"bench.py: --gpus {n} but the launcher started {world} rank(s); `n_gpus` must be the ranks that ran")
     if n > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -162,8 +191,30 @@ def served_main(args, rank, world, dist, dev, mimi, mcfg, B):
         dist.destroy_process_group()
 
 
+def launchcheck_main(args, backend):
+    """The launch + aggregation skeleton alone (no model): what tests/test_bench_dist.py drives through the self-launch."""
+    rank, local, world, dist = dist_setup(args.gpus, backend=backend)
+    dev = torch.device("cpu") if backend == "gloo" else torch.device("cuda", local)
+    if dist is not None:
+        dist.barrier()
+    dt = job_time(0.5 + 0.25 * rank, dist, dev)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launchcheck", "value": job_value(world, args.batch, args.steps, dt), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "backend": backend}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    rc = self_launch(args)
+    if rc is not None:
+        sys.exit(rc)
+    if args.workload == "launchcheck":
+        return launchcheck_main(args, os.environ.get("MMI_BENCH_BACKEND", "nccl"))
     rank, local, world, dist = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     from moshi_amd import MimiConfig, MimiModel
@@ -202,7 +253,7 @@ def main():
         tokens = lm_gen.step(codes)
         if tokens is None:
             return None
-        return mimi.decode(tokens[:, 1:].clamp(min=0))
+        return mimi.decode(tokens[:, 1:])      # the -2 "not yet valid" rows are clamped by the decoder's own gather kernel
 
     def sync():
         if dist is not None:
@@ -263,8 +314,20 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "whole Mimi step (all kernels)", "algorithmic_bytes": nbytes}
         elif lm_gen is not None:
-            from bench_lm import roofline_lm
+            from bench_lm import lm_step_algorithmic_bytes, roofline_lm
             out["roofline"] = roofline_lm(lm_gen, step, args, sync)
+            # the WHOLE step against the HBM roofline: LM weights once + every session's KV at its depth at
+            # the middle of the timed region (+ Mimi's weights / rings / KV when the step includes the codec)
+            mid = args.warmup + args.steps // 2
+            L_rows = [args.stagger * b + mid if B > 1 else staggered + mid for b in range(B)]
+            step_bytes = lm_step_algorithmic_bytes(lm_gen.lm_model.config, L_rows, quant=args.quant, kv=args.kv)
+            parts = {"lm": step_bytes}
+            if workload == "duplex":
+                parts["mimi"] = mimi_algorithmic_bytes(mcfg, B, mid)
+                step_bytes += parts["mimi"]
+            ach = step_bytes / (ms * 1e-3) / 1e9
+            out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "parts": parts, "achieved": ach, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBS, "ms_per_step": ms}
         if not args.no_cpu_baseline:
             cpu_sd = {k: v.cpu() for k, v in msd.items()}
             base = cpu_baseline_mimi(mcfg, cpu_sd)

@@ -68,14 +68,20 @@ def stagger(mimi, lm_gen, step_fn, B, frames_apart, dev):
     return n
 
 
-def lm_step_algorithmic_bytes(cfg, L_per_row):   # bf16 weights
-    """weights once per step + per-stream KV read/write (bf16)."""
+def lm_step_algorithmic_bytes(cfg, L_per_row, quant="none", kv="bf16"):
+    """weights once per step (2 B bf16; 1 B + a 4-byte scale per output row for int8 / fp8) + per-stream KV
+    read of the valid positions and write of the new one (2 B bf16, 1 B fp8)."""
     d, dd, h, dh = cfg.dim, cfg.depformer_dim, cfg.ffn_hidden, cfg.depformer_ffn_hidden
     per_layer = 3 * d * d + d * d + 2 * h * d + d * h
+    rows_layer = 3 * d + d + 2 * h + d
     dep = cfg.depformer_num_layers * cfg.dep_q * (3 * dd * dd + dd * dd + 2 * dh * dd + dd * dh)
+    dep_rows = cfg.depformer_num_layers * cfg.dep_q * (3 * dd + dd + 2 * dh + dd)
     nw = cfg.num_layers * per_layer + cfg.text_card * d + dep + cfg.dep_q * dd * d + cfg.dep_q * cfg.card * dd
-    kv = sum(2 * cfg.num_layers * 2 * d * (min(int(L), cfg.context) + 1) for L in L_per_row)
-    return 2 * nw + kv
+    nrows = cfg.num_layers * rows_layer + cfg.text_card + dep_rows + cfg.dep_q * dd + cfg.dep_q * cfg.card
+    s_kv = 1 if kv == "fp8" else 2
+    kvb = sum(s_kv * cfg.num_layers * 2 * d * (min(int(L), cfg.context) + 1) for L in L_per_row)
+    wbytes = 2 * nw if quant == "none" else nw + 4 * nrows
+    return wbytes + kvb
 
 
 def roofline_lm(lm_gen, step_fn, args, sync):
@@ -110,35 +116,68 @@ def roofline_lm(lm_gen, step_fn, args, sync):
         rec = json.loads(pmc.read_text())
         if rec["kernel"] in kname and rec["algorithmic_bytes_per_launch"] == nbytes.value:
             out["traffic"] = rec["traffic_bytes_per_launch"]
-            out["traffic_source"] = "profiles/pmc_dominant_kernel.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            out["traffic_source"] = ("profiles/pmc_dominant_kernel.json: a COMMITTED measurement of this kernel, shape and batch (rocprofv3 --pmc "
+                                     "FETCH_SIZE x2 + WRITE_SIZE, separate passes, standalone launcher) - not collected in this run")
+            out["traffic_measured_in_this_run"] = False
     return out
 
 
-def cpu_baseline_duplex(mimi_base, args):
-    """`port` baseline for the full frame on the host cores: the numpy oracles.  Mimi is timed directly (mimi_base);
-    the LM oracle is timed at reduced depth (1 and 2 temporal layers, full depformer, B=1) and extrapolated linearly to
-    32 layers - a layer-scaled proxy, as BASELINE.md section 3 allows when the full 7B fp32 oracle (30 GB) is too heavy."""
+def _host_info():
+    ram = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal"):
+                ram = int(line.split()[1]) // (1 << 20)
+    except OSError:
+        pass
+    return os.cpu_count(), ram
+
+
+def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5):
+    """`port` baseline for the full frame on the host cores: the numpy oracles (the reference itself cannot travel to the GPU
+    box).  Mimi is timed directly (mimi_base); the LM oracle (fp32, B=1, full depformer and text head) is timed at two reduced
+    depths - median of `timed` steps after one warm-up step each, the temporal stack (`forward_text`) also on its own clock -
+    and extrapolated linearly to the model's 32 temporal layers with the per-layer cost of that stack: the layer-scaled proxy BASELINE.md section 3 allows when the full 7B fp32 oracle (30 GB) is too heavy for a
+    default run.  The slope must be positive (a 32-layer model that costs what one layer costs is not a baseline)."""
     from moshi_amd.config import LMConfig
     from moshi_amd.weights import random_lm_state_dict
     from oracle.lm_oracle import LMOracle
-    times = {}
-    for nl in (1, 2):
+    times, text_times = {}, {}
+    for nl in layers:
         cfg = LMConfig(num_layers=nl, context=64)
         o = LMOracle(random_lm_state_dict(cfg, seed=1, device="cpu"), cfg)
         o.streaming(1)
-        codes = np.zeros((1, 8, 1), np.int64)
-        o.step(codes, use_sampling=False)
-        t0 = time.perf_counter()
-        n = 2
-        for _ in range(n):
+        ft = o.forward_text
+        ft_t = []
+
+        def timed_forward_text(tokens, _ft=ft, _acc=ft_t):      # the depth-dependent part, timed on its own: the 208 small
+            t0 = time.perf_counter()                            # depformer GEMVs of a step are noisy under a threaded BLAS
+            r = _ft(tokens)
+            _acc.append(time.perf_counter() - t0)
+            return r
+        o.forward_text = timed_forward_text
+        rng = np.random.default_rng(nl)
+        o.step(rng.integers(0, cfg.card, (1, 8, 1)), use_sampling=False)
+        ft_t.clear()
+        ts = []
+        for _ in range(timed):
+            codes = rng.integers(0, cfg.card, (1, 8, 1))
+            t0 = time.perf_counter()
             o.step(codes, use_sampling=False)
-        times[nl] = (time.perf_counter() - t0) / n
+            ts.append(time.perf_counter() - t0)
+        times[nl], text_times[nl] = float(np.median(ts)), float(np.median(ft_t))
         del o
+    lo, hi = layers
+    per_layer = (text_times[hi] - text_times[lo]) / (hi - lo)
+    if not per_layer > 0:
+        raise RuntimeError(f"cpu_baseline: non-positive per-layer cost ({text_times}); the host is too noisy for a baseline")
     full_layers = 32 if not args.lm_layers else args.lm_layers
-    per_layer = max(times[2] - times[1], 0.0)
-    lm_s = times[1] + (full_layers - 1) * per_layer
+    lm_s = times[lo] + (full_layers - lo) * per_layer
     mimi_s = 1.0 / mimi_base["value"]
-    return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle timed at 1 and 2 "
-                       f"temporal layers + full depformer ({times[1]:.2f} s, {times[2]:.2f} s per step) and extrapolated "
-                       f"linearly to {full_layers} layers = {lm_s:.2f} s/step (layer-scaled proxy)")}
+    cores, ram = _host_info()
+    return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": cores, "host_ram_gib": ram, "kind": "port",
+            "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle (fp32 numpy) median of "
+                       f"{timed} steps at {lo} and {hi} temporal layers + full depformer and text head ({times[lo]:.3f} s, "
+                       f"{times[hi]:.3f} s per step; temporal stack alone {text_times[lo]*1e3:.0f} / {text_times[hi]*1e3:.0f} ms = "
+                       f"{per_layer*1e3:.1f} ms per temporal layer) extrapolated linearly to "
+                       f"{full_layers} layers = {lm_s:.2f} s/step (layer-scaled proxy)")}

@@ -66,3 +66,41 @@ def test_weight_broadcast_at_load_two_ranks():
     out = mp.Manager().dict()
     mp.spawn(_bcast_worker, args=(world, 29613, out), nprocs=world, join=True)
     assert out[0] and out[1]
+
+
+def _run_bench(extra, env_extra):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher environment) starts two ranks itself; `n_gpus` is the ranks that rendezvoused."""
+    import json
+    r = _run_bench(["--gpus", "2", "--workload", "launchcheck", "--steps", "10"], {"MMI_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2
+    assert abs(out["value"] - 2 * 32 * 10 / 0.75) < 1e-6      # both ranks' sessions over the slower rank's time
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """On a box with fewer GPUs than requested the RCCL job must fail loudly, not print a 1-GPU line labelled N."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run_bench(["--gpus", str(have + 2), "--workload", "launchcheck"], {})
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_bench_rejects_rank_count_mismatch():
+    """Started by a launcher with a different world size than --gpus: refuse (the line's n_gpus must be what ran)."""
+    r = _run_bench(["--gpus", "4", "--workload", "launchcheck"],
+                   {"MMI_BENCH_BACKEND": "gloo", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29617"})
+    assert r.returncode != 0 and "rank(s)" in (r.stderr + r.stdout)
