@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--quant", default="none", choices=["none", "q8", "fp8"],
                     help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears widened to bf16 in registers; fp8 = e4m3 linears on the fp8 MFMA")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "fp8"], help="KV ring of the temporal transformer: the reference's bf16, or e4m3 (half the attention stream)")
+    ap.add_argument("--launch-lists", default="", help="directory to write the step's launch lists (site per kernel launch) into, for scripts/rocpd_sites.py")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
     return ap.parse_args()
 
@@ -278,6 +279,16 @@ def main():
 
     ms = 1e3 * dt / args.steps
     value = job_value(world, B, args.steps, dt)
+    if args.launch_lists and rank == 0:
+        d = Path(args.launch_lists)
+        d.mkdir(parents=True, exist_ok=True)
+        lists = {}
+        if workload in ("duplex", "mimi"):
+            lists["mimi_encode"], lists["mimi_decode"] = mimi.launch_list("encode"), mimi.launch_list("decode")
+        if lm_gen is not None:
+            lists["lm"] = lm_gen.launch_list()
+        for k, v in lists.items():
+            (d / f"launch_list_{k}.tsv").write_text("".join(f"{s_}\t{kn}\n" for s_, kn in v))
 
     # p50 / p95 latency of a single step (BASELINE.json's second figure): a separate, untimed-for-`value` pass with a
     # device event before and after every step and no host synchronisation inside the loop

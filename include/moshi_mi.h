@@ -217,6 +217,11 @@ typedef struct mmi_guidance {
 int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide_or_null,
                                   mmi_stream stream);
 int mmi_lm_model_rows(const mmi_lm* lm);
+/* A handle binds to the HIP device that is current when it is created (weights, state, streams and graphs live there); every
+ * entry point switches the calling thread to that device for the call and restores the caller's.  Pointers passed in must be
+ * on that device.  mmi_*_device return the ordinal. */
+int mmi_lm_device(const mmi_lm* lm);
+int mmi_mimi_device(const mmi_mimi* m);
 /* Engine counters for tests / diagnostics.  which = 0: GEMM launches (or captured graph nodes) that took the LDS-resident
  * kernel (k_gemm_xlds, enabled with MMI_GEMM_LDS=1). */
 int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which);   /* rows the model runs for the current stream: batch, or 2 * batch when guided */
@@ -250,6 +255,20 @@ int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* 
  * sampling.  Covers LMGen.step's `depformer_replace_tokens` argument (lm.py:751-755) and lets the parity tests
  * replay the reference's token history exactly. */
 int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream);
+
+/* The launch list of one frame step, recorded while the step ran for the first time: one line "site<TAB>kernel" per kernel
+ * launch in launch order (sites: "L.in_proj", "L.ffn_in", "dep.out_proj", "text_linear", ...).  scripts/rocpd_sites.py joins
+ * it with a rocprofv3 kernel trace by position inside the step, which is how per-site durations of kernels that share one
+ * name are recomputed under profiles/.  Returns the bytes needed including the final NUL (call with buf = NULL to size);
+ * 0 before the first step.  mmi_mimi_launch_list: which = 0 encoder step, 1 decoder step. */
+int64_t mmi_lm_launch_list(const mmi_lm* lm, char* buf, int64_t cap);
+int64_t mmi_mimi_launch_list(const mmi_mimi* m, int32_t which, char* buf, int64_t cap);
+
+/* Test / benchmark aid (no reference counterpart): move every session to stream position offsets[b] (host i64 [batch]) WITHOUT
+ * touching the KV ring - the positions skipped read whatever the ring holds (zeros after streaming_start).  Lets the ring
+ * wrap at the real capacity (context 3000) be exercised in seconds, and a full-context step be timed without 3000 warm-up
+ * steps.  The host step counter becomes max(offsets). */
+int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream);
 
 /* Dominant-kernel timing tap for bench.py's roofline object: when enabled, steps run un-graphed and
  * every launch of the widest weight-streaming GEMM is bracketed by hipEvents on `stream`. */

@@ -92,6 +92,8 @@ SIGNATURES = {
     "mmi_lm_streaming_start": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), _P]),
     "mmi_lm_streaming_start_guided": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), C.POINTER(Guidance), _P]),
     "mmi_lm_model_rows": (C.c_int, [_P]),
+    "mmi_lm_device": (C.c_int, [_P]),
+    "mmi_mimi_device": (C.c_int, [_P]),
     "mmi_lm_stat": (C.c_int64, [_P, C.c_int32]),
     "mmi_lm_extra_heads": (C.c_int, [_P, _P, _P]),
     "mmi_lm_state_bytes": (C.c_int64, [_P]),
@@ -115,6 +117,9 @@ SIGNATURES = {
     "mmi_batcher_step": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "mmi_batcher_pop": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]),
     "mmi_batcher_get_stats": (C.c_int, [_P, C.POINTER(BatcherStats)]),
+    "mmi_lm_launch_list": (C.c_int64, [_P, _P, C.c_int64]),
+    "mmi_mimi_launch_list": (C.c_int64, [_P, C.c_int32, _P, C.c_int64]),
+    "mmi_lm_seek": (C.c_int, [_P, _P, _P]),
     "mmi_lm_profile_begin": (C.c_int, [_P]),
     "mmi_lm_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_char_p)]),
@@ -197,3 +202,28 @@ def stream_ptr(device: torch.device) -> Optional[int]:
     if device.type == "cuda":
         return torch.cuda.current_stream(device).cuda_stream
     return None
+
+
+def launch_list(call):
+    """Decode a `mmi_*_launch_list` buffer: [(site, kernel)] in launch order; [] before the first step."""
+    need = int(call(None, 0))
+    if need <= 1:
+        return []
+    buf = C.create_string_buffer(need)
+    call(C.cast(buf, C.c_void_p), need)
+    out = []
+    for line in buf.value.decode().splitlines():
+        site, _, kern = line.partition("\t")
+        out.append((site, kern))
+    return out
+
+
+def device_scope(device):
+    """Context in which `device` is the current HIP device: handles bind to the device current at `mmi_*_create` (every later
+    entry point switches to it by itself, include/moshi_mi.h).  A no-op for the simulator's CPU device."""
+    import contextlib
+    import torch
+    device = torch.device(device)
+    if device.type != "cuda":
+        return contextlib.nullcontext()
+    return torch.cuda.device(device)

@@ -62,6 +62,7 @@ class SessionBatcher:
                 cs = cs.to(device=lm_model.device, dtype=torch.bfloat16).contiguous().view(rows, lm_model.dim)
                 keep.append(cs)
                 cfg.guidance.condition_sum = cs.data_ptr()
+        assert mimi.device == lm_model.device, "the codec and the LM of a batcher must live on the same GPU"
         self._handle = C.c_void_p()
         mimi._sync()
         self._lib.check(self._lib.mmi_batcher_create(mimi._handle, lm_model._handle, C.byref(cfg), C.byref(self._handle)))

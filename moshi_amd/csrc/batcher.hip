@@ -180,6 +180,7 @@ int create_impl(mmi_batcher* b) {
 }  // namespace
 
 extern "C" int mmi_batcher_create(mmi_mimi* mimi, mmi_lm* lm, const mmi_batcher_cfg* cfg, mmi_batcher** out) {
+    MmiDeviceGuard dev_guard_(lm ? mmi_lm_device(lm) : -1);
     if (!mimi || !lm || !cfg || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (cfg->slots <= 0) return mmi_fail(MMI_ERR_INVALID, "slots must be positive");
     mmi_batcher* b = new mmi_batcher();
@@ -198,10 +199,12 @@ extern "C" int mmi_batcher_create(mmi_mimi* mimi, mmi_lm* lm, const mmi_batcher_
 }
 
 extern "C" void mmi_batcher_destroy(mmi_batcher* b) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (b) release(b);
 }
 
 extern "C" int mmi_batcher_open(mmi_batcher* b, int64_t* channel_id) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b || !channel_id) return mmi_fail(MMI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(b->mu);
     for (auto& c : b->channels) {
@@ -218,6 +221,7 @@ extern "C" int mmi_batcher_open(mmi_batcher* b, int64_t* channel_id) {
 }
 
 extern "C" int mmi_batcher_close(mmi_batcher* b, int64_t channel_id) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b) return mmi_fail(MMI_ERR_INVALID, "null handle");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
@@ -228,6 +232,7 @@ extern "C" int mmi_batcher_close(mmi_batcher* b, int64_t channel_id) {
 }
 
 extern "C" int mmi_batcher_push_pcm(mmi_batcher* b, int64_t channel_id, const float* pcm, int32_t n_samples) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b || (!pcm && n_samples > 0) || n_samples < 0) return mmi_fail(MMI_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
@@ -239,6 +244,7 @@ extern "C" int mmi_batcher_push_pcm(mmi_batcher* b, int64_t channel_id, const fl
 }
 
 extern "C" int mmi_batcher_step(mmi_batcher* b, int32_t* n_active) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b) return mmi_fail(MMI_ERR_INVALID, "null handle");
     const int B = b->B, F = b->F;
     Staging& h = b->host;
@@ -327,6 +333,7 @@ extern "C" int mmi_batcher_step(mmi_batcher* b, int32_t* n_active) {
 }
 
 extern "C" int mmi_batcher_pop(mmi_batcher* b, int64_t channel_id, float* pcm, int64_t* tokens, int32_t* got) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b || !got) return mmi_fail(MMI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
@@ -342,6 +349,7 @@ extern "C" int mmi_batcher_pop(mmi_batcher* b, int64_t channel_id, float* pcm, i
 }
 
 extern "C" int mmi_batcher_get_stats(mmi_batcher* b, mmi_batcher_stats* out) {
+    MmiDeviceGuard dev_guard_(b ? mmi_lm_device(b->lm) : -1);
     if (!b || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(b->mu);
     *out = b->stats;

@@ -34,6 +34,7 @@ struct EvPair { hipEvent_t a, b; };
 
 struct mmi_lm {
     mmi_lm_cfg cfg;
+    int device = -1;                // HIP device the handle lives on (current at create); see MmiDeviceGuard
     int max_batch = 0;
     int T = 32;                     // MFMA tile of the whole model: 16 when max_batch <= 16, else 32 (lm_kernels.h)
     int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py),
@@ -542,6 +543,7 @@ int build_program(mmi_lm* lm) {
     const int n_user = c.n_q - c.dep_q;
     MmiProgram& P = lm->prog;
     // ---- token ring in, embeddings
+    P.site("prepare");
     {
         TokArgs t = tok_args(lm);
         const int* user = lm->user_i32; int* tokens = lm->tokens;
@@ -568,12 +570,14 @@ int build_program(mmi_lm* lm) {
     int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
+        P.site("L.norm1");
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
         LmAttnArgs a;
         a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
+        P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
             memset(&ga, 0, sizeof(ga));
@@ -583,6 +587,7 @@ int build_program(mmi_lm* lm) {
             GemmW gw = L.in_proj;
             P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
         }
+        P.site("L.attn");
         P.add([=](hipStream_t s) {
             int rc = launch_attn_split(s, a, kv8);
             if (rc) return rc;
@@ -590,45 +595,62 @@ int build_program(mmi_lm* lm) {
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
+        P.site("L.out_proj");
         pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
+        P.site("L.norm2");
         add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d);
+        P.site("L.ffn_in");
         add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
+        P.site("L.ffn_out");
         pending = add_gemm_resid(lm, L.ffn_out, lm->hb, lm->x, d);
     }
+    P.site("out_norm");
     add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
+    P.site("text_linear");
     add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr);
     // depformer_in[k](transformer_out) for every micro-step in one launch; each sampler then adds its token's embedding row
     // and writes the next micro-step's input (lm.py:465-470) - 8 dependent launches less on the sequential chain
     const bool grouped = lm->dep_in_grouped;
+    P.site("dep.in_all");
     if (grouped) add_gemm(lm, lm->dep_in_all, lm->tout, lm->dpre, c.dep_q * dd, false, MMI_EPI_STORE, nullptr);
+    P.site("text_sample");
     add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1, grouped ? 0 : -1);
     // ---- depformer: dep_q sequential micro-steps
     const size_t dkv_layer = (size_t)B * Hd * c.dep_q * Dhd;
     for (int k = 0; k < c.dep_q; ++k) {
         const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
         const int prev_stride = k == 0 ? 1 : c.dep_q;
+        P.site("dep.in");
         if (!grouped) add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
+            P.site("dep.in_proj");
             add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
+            P.site("dep.attn");
             P.add([=](hipStream_t s) {
                 MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
+            P.site("dep.out_proj");
             add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            P.site("dep.ffn_in");
             add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE);
+            P.site("dep.ffn_out");
             add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
+        P.site("dep.lin");
         add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr);
+        P.site("dep.sample");
         add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q, grouped && k + 1 < c.dep_q ? k + 1 : -1);
     }
     // ---- token ring out
+    P.site("commit");
     {
         TokArgs t = tok_args(lm);
         const int *tt = lm->text_tok, *at = lm->audio_tok; int* out = lm->out_i32; unsigned long long* rng = lm->rng;
@@ -676,6 +698,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     int rc = check_cfg(norm_cfg);
     if (rc) return rc;
     mmi_lm* lm = new mmi_lm();
+    if (hipGetDevice(&lm->device) != hipSuccess) lm->device = -1;
     lm->cfg = norm_cfg;
     lm->max_batch = max_batch;
     lm->T = max_batch <= 16 ? 16 : 32;
@@ -780,6 +803,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
 }
 
 extern "C" void mmi_lm_destroy(mmi_lm* lm) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return;
     mmi_lm_streaming_stop(lm);
     lm->wts.release();
@@ -789,17 +813,20 @@ extern "C" void mmi_lm_destroy(mmi_lm* lm) {
 }
 
 extern "C" int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     *out = lm->cfg;
     return MMI_OK;
 }
 
 extern "C" int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     return mmi_lm_streaming_start_guided(lm, batch, sampling, nullptr, stream);
 }
 
 extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide,
                                              mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !sampling) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (lm->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");
     const bool guided = guide && guide->cfg_coef != 1.0f;
@@ -903,6 +930,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
 }
 
 extern "C" int mmi_lm_streaming_stop(mmi_lm* lm) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->streaming) return MMI_OK;
     hipDeviceSynchronize();
@@ -916,6 +944,7 @@ extern "C" int mmi_lm_streaming_stop(mmi_lm* lm) {
 }
 
 extern "C" int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     MMI_HIP_CHECK(hipMemcpyAsync(lm->exec, mask, lm->gen_batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -923,6 +952,7 @@ extern "C" int mmi_lm_set_exec_mask(mmi_lm* lm, const uint8_t* mask, mmi_stream 
 }
 
 extern "C" int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     TokArgs t = tok_args(lm);
@@ -934,6 +964,7 @@ extern "C" int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask, mmi_stream stream) 
 
 extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* out_tokens, float* opt_text_logits,
                            float* opt_audio_logits, const float* opt_noise, int32_t batch, int32_t* valid, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !user_codes || !out_tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming)
         return mmi_fail(MMI_ERR_STATE, "You should wrap those calls with a `with lm_gen.streaming(): ...`.");   // lm.py:673-676
@@ -976,6 +1007,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
 }
 
 extern "C" int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !tokens) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     hipStream_t s = (hipStream_t)stream;
@@ -990,6 +1022,7 @@ extern "C" int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_s
 extern "C" int64_t mmi_lm_state_bytes(const mmi_lm* lm) { return lm && lm->streaming ? (int64_t)lm->st.bytes : 0; }
 
 extern "C" int mmi_lm_state_save(mmi_lm* lm, void* dst, int64_t bytes, int64_t* host_word, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !dst || !host_word) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot buffer has the wrong size");
@@ -999,6 +1032,7 @@ extern "C" int mmi_lm_state_save(mmi_lm* lm, void* dst, int64_t bytes, int64_t* 
 }
 
 extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int64_t host_word, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !src) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch / guidance)");
@@ -1009,6 +1043,7 @@ extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int
 }
 
 extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !probs) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     const mmi_lm_cfg& c = lm->cfg;
@@ -1020,13 +1055,45 @@ extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
 }
 
 extern "C" int mmi_lm_model_rows(const mmi_lm* lm) { return lm ? lm->batch : 0; }
+extern "C" int mmi_lm_device(const mmi_lm* lm) { return lm ? lm->device : -1; }
+
+int64_t mmi_copy_launch_log(const std::vector<std::string>& log, char* buf, int64_t cap);   // api_common.hip
+
+extern "C" int64_t mmi_lm_launch_list(const mmi_lm* lm, char* buf, int64_t cap) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !lm->streaming || !lm->prog.logged) return 0;
+    return mmi_copy_launch_log(lm->prog.launch_log, buf, cap);
+}
+
+extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !offsets) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
+    const int G = lm->gen_batch;
+    std::vector<long> off(lm->batch);
+    long mx = 0;
+    for (int b = 0; b < G; ++b) {
+        if (offsets[b] < 0) return mmi_fail(MMI_ERR_INVALID, "negative offset");
+        off[b] = (long)offsets[b];
+        if (lm->batch > G) off[G + b] = off[b];      // the guidance twins follow their session
+        mx = off[b] > mx ? off[b] : mx;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    MMI_HIP_CHECK(hipStreamSynchronize(s));
+    MMI_HIP_CHECK(hipMemcpy(lm->offsets, off.data(), (size_t)G * sizeof(long), hipMemcpyHostToDevice));
+    if (lm->offsets_m != lm->offsets) MMI_HIP_CHECK(hipMemcpy(lm->offsets_m, off.data(), (size_t)lm->batch * sizeof(long), hipMemcpyHostToDevice));
+    lm->offset_cpu = mx;
+    return MMI_OK;
+}
 
 extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return -1;
     return which == 0 ? (int64_t)lm->xlds_launches : -1;
 }
 
 extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     lm->profiling = true;
     lm->ev_used = 0;
@@ -1035,6 +1102,7 @@ extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
 
 extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,
                                   const char** kernel_name) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->profiling) return mmi_fail(MMI_ERR_STATE, "profiling was not started");
     lm->profiling = false;

@@ -27,6 +27,7 @@ struct Buf {            // activation buffer [B][C][ld]; first H columns = causa
 }  // namespace
 
 struct mmi_mimi {
+    int device = -1;                // HIP device the handle lives on (current at create); see MmiDeviceGuard
     mmi_mimi_cfg cfg;
     int max_batch = 0;
     int n_codebooks = 8;
@@ -561,6 +562,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     {   // conv0: channels -> n_filters, K = kernel_size; consumer = resblock conv (K = residual_kernel_size)
         Buf nxt;
         if ((rc = alloc_buf(m, B, c.n_filters, c.residual_kernel_size - 1, T, &nxt, s0))) return rc;
+        prog.site("enc.conv0");
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false)))) return rc;
         hist.push_back(hist_of(nxt, T));
         cur = nxt;
@@ -572,6 +574,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         Buf hid, nxt;
         if ((rc = alloc_buf(m, B, ch / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
+        prog.site("enc.res" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->enc_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
         a.res = cur.p; a.res_ld = cur.ld; a.res_off = cur.H;
@@ -583,6 +586,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? c.residual_kernel_size - 1 : c.last_kernel_size - 1;
         Buf nx2;
         if ((rc = alloc_buf(m, B, 2 * ch, Hn, Tn, &nx2, s0))) return rc;
+        prog.site("enc.down" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true)))) return rc;
         hist.push_back(hist_of(nx2, Tn));
         cur = nx2;
@@ -593,6 +597,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     const int stride = c.resample_stride;
     Buf dsin;
     if ((rc = alloc_buf(m, B, c.dimension, 2 * stride - stride, T, &dsin, s0))) return rc;
+    prog.site("enc.final");
     if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, dsin, dsin.H, B, true)))) return rc;
     hist.push_back(hist_of(dsin, T));
     // encoder transformer, in place on dsin[:, :, H:H+T]
@@ -601,6 +606,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         size_t kvn = (size_t)2 * c.tr_num_layers * B * c.tr_num_heads * c.tr_context * Dh;
         MMI_HIP_CHECK(m->st.alloc(&m->enc_kv, kvn));
         MMI_HIP_CHECK(hipMemsetAsync(m->enc_kv, 0, kvn * sizeof(float), s0));
+        prog.site("enc.tr");
         if ((rc = add_transformer(m, prog, m->enc_tr, dsin, dsin.H, T, m->enc_kv, m->counters, B, s0))) return rc;
     }
     const int T_tr = T;
@@ -611,9 +617,12 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     {
         ConvGemmArgs a = conv_args(m->downsample, dsin, 0, 1, m->latent, 0, B, false);
         a.first = m->first; a.exec = m->exec;
+        prog.site("enc.downsample");
         if ((rc = add_conv(m, prog, a))) return rc;
     }
+    prog.site("enc.rvq");
     if ((rc = add_quantize_ops(m, prog, m->latent.p, 1, 0, B))) return rc;
+    prog.site("enc.commit");
     // commit
     if ((rc = upload_hist(m, hist, B, &m->enc_hist, &m->enc_nhist, &m->enc_hist_rows))) return rc;
     {
@@ -637,7 +646,9 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     const int stride = c.resample_stride;
     // dequantised latent [B][dim][1]
     if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->dec_codes_lat, s0))) return rc;
+    prog.site("dec.dequant");
     if ((rc = add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B))) return rc;
+    prog.site("dec.upsample");
     // upsample (depthwise transposed conv) into the decoder transformer buffer = input of decoder conv0
     int T = stride;
     Buf din;
@@ -663,6 +674,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         size_t kvn = (size_t)2 * c.tr_num_layers * B * c.tr_num_heads * c.tr_context * Dh;
         MMI_HIP_CHECK(m->st.alloc(&m->dec_kv, kvn));
         MMI_HIP_CHECK(hipMemsetAsync(m->dec_kv, 0, kvn * sizeof(float), s0));
+        prog.site("dec.tr");
         if ((rc = add_transformer(m, prog, m->dec_tr, din, din.H, T, m->dec_kv, m->counters + B, B, s0))) return rc;
     }
     const int T_tr = T;
@@ -671,6 +683,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     Buf cur;
     {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
         if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
+        prog.site("dec.conv0");
         if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false)))) return rc;
     }
     for (int i = 0; i < c.n_ratios; ++i) {
@@ -682,6 +695,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Tn = T * ratio;
         if ((rc = alloc_buf(m, B, cout, c.residual_kernel_size - 1, Tn, &up, s0))) return rc;
         const ConvW& wtr = m->dec_convs[ci++];
+        prog.site("dec.convtr" + std::to_string(i));
         {
             ConvGemmArgs a = conv_args(wtr, cur, 0, T, tmp, 0, B, true);
             a.bias = nullptr;  // bias is added once, in the combine step
@@ -709,6 +723,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? 0 : c.last_kernel_size - 1;
         if ((rc = alloc_buf(m, B, cout / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
+        prog.site("dec.res" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->dec_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
         a.res = up.p; a.res_ld = up.ld; a.res_off = up.H;
@@ -719,7 +734,9 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     }
     if (T != c.frame_size) return mmi_fail(MMI_ERR_UNSUPPORTED, "decoder does not reproduce frame_size samples");
     if ((rc = alloc_buf(m, B, c.channels, 0, T, &m->dec_out, s0))) return rc;
+    prog.site("dec.final");
     if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], cur, 0, T, m->dec_out, 0, B, true)))) return rc;
+    prog.site("dec.commit");
     if ((rc = upload_hist(m, hist, B, &m->dec_hist, &m->dec_nhist, &m->dec_hist_rows))) return rc;
     {
         HistDesc* hd = m->dec_hist; int nh = m->dec_nhist, rows = m->dec_hist_rows;
@@ -769,6 +786,7 @@ extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* w
     int rc = check_cfg(*cfg);
     if (rc) return rc;
     mmi_mimi* m = new mmi_mimi();
+    if (hipGetDevice(&m->device) != hipSuccess) m->device = -1;
     m->cfg = *cfg;
     m->max_batch = max_batch;
     m->n_codebooks = cfg->q_n_q < 8 ? cfg->q_n_q : 8;
@@ -861,6 +879,7 @@ extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* w
 }
 
 extern "C" void mmi_mimi_destroy(mmi_mimi* m) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m) return;
     mmi_mimi_streaming_stop(m);
     m->wts.release();
@@ -869,6 +888,7 @@ extern "C" void mmi_mimi_destroy(mmi_mimi* m) {
 }
 
 extern "C" int mmi_mimi_set_num_codebooks(mmi_mimi* m, int32_t n) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (n < 1 || n > m->cfg.q_n_q) return mmi_fail(MMI_ERR_INVALID, "num_codebooks out of range");
     if (m->streaming) return mmi_fail(MMI_ERR_STATE, "set_num_codebooks while streaming");
@@ -877,14 +897,27 @@ extern "C" int mmi_mimi_set_num_codebooks(mmi_mimi* m, int32_t n) {
 }
 
 extern "C" int mmi_mimi_num_codebooks(const mmi_mimi* m) { return m ? m->n_codebooks : 0; }
+extern "C" int mmi_mimi_device(const mmi_mimi* m) { return m ? m->device : -1; }
+
+int64_t mmi_copy_launch_log(const std::vector<std::string>& log, char* buf, int64_t cap);   // api_common.hip
+
+extern "C" int64_t mmi_mimi_launch_list(const mmi_mimi* m, int32_t which, char* buf, int64_t cap) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
+    if (!m || !m->streaming) return 0;
+    const MmiProgram& p = which == 0 ? m->enc_prog : m->dec_prog;
+    if (!p.logged) return 0;
+    return mmi_copy_launch_log(p.launch_log, buf, cap);
+}
 
 extern "C" int mmi_mimi_get_cfg(const mmi_mimi* m, mmi_mimi_cfg* out) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     *out = m->cfg;
     return MMI_OK;
 }
 
 extern "C" int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (m->streaming) return mmi_fail(MMI_ERR_STATE, "already streaming");  // streaming.py:113
     if (batch <= 0 || batch > m->max_batch) return mmi_fail(MMI_ERR_SHAPE, "batch exceeds max_batch");
@@ -906,6 +939,7 @@ extern "C" int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream s
 }
 
 extern "C" int mmi_mimi_streaming_stop(mmi_mimi* m) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!m->streaming) return MMI_OK;
     hipDeviceSynchronize();
@@ -922,6 +956,7 @@ extern "C" int mmi_mimi_streaming_stop(mmi_mimi* m) {
 extern "C" int64_t mmi_mimi_state_bytes(const mmi_mimi* m) { return m && m->streaming ? (int64_t)m->st.bytes : 0; }
 
 extern "C" int mmi_mimi_state_save(mmi_mimi* m, void* dst, int64_t bytes, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !dst) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     if (bytes != (int64_t)m->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot buffer has the wrong size");
@@ -930,6 +965,7 @@ extern "C" int mmi_mimi_state_save(mmi_mimi* m, void* dst, int64_t bytes, mmi_st
 }
 
 extern "C" int mmi_mimi_state_load(mmi_mimi* m, const void* src, int64_t bytes, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !src) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     if (bytes != (int64_t)m->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch)");
@@ -938,6 +974,7 @@ extern "C" int mmi_mimi_state_load(mmi_mimi* m, const void* src, int64_t bytes, 
 }
 
 extern "C" int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !mask) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     MMI_LAUNCH(k_set_mask, mmi_cdiv(m->batch, 64), 64, 0, (hipStream_t)stream, m->exec, mask, m->batch);
@@ -946,6 +983,7 @@ extern "C" int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stre
 }
 
 extern "C" int mmi_mimi_reset(mmi_mimi* m, const uint8_t* mask, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     hipStream_t s = (hipStream_t)stream;
@@ -985,18 +1023,21 @@ static int encode_impl(mmi_mimi* m, const float* pcm, int64_t* codes, float* lat
 
 extern "C" int mmi_mimi_encode_step(mmi_mimi* m, const float* pcm, int64_t* codes, int32_t batch, int32_t n_frames,
                                     mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!codes) return mmi_fail(MMI_ERR_INVALID, "null codes");
     return encode_impl(m, pcm, codes, nullptr, batch, n_frames, (hipStream_t)stream);
 }
 
 extern "C" int mmi_mimi_encode_latent_step(mmi_mimi* m, const float* pcm, float* latent, int32_t batch, int32_t n_frames,
                                            mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!latent) return mmi_fail(MMI_ERR_INVALID, "null latent");
     return encode_impl(m, pcm, nullptr, latent, batch, n_frames, (hipStream_t)stream);
 }
 
 extern "C" int mmi_mimi_quantize(mmi_mimi* m, const float* latent, int64_t* codes, int32_t batch, int32_t n_frames,
                                  mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !latent || !codes) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (batch <= 0 || batch > m->max_batch || n_frames <= 0) return mmi_fail(MMI_ERR_SHAPE, "bad batch / frames");
     hipStream_t s = (hipStream_t)stream;
@@ -1016,6 +1057,7 @@ extern "C" int mmi_mimi_quantize(mmi_mimi* m, const float* latent, int64_t* code
 
 extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* latent, int32_t batch, int32_t n_codebooks,
                                       int32_t n_frames, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !latent || !codes) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (batch <= 0 || batch > m->max_batch || n_frames <= 0 || n_codebooks < 1 || n_codebooks > m->cfg.q_n_q)
         return mmi_fail(MMI_ERR_SHAPE, "bad batch / codebooks / frames");
@@ -1035,6 +1077,7 @@ extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* 
 
 extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pcm, int32_t batch, int32_t n_codebooks,
                                     int32_t n_frames, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(m ? m->device : -1);
     int rc = frame_count_ok(m, batch, n_frames);
     if (rc) return rc;
     if (!codes || !pcm) return mmi_fail(MMI_ERR_INVALID, "null argument");

@@ -49,6 +49,20 @@ int mmi_fail(int code, const std::string& msg);
             return mmi_fail(MMI_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_));    \
     } while (0)
 
+// A handle binds to the HIP device that was current when it was created; every ABI entry switches the calling thread to that
+// device for the duration of the call and restores the caller's (so `device='cuda:1'` works without the caller having made
+// device 1 current, and nothing leaks into the caller's - e.g. torch's - notion of the current device).
+struct MmiDeviceGuard {
+    int prev = -1;
+    explicit MmiDeviceGuard(int dev) {
+        int cur = -1;
+        if (dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~MmiDeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+    MmiDeviceGuard(const MmiDeviceGuard&) = delete;
+    MmiDeviceGuard& operator=(const MmiDeviceGuard&) = delete;
+};
+
 // ---- weight table lookup -------------------------------------------------------------------
 struct MmiWeights {
     const mmi_tensor_desc* descs;

@@ -18,8 +18,14 @@ typedef __bf16 mmi_bf16x8 __attribute__((ext_vector_type(8)));
 #define MMI_DYN_SHARED(T, name)                                                   \
     extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[];  \
     T* name = reinterpret_cast<T*>(name##_raw_)
-#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...) \
-    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
+// every launch is announced to the launch-list recorder (mmi_graph.h: which site of the step issued which kernel; a
+// no-op unless a program is being recorded)
+void mmi_note_launch(const char* kernel);
+#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...)                    \
+    do {                                                                     \
+        mmi_note_launch(#kern);                                              \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);   \
+    } while (0)
 
 // float -> bf16, round-to-nearest-even.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); host code (weight
 // import helpers) takes the bit-level definition in mmi_common.h.

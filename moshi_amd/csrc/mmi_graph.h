@@ -7,19 +7,36 @@
 #include "mmi_common.h"
 #include <stdlib.h>
 
+// Launch-list recorder: while a program runs for the first time (eagerly, or under stream capture) every MMI_LAUNCH is
+// logged as "site<TAB>kernel", where the site is the label of the op that issued it ("L.ffn_in", "dep.out_proj", ...).
+// profiles/ joins that list with a rocprofv3 kernel trace by position inside the step (scripts/rocpd_sites.py), which is how
+// the per-site durations of kernels that share one name (k_gemm_xp serves six GEMM shapes) are recomputed.
+void mmi_record_begin(std::vector<std::string>* log);
+void mmi_record_site(const char* site);
+void mmi_record_end();
+
 struct MmiProgram {
     std::vector<std::function<int(hipStream_t)>> ops;
+    std::vector<std::string> sites;             // one label per op
+    std::vector<std::string> launch_log;        // "site\tkernel" per launch, in launch order (filled by the first run)
+    std::string site_ = "-";                    // label given to the ops added from now on
+    bool logged = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 
-    void add(std::function<int(hipStream_t)> f) { ops.push_back(std::move(f)); }
+    void site(const std::string& label) { site_ = label; }
+    void add(std::function<int(hipStream_t)> f) { ops.push_back(std::move(f)); sites.push_back(site_); }
 
     int run_eager(hipStream_t s) {
-        for (auto& op : ops) {
-            int rc = op(s);
-            if (rc) return rc;
+        const bool rec = !logged;
+        if (rec) mmi_record_begin(&launch_log);
+        int rc = MMI_OK;
+        for (size_t i = 0; i < ops.size() && !rc; ++i) {
+            if (rec) mmi_record_site(sites[i].c_str());
+            rc = ops[i](s);
         }
-        return MMI_OK;
+        if (rec) { mmi_record_end(); logged = true; }
+        return rc;
     }
 
     int run(hipStream_t s, bool use_graph, hipStream_t capture_stream) {
@@ -42,6 +59,10 @@ struct MmiProgram {
         exec = nullptr;
         graph = nullptr;
         ops.clear();
+        sites.clear();
+        launch_log.clear();
+        logged = false;
+        site_ = "-";
     }
 };
 

@@ -116,7 +116,8 @@ class LMModel:
         cfg = _lm_cfg_struct(self.config)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        lib.check(lib.mmi_lm_create(C.byref(cfg), descs, len(sd), max_batch, C.byref(self._handle)))
+        with _capi.device_scope(self.device):             # the handle binds to the device current at create
+            lib.check(lib.mmi_lm_create(C.byref(cfg), descs, len(sd), max_batch, C.byref(self._handle)))
         del keep, sd
         self.max_batch = max_batch
         self.training = False
@@ -321,6 +322,21 @@ class LMGen:
         assert self.is_streaming
         keep, ptr = self._mask_ptr(exec_mask)
         self._lib.check(self._lib.mmi_lm_set_exec_mask(self.lm_model._handle, ptr, self._stream()))
+
+    # ---- test / benchmark aids (no reference counterpart) -----------------------------------------
+    def seek(self, offsets) -> None:
+        """Move every session to stream position offsets[b] without touching the KV ring (mmi_lm_seek): the skipped positions
+        read whatever the ring holds (zeros after `streaming`).  For ring-wrap tests at the real capacity and for timing a
+        full-context step without thousands of warm-up steps."""
+        assert self.is_streaming
+        offs = [int(v) for v in offsets]
+        assert len(offs) == self._batch
+        arr = (C.c_int64 * len(offs))(*offs)
+        self._lib.check(self._lib.mmi_lm_seek(self.lm_model._handle, C.cast(arr, C.c_void_p), self._stream()))
+
+    def launch_list(self):
+        """[(site, kernel)] per kernel launch of one step, in launch order (recorded during the first step)."""
+        return _capi.launch_list(lambda buf, cap: self._lib.mmi_lm_launch_list(self.lm_model._handle, buf, cap))
 
     # ---- step ------------------------------------------------------------------------------------
     def _step(self, input_tokens: torch.Tensor, want_taps: bool, noise: Optional[torch.Tensor],

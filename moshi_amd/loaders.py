@@ -188,17 +188,23 @@ class CheckpointInfo:
     raw_config: Optional[dict] = None
     mimi_config: Optional[dict] = None
     model_type: str = "moshi"
+    lora_weights: Optional[Path] = None
     lm_gen_config: dict = field(default_factory=dict)
+    tts_config: dict = field(default_factory=dict)
+    stt_config: dict = field(default_factory=dict)
+    model_id: dict = field(default_factory=dict)
 
     @staticmethod
     def from_hf_repo(*args, **kwargs):
         raise RuntimeError("the engine has no network path: download the repository and use CheckpointInfo.from_local(dir)")
 
     @staticmethod
-    def from_local(path: str | Path, moshi_weights=None, mimi_weights=None, tokenizer=None) -> "CheckpointInfo":
+    def from_local(path: str | Path, moshi_weights=None, mimi_weights=None, tokenizer=None, lora_weights=None,
+                   mimi_config_path=None) -> "CheckpointInfo":
         """`path`: a directory with `config.json` (the released layout, loaders.py:181-280) or the config file itself.
-        config.json keys: `moshi_name`, `mimi_name`, `tokenizer_name`, optional `model_type`, `lm_gen_config`, `mimi_config`;
-        everything else is the LM's kwargs."""
+        config.json keys: `moshi_name`, `mimi_name`, `tokenizer_name`, optional `model_type`, `lm_gen_config`, `mimi_config` /
+        `mimi_config_name`, `lora_name`, `tts_config`, `stt_config`, `model_id`; everything else is the LM's kwargs.  A
+        fine-tune's adapter (`lora_name`, or `lora_weights=`) is resolved here and merged at load (loaders.py:229,260-265,305)."""
         path = Path(path)
         cfg_file = path / "config.json" if path.is_dir() else path
         root = cfg_file.parent
@@ -208,8 +214,11 @@ class CheckpointInfo:
         model_type = lm_config.pop("model_type", "moshi")
         lm_gen_config = lm_config.pop("lm_gen_config", {})
         mimi_config = lm_config.pop("mimi_config", None)
-        for k in ("tts_config", "stt_config", "model_id", "lora_name"):
-            lm_config.pop(k, None)
+        mimi_config_name = lm_config.pop("mimi_config_name", None)
+        lora_name = lm_config.pop("lora_name", None)
+        tts_config = lm_config.pop("tts_config", {})
+        stt_config = lm_config.pop("stt_config", {})
+        model_id = lm_config.pop("model_id", {})
 
         def local(given, name):
             if given is not None:
@@ -219,9 +228,22 @@ class CheckpointInfo:
             if str(name).startswith("hf://"):
                 name = str(name).rsplit("/", 1)[-1]     # the file must already sit next to config.json
             return root / name
+        mimi_cfg_file = local(mimi_config_path, mimi_config_name)            # loaders.py:251-258
+        if mimi_cfg_file is not None:
+            if not mimi_cfg_file.exists():
+                raise FileNotFoundError(f"mimi config {mimi_cfg_file} named by {cfg_file} is missing")
+            mimi_config = json.loads(mimi_cfg_file.read_text())
+        lora_file = local(lora_weights, lora_name)                          # loaders.py:260-265
+        if lm_config.get("lora", False):
+            if lora_file is None or not lora_file.exists():
+                raise FileNotFoundError(f"{cfg_file} describes a LoRA fine-tune (`lora`: true) but no adapter file was found "
+                                        f"({lora_file}): refusing to run the base weights under that name")
+        elif lora_file is not None and lora_weights is None:
+            lora_file = None                                                 # `lora_name` without `lora`: nothing to merge
         return CheckpointInfo(local(moshi_weights, names["moshi_name"]), local(mimi_weights, names["mimi_name"]),
                               local(tokenizer, names["tokenizer_name"]), lm_config=lm_config, raw_config=raw,
-                              mimi_config=mimi_config, model_type=model_type, lm_gen_config=lm_gen_config)
+                              mimi_config=mimi_config, model_type=model_type, lora_weights=lora_file,
+                              lm_gen_config=lm_gen_config, tts_config=tts_config, stt_config=stt_config, model_id=model_id)
 
     def get_mimi(self, device: torch.device | str = "cuda", **kwargs) -> MimiModel:      # loaders.py:282-291
         n = 8 if self.lm_config is None else max(self.lm_config["dep_q"], self.lm_config["n_q"] - self.lm_config["dep_q"])
@@ -232,5 +254,6 @@ class CheckpointInfo:
             w = state["text_emb.weight"].clone()
             w[2] = w[3]
             state["text_emb.weight"] = w
+        kwargs.setdefault("lora_weights", self.lora_weights)                                         # loaders.py:305
         return get_moshi_lm(self.moshi_weights, lm_kwargs=self.lm_config, device=device, dtype=dtype,
                             state_patch=hibiki if self.model_type == "hibiki" else None, **kwargs)   # loaders.py:293-313

@@ -77,7 +77,8 @@ class MimiModel:
         descs, keep = _capi.tensor_descs(sd)
         cfg = _mimi_cfg_struct(self.config)
         self._sync()
-        lib.check(lib.mmi_mimi_create(C.byref(cfg), descs, len(sd), max_batch, C.byref(self._handle)))
+        with _capi.device_scope(self.device):             # the handle binds to the device current at create
+            lib.check(lib.mmi_mimi_create(C.byref(cfg), descs, len(sd), max_batch, C.byref(self._handle)))
         del keep
         self.max_batch = max_batch
         self.set_num_codebooks(min(num_codebooks, self.config.q_n_q))
@@ -105,6 +106,11 @@ class MimiModel:
         m = mask.to(device=self.device, dtype=torch.bool).contiguous().view(torch.uint8)
         assert m.numel() == self._batch, f"mask has {m.numel()} entries, streaming batch is {self._batch}"
         return m, m.data_ptr()
+
+    def launch_list(self, which: str = "encode"):
+        """[(site, kernel)] per kernel launch of one encoder / decoder step (recorded during the first step)."""
+        w = {"encode": 0, "decode": 1}[which]
+        return _capi.launch_list(lambda buf, cap: self._lib.mmi_mimi_launch_list(self._handle, w, buf, cap))
 
     # ---- properties (compression.py:232-265) -----------------------------------------------------
     @property

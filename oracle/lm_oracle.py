@@ -28,7 +28,24 @@ def bf16r(x: np.ndarray) -> np.ndarray:
     return r.view(f32)
 
 
-def _np(t) -> np.ndarray:
+class LazyWeight:
+    """A linear weight that stays wherever its tensor lives (e.g. bf16 on the GPU) and is widened to fp32 numpy only while a
+    `linear` uses it: lets the 32-layer 7B oracle (30 GB in fp32) run on a host that cannot hold it (tests only)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    def numpy(self) -> np.ndarray:
+        return self.tensor.detach().cpu().float().numpy()
+
+
+def _np(t):
+    if isinstance(t, LazyWeight):
+        return t
     if isinstance(t, np.ndarray):
         return t.astype(f32)
     return t.detach().cpu().float().numpy()
@@ -94,6 +111,8 @@ def linear(x: np.ndarray, w) -> np.ndarray:
         return bf16r((acc * (w.scale * w.input_scale)[None, :]).astype(f32))
     if isinstance(w, QWeight):
         return bf16r(((x @ w.q.T).astype(f32) * w.scale[None, :]).astype(f32))
+    if isinstance(w, LazyWeight):
+        w = w.numpy()
     return bf16r((x @ w.T).astype(f32))
 
 
@@ -247,6 +266,13 @@ class LMOracle:
 
     def set_exec_mask(self, mask):
         self.exec_mask = np.asarray(mask, bool).copy()
+
+    def seek(self, offsets):
+        """The checker's side of `mmi_lm_seek`: every session jumps to stream position offsets[b]; the ring keeps its contents."""
+        offsets = np.asarray(offsets, np.int64)
+        self.offsets = offsets.copy()
+        self.tr_offset = self._model_rows(offsets).copy()
+        self.offset_cpu = int(offsets.max())
 
     # ---- temporal transformer (lm.py:379-408; transformer.py:533-597, 752-802) -------------------------
     def _embed(self, emb: np.ndarray, tok: np.ndarray) -> np.ndarray:

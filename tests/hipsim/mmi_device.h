@@ -27,8 +27,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MMI_WAVE 64
 #define MMI_SHARED static thread_local
 #define MMI_DYN_SHARED(T, name) T* name = reinterpret_cast<T*>(hipsim::dyn_smem())
-#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...) \
-    hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+void mmi_note_launch(const char* kernel);
+#define MMI_LAUNCH(kern, grid, block, shmem, stream, ...)                                               \
+    do {                                                                                                \
+        mmi_note_launch(#kern);                                                                         \
+        hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); });        \
+    } while (0)
 
 using std::min;
 using std::max;

@@ -214,6 +214,115 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
             stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
 
 
+class ErrorLog:
+    """Measured engine-vs-checker logit errors per sampling site, relative to max|ref| of the row: what the tolerance is set from."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def add(self, site: str, a: np.ndarray, ref: np.ndarray):
+        scale = float(np.abs(ref).max()) + 1e-6
+        d = np.abs(a - ref)
+        self.rows.setdefault(site, []).append((float(d.max()) / scale, float(d.mean()) / scale))
+
+    def summary(self) -> dict:
+        out = {}
+        for site, v in self.rows.items():
+            mx, mn = np.array([x[0] for x in v]), np.array([x[1] for x in v])
+            out[site] = {"n": len(v), "max_rel_worst": float(mx.max()), "max_rel_median": float(np.median(mx)),
+                         "mean_rel_worst": float(mn.max()), "mean_rel_median": float(np.median(mn))}
+        return out
+
+    def dump(self, name: str):
+        import json
+        summ = self.summary()
+        worst = max(v["max_rel_worst"] for v in summ.values())
+        worst_mean = max(v["mean_rel_worst"] for v in summ.values())
+        print(f"[parity] {name}: worst max-rel {worst:.4f}, worst mean-rel {worst_mean:.4f} over {sum(v['n'] for v in summ.values())} (row, site) pairs")
+        for site, v in summ.items():
+            print(f"[parity]   {site:8s} max-rel worst {v['max_rel_worst']:.4f} median {v['max_rel_median']:.4f} | "
+                  f"mean-rel worst {v['mean_rel_worst']:.4f} median {v['mean_rel_median']:.4f}")
+        out = Path(__file__).resolve().parent.parent / "gpurun_out"
+        if out.is_dir():
+            (out / f"parity_{name}.json").write_text(json.dumps({"case": name, "sites": summ}, indent=1))
+        return worst, worst_mean
+
+
+def lazy_temporal_linears(sd):
+    """The checker keeps the temporal transformer's big linears where they are (bf16 on the GPU) and widens each to fp32 only
+    while it multiplies with it (oracle.lm_oracle.LazyWeight): the 32-layer oracle then needs ~2 GB of host memory, not 30."""
+    from oracle.lm_oracle import LazyWeight
+    out = {}
+    for k, v in sd.items():
+        big = k.startswith("transformer.layers.") and k.endswith(".weight")
+        out[k] = LazyWeight(v) if big else v
+    return out
+
+
+def full_depth_vs_oracle(device, lib, B=32, S=3, num_layers=32, seed=4242, name="full_depth_b32", cfg=None):
+    """The model bench.py times - LMConfig(): 32 temporal layers, context 3000, B sessions - against the numpy oracle,
+    teacher-forced, rows at different depths.  The checker's ring is shortened to 64 slots (no wrap inside this test; the
+    real 3000-slot wrap is `ring_wrap_at_real_capacity`), the engine runs its real ring."""
+    from dataclasses import replace
+    cfg = cfg or LMConfig(num_layers=num_layers)
+    sd = random_lm_state_dict(cfg, seed=seed, device=device)
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(lazy_temporal_linears(sd), replace(cfg, context=64))
+    orc.streaming(B)
+    rng = np.random.default_rng(seed)
+    log = ErrorLog()
+    start = (np.arange(B) % 5) * 7                 # rows at different stream positions (0 .. 28), none near the 64-slot checker ring
+    bad = []
+    with gen.streaming(B):
+        gen.seek(start); orc.seek(start)
+        for s in range(S):
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            assert np.array_equal(out, oo), f"step {s}: ring output differs"
+            for b in range(B):
+                log.add("text", tl[b], otl[b])
+                if not logits_close(tl[b], otl[b]):
+                    bad.append((s, b, "text"))
+                for k in range(cfg.dep_q):
+                    log.add(f"audio{k}", al[b, k], oal[b, k])
+                    if not logits_close(al[b, k], oal[b, k]):
+                        bad.append((s, b, f"audio{k}"))
+    worst, worst_mean = log.dump(name)
+    assert not bad, f"{len(bad)} (step, row, site) pairs outside the tolerance, first {bad[:5]}; worst max-rel {worst:.4f} mean-rel {worst_mean:.4f}"
+    return log
+
+
+def ring_wrap_at_real_capacity(device, lib, B=2, S=14, seed=91):
+    """The temporal ring at its real geometry (3000 slots x 32 heads x 128) wrapping: sessions are moved to positions
+    2995 / 2990 of an all-zero ring (mmi_lm_seek), then stepped across slot 2999 -> 0; engine and checker hold the same ring."""
+    cfg = LMConfig(num_layers=2)
+    sd = random_lm_state_dict(cfg, seed=seed, device=device)
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(B)
+    rng = np.random.default_rng(seed)
+    start = np.array([cfg.context - 5 - 5 * b for b in range(B)])
+    log = ErrorLog()
+    with gen.streaming(B):
+        gen.seek(start); orc.seek(start)
+        for s in range(S):
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            assert np.array_equal(out, oo), f"step {s}: ring output differs"
+            for b in range(B):
+                log.add("text", tl[b], otl[b])
+                assert logits_close(tl[b], otl[b]), f"step {s} row {b} (position {start[b] + s}): text logits"
+                for k in range(cfg.dep_q):
+                    assert logits_close(al[b, k], oal[b, k]), f"step {s} row {b} cb {k}"
+    log.dump("ring_wrap_3000")
+
+
 def smoke_lm(dev):
     """One tiny LMGen.step on the GPU against the oracle (called by __graft_entry__.smoke)."""
     cfg = tiny_lm_config()

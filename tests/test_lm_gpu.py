@@ -176,6 +176,24 @@ def test_full_width_layers_match_oracle(gpu_lib):
     lm_cases.oracle_vs_engine(DEV, None, cfg, seed=7, B=3, S=3, use_masks=True)
 
 
+def test_full_depth_32_layers_at_the_benchmark_batch_match_oracle(gpu_lib):
+    """The exact model `bench.py` times - 32 temporal layers, 3000-slot ring, 32 sessions - against the numpy oracle for three
+    teacher-forced steps; the measured error per sampling site is printed and written to gpurun_out/parity_*.json."""
+    lm_cases.full_depth_vs_oracle(DEV, None, B=32, S=3)
+
+
+@pytest.mark.parametrize("B", [40, 64])
+def test_two_batch_tiles_at_full_width_match_oracle(gpu_lib, B):
+    """33..64 sessions at the 7B layer shapes on the DEFAULT GEMM path (k_gemm_xp with two batch tiles per weight fragment:
+    what BASELINE configs[4] runs at 64 sessions)."""
+    cfg = LMConfig(num_layers=2, context=64)
+    lm_cases.oracle_vs_engine(DEV, None, cfg, seed=300 + B, B=B, S=2, use_masks=True)
+
+
+def test_ring_wraps_at_the_real_capacity(gpu_lib):
+    lm_cases.ring_wrap_at_real_capacity(DEV, None)
+
+
 def _greedy_run(cfg, sd, B, codes, steps, graph=True, monkeypatch=None):
     lm = LMModel(sd, cfg, device=DEV, max_batch=B)
     gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)

@@ -232,3 +232,40 @@ def test_guided_batch_must_fit_twice(sim_lib):
 
 def test_get_and_set_streaming_state_resume_a_dialogue(sim_lib):
     lm_cases.check_streaming_state_snapshot("cpu", sim_lib)
+
+
+def test_seek_moves_sessions_and_the_ring_wraps(sim_lib):
+    """mmi_lm_seek (test / benchmark aid): sessions jump to positions just before the ring capacity of an all-zero ring and
+    step across the wrap; engine and oracle agree.  Also the launch list of the step names a site for every kernel."""
+    from oracle.lm_oracle import LMOracle
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=12)
+    gen = lm_cases.make_engine(cfg, sd, "cpu", sim_lib, 2, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(2)
+    start = np.array([cfg.context - 2, 3 * cfg.context - 1])
+    rng = np.random.default_rng(3)
+    with gen.streaming(2):
+        assert gen.launch_list() == []
+        gen.seek(start); orc.seek(start)
+        for s in range(4):
+            codes = rng.integers(0, cfg.card, (2, 8, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes), forced_tokens=torch.from_numpy(forced))
+            assert np.array_equal(out.numpy(), oo)
+            for b in range(2):
+                assert lm_cases.logits_close(tl[b].numpy(), otl[b])
+        ll = gen.launch_list()
+    sites = [s for s, _ in ll]
+    assert sites[0] == "prepare" and sites[-1] == "commit" and "-" not in sites
+    assert sites.count("L.ffn_in") == cfg.num_layers and sites.count("dep.out_proj") == cfg.dep_q * cfg.depformer_num_layers
+    assert all(k.startswith("k_") for _, k in ll)
+
+
+def test_full_depth_checker_plumbing_on_the_tiny_model(sim_lib):
+    """The machinery of the 32-layer GPU parity test (lazy fp32 widening of the temporal linears, rows at different depths,
+    per-site error log) on the tiny model, where it runs in seconds."""
+    from dataclasses import replace
+    log = lm_cases.full_depth_vs_oracle("cpu", sim_lib, B=3, S=2, seed=9, name="plumbing", cfg=replace(tiny_lm_config(), context=100))
+    assert set(log.summary()) == {"text"} | {f"audio{k}" for k in range(tiny_lm_config().dep_q)}

@@ -139,3 +139,37 @@ def test_lora_adapter_is_merged_like_the_reference(sim_lib, tmp_path):
     lm = loaders.get_moshi_lm(tmp_path / "model.safetensors", {**tiny_lm_kwargs(), "lora": True, "lora_rank": rank, "lora_scaling": scaling},
                               device="cpu", max_batch=2, lib=sim_lib, lora_weights=tmp_path / "lora.safetensors", fuse_lora=True)
     assert np.array_equal(greedy_tokens(lm), greedy_tokens(LMModel(merged, cfg, device="cpu", max_batch=2, lib=sim_lib)))
+
+
+def test_checkpoint_info_resolves_lora_and_mimi_config_names(sim_lib, tmp_path):
+    """A fine-tune's config.json (`lora`: true, `lora_name`, `mimi_config_name`): the adapter is found and merged by get_moshi,
+    the codec config is read from the named file, and a missing adapter is an error - never the base model run silently
+    (loaders.py:226-265, 305)."""
+    from moshi_amd.weights import fuse_lora_state_dict, normalize_lm_state_dict
+    lcfg = tiny_lm_config()
+    mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.dep_q)
+    sd = random_lm_state_dict(lcfg, seed=5)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    save_file(random_mimi_state_dict(mcfg, seed=6), str(tmp_path / "mimi.safetensors"))
+    g = torch.Generator().manual_seed(1)
+    w = sd["text_linear.weight"]
+    lora = {"text_linear.lora_A.weight": (0.3 * torch.randn(4, w.shape[1], generator=g)).to(torch.bfloat16),
+            "text_linear.lora_B.weight": (0.3 * torch.randn(w.shape[0], 4, generator=g)).to(torch.bfloat16)}
+    (tmp_path / "mimi_config.json").write_text(json.dumps(mcfg.reference_kwargs()))
+    conf = {**tiny_lm_kwargs(), "moshi_name": "model.safetensors", "mimi_name": "mimi.safetensors", "tokenizer_name": "tok.model",
+            "lora": True, "lora_rank": 4, "lora_scaling": 2.0, "lora_name": "lora.safetensors", "mimi_config_name": "mimi_config.json",
+            "stt_config": {"audio_delay_seconds": 0.5}, "model_id": {"sig": "abc"}}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    with pytest.raises(FileNotFoundError, match="adapter"):
+        loaders.CheckpointInfo.from_local(tmp_path)
+    save_file(lora, str(tmp_path / "lora.safetensors"))
+    info = loaders.CheckpointInfo.from_local(tmp_path)
+    assert info.lora_weights == tmp_path / "lora.safetensors" and info.stt_config == {"audio_delay_seconds": 0.5}
+    assert info.mimi_config == mcfg.reference_kwargs() and "mimi_config_name" not in info.lm_config
+    assert info.get_mimi(device="cpu", max_batch=2, lib=sim_lib).cardinality == lcfg.card
+    from moshi_amd.lm import LMModel
+    merged = fuse_lora_state_dict(normalize_lm_state_dict(dict(sd), lcfg), lora, 2.0)
+    want = greedy_tokens(LMModel(merged, lcfg, device="cpu", max_batch=2, lib=sim_lib))
+    base = greedy_tokens(LMModel(sd, lcfg, device="cpu", max_batch=2, lib=sim_lib))
+    got = greedy_tokens(info.get_moshi(device="cpu", max_batch=2, lib=sim_lib))
+    assert np.array_equal(got, want) and not np.array_equal(got, base)

@@ -1,0 +1,31 @@
+"""scripts/rocpd_sites.py: the join of the engine's launch list with a rocprofv3 kernel trace, on a synthetic trace."""
+import sqlite3
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_sites_join_by_position(tmp_path):
+    ll = [("prepare", "k_lm_prepare"), ("L.in_proj", "k_gemm_xp"), ("L.ffn_in", "k_gemm_xp"), ("L.in_proj", "k_gemm_xp"),
+          ("L.ffn_in", "k_gemm_xp"), ("commit", "k_lm_commit")]
+    (tmp_path / "launch_list_lm.tsv").write_text("".join(f"{s}\t{k}\n" for s, k in ll))
+    db = tmp_path / "t.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer)")
+    t = 0
+    full = {"k_lm_prepare": "k_lm_prepare(TokArgs, int const*)", "k_gemm_xp": "void k_gemm_xp<32, 1, 1, 8, 4, 0>(GemmArgs)",
+            "k_lm_commit": "k_lm_commit(TokArgs)"}
+    for step in range(4):
+        c.execute("insert into kernels values (?,?,?)", ("__amd_rocclr_fillBufferAligned", t, t + 1000)); t += 2000
+        for site, k in ll:
+            d = {"prepare": 5000, "L.in_proj": 20000, "L.ffn_in": 40000, "commit": 7000}[site]
+            c.execute("insert into kernels values (?,?,?)", (full[k], t, t + d)); t += d + 500
+    c.commit(); c.close()
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_sites.py"), str(db), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = {ln.split(",")[1]: ln.split(",") for ln in r.stdout.splitlines() if ln.startswith("lm,")}
+    assert rows["L.in_proj"][2] == "2" and abs(float(rows["L.in_proj"][3]) - 40.0) < 1e-6 and abs(float(rows["L.in_proj"][4]) - 20.0) < 1e-6
+    assert abs(float(rows["L.ffn_in"][4]) - 40.0) < 1e-6
+    assert abs(float(rows["L.ffn_in"][6]) - 2 * 2 * 11264 * 4096 / 40e-6 / 1e9) < 1.0      # GB/s of the 7B shape
