@@ -93,6 +93,7 @@ struct mmi_lm {
     unsigned long long* rng = nullptr;
     long offset_cpu = 0;
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
+    bool dominant_xlds = false;     // the profiled (dominant) GEMM ran on k_gemm_xlds
     MmiProgram prog;
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
@@ -275,14 +276,17 @@ int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmAr
     return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
 }
 
-// k_gemm_xlds (activations resident in LDS, one workgroup per CU): which GEMMs take it, and how.  Off unless MMI_GEMM_LDS=1:
-// built and checked on the simulator and in the microbenchmark this round, not yet validated in the step on hardware.
+// k_gemm_xlds (activations resident in LDS, one workgroup per CU): which GEMMs take it, and how.  MMI_GEMM_LDS: "2" = with
+// the staggered tail (each tile's epilogue under the last chunk's weight stream; the DEFAULT for bf16 weights at the 32-row
+// tile: same-box A/B of the default benchmark 8.10 / 8.12 ms against 8.17 / 8.20 ms with k_gemm_xp, dominant kernel 38.6
+// against 40.2 us live, profiles/r02_logs/ab_gemm_xlds_stagger_in_step.txt), "1" = plain tails (also what int8 / fp8 weight
+// entries take when asked for; they stay on k_gemm_xp by default), "0" = k_gemm_xp everywhere.
 struct XldsPlan { bool on; int kc, grid; size_t smem; bool stagger; };
 XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) {
     XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
-    const bool enabled = en && en[0] && en[0] != '0';
-    if (!enabled || lm->T != 32 || mt > 2) return p;
+    const char mode = en && en[0] ? en[0] : (g.wq == 0 ? '2' : '0');
+    if (mode == '0' || lm->T != 32 || mt > 2) return p;
     if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
@@ -295,7 +299,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     else return p;
     p.grid = g.NT < cus ? g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
-    p.stagger = en[0] == '2' && g.wq == 0;                    // MMI_GEMM_LDS=2: per-tile epilogues under the last chunk's stream (bf16)
+    p.stagger = mode == '2' && g.wq == 0;                     // per-tile epilogues under the last chunk's stream (bf16)
     const size_t chunks = (size_t)2 * mt * p.kc * xs * 1024, red = mt == 1 ? 40960 : 65536;   // red: the epilogue's reduction scratch
     p.smem = chunks > red ? chunks : red;
     if (p.stagger && chunks < 131072) p.smem = chunks + red; // short test chunks: the scratch sits behind both buffers
@@ -350,6 +354,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
         MMI_HIP_CHECK(hipEventRecord(ev->a, s));
     }
     int rc;
+    if (is_dominant) lm->dominant_xlds = xl.on;
     if (xl.on) {
         lm->xlds_launches += 1;
         rc = mt == 1 ? launch_xlds<1>(s, xl, a) : launch_xlds<2>(s, xl, a);
@@ -1124,6 +1129,8 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (kernel_name)
         *kernel_name = lm->q8 == 1   ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
                        : lm->q8 == 2 ? "k_gemm_xp<32, 1, 1, 8, 2, 2> (temporal FFN linear_in, fp8 weights on the fp8 MFMA + SiLU gate)"
+                       : lm->dominant_xlds ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
+                                                             : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)")
                                      : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;

@@ -1338,8 +1338,17 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         return;
     }
 
+    // The production path (top-k, on-device RNG): argmax_i p_i / q_i over the top-k set does not need the softmax at all -
+    // log(p_i / q_i) = logit_i / temp - log q_i + const - and with no recorded draws to replay the Exp(1) draw of an entry may
+    // be indexed by the entry instead of by its rank in the sorted top-k (i.i.d. draws assigned independently of their values:
+    // the same distribution, checked by the frequency test the reference uses for its own sampler, sampling.py:109-127).  That
+    // removes the two softmax passes, the ordered compaction and the rank computation from the critical path of every
+    // sampling site; what stays is the radix select of the k-th largest logit.  Supplied noise (the parity taps) keeps the
+    // reference's rank-indexed form below.
+    const bool fast = a.k > 0 && *a.use_noise == 0;
+    float mx = -INFINITY, sum = 1.f;
+    if (!fast) {
     // ---- softmax statistics of logits / temp (fp32)
-    float mx = -INFINITY;
     MMI_S_FOREACH({ mx = fmaxf(mx, mmi_bf16_to_f32(bits) / a.temp); })
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, mmi_shfl_xor(mx, m));
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     mx = redf[0];
     for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, redf[w]);
     __syncthreads();
-    float sum = 0.f;
+    sum = 0.f;
     MMI_S_FOREACH({ sum += expf(mmi_bf16_to_f32(bits) / a.temp - mx); })
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sum += mmi_shfl_xor(sum, m);
@@ -1357,6 +1366,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     sum = 0.f;
     for (int w = 0; w < NT / 64; ++w) sum += redf[w];
     __syncthreads();
+    }
 
     if (a.k <= 0) {
         // top_k = 0: `multinomial(probs)` over the whole vocabulary (sampling.py:98-106 without top-k/top-p): the reference
@@ -1429,6 +1439,43 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     const int eq_base = mmi_block_excl_scan<NT>(n_eq, wsum, &tot);
     int eq_take = want_eq - eq_base;
     eq_take = eq_take < 0 ? 0 : (eq_take > n_eq ? n_eq : eq_take);
+    if (fast) {
+        // every member of the set scores logit / temp - log(q), q ~ Exp(1) drawn at (site, session, entry); the largest wins
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        int eq_seen_f = 0;
+        const float inv_t = 1.0f / a.temp;
+        MMI_S_FOREACH({
+            const unsigned ky = mmi_bf16_key(bits);
+            bool take = ky > Tkey;
+            if (ky == Tkey) { take = eq_seen_f < eq_take; ++eq_seen_f; }
+            if (take) {
+                const float q = mmi_exp_noise(a.rng[0], a.rng[1], (unsigned)(a.site * a.B + b), (unsigned)i);
+                const float sc_ = mmi_bf16_to_f32(bits) * inv_t - logf(q);
+                if (sc_ > best || (sc_ == best && i < bi)) { best = sc_; bi = i; }
+            }
+        })
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ob = mmi_shfl_xor(best, m);
+            const int oi = mmi_shfl_xor(bi, m);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NT / 64; ++w)
+                if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+            bi = mmi_apply_forced(a, b, bi);
+            a.out[(long)b * a.out_stride] = bi;
+            redi[0] = bi;
+        }
+        if (a.nx_out) {
+            __syncthreads();
+            mmi_sample_next_input(a, b, redi[0]);
+        }
+        return;
+    }
     int pos = mmi_block_excl_scan<NT>(n_gt + eq_take, wsum, &tot);
     int eq_seen = 0;
     MMI_S_FOREACH({

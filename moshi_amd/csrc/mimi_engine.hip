@@ -22,6 +22,11 @@ struct TrLayerW {
 struct Buf {            // activation buffer [B][C][ld]; first H columns = causal history of its consumer
     float* p = nullptr;
     int C = 0, ld = 0, H = 0;
+    // ELU hoisted into the producers (ConvGemmArgs::elu_out / out2, mimi_kernels.h):
+    float* pe = nullptr;   // twin of the same geometry holding ELU(values) - what the ELU-fronted consumer conv reads
+    bool elu = false;      // `p` itself holds ELU(values) (no reader wants the raw ones)
+    float* conv_src() const { return pe ? pe : p; }                    // what an ELU-fronted conv reads
+    bool needs_elu_at_load() const { return !pe && !elu; }
 };
 
 }  // namespace
@@ -239,15 +244,20 @@ struct ConvPlan {
     bool pack = false;
 };
 
-template <int MTB, int U>
-void launch_wide_w(hipStream_t s, const ConvGemmArgs& a, int W, dim3 grid) {
+template <int MTB, int U, bool ELU_IN>
+void launch_wide_e(hipStream_t s, const ConvGemmArgs& a, int W, dim3 grid) {
     const size_t smem = (size_t)W * MTB * 16 * 64 * sizeof(float);
     switch (W) {
-        case 1: MMI_LAUNCH((k_conv_wide<MTB, 1, U>), grid, 64, 0, s, a); break;
-        case 2: MMI_LAUNCH((k_conv_wide<MTB, 2, U>), grid, 128, smem, s, a); break;
-        case 4: MMI_LAUNCH((k_conv_wide<MTB, 4, U>), grid, 256, smem, s, a); break;
-        default: MMI_LAUNCH((k_conv_wide<MTB, 8, U>), grid, 512, smem, s, a); break;
+        case 1: MMI_LAUNCH((k_conv_wide<MTB, 1, U, ELU_IN>), grid, 64, 0, s, a); break;
+        case 2: MMI_LAUNCH((k_conv_wide<MTB, 2, U, ELU_IN>), grid, 128, smem, s, a); break;
+        case 4: MMI_LAUNCH((k_conv_wide<MTB, 4, U, ELU_IN>), grid, 256, smem, s, a); break;
+        default: MMI_LAUNCH((k_conv_wide<MTB, 8, U, ELU_IN>), grid, 512, smem, s, a); break;
     }
+}
+template <int MTB, int U>
+void launch_wide_w(hipStream_t s, const ConvGemmArgs& a, int W, dim3 grid) {
+    if (a.elu_in) launch_wide_e<MTB, U, true>(s, a, W, grid);      // ELU at the load (inputs nobody pre-activated)
+    else launch_wide_e<MTB, U, false>(s, a, W, grid);
 }
 
 int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
@@ -363,9 +373,13 @@ ConvGemmArgs conv_args(const ConvW& w, const Buf& in, int x_off, int T_out, cons
                        bool elu_in) {
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = in.p; a.x_ld = in.ld; a.x_bstride = (long)in.C * in.ld; a.x_off = x_off; a.H = in.H;
+    // an ELU-fronted conv reads the producer's pre-activated values when they exist (Buf::pe / Buf::elu)
+    a.x = elu_in ? in.conv_src() : in.p;
+    if (elu_in && !in.needs_elu_at_load()) elu_in = false;
+    a.x_ld = in.ld; a.x_bstride = (long)in.C * in.ld; a.x_off = x_off; a.H = in.H;
     a.wpk = w.wpk; a.bias = w.bias;
     a.out = out.p; a.out_ld = out.ld; a.out_off = out_off;
+    a.out2 = out.pe; a.elu_out = out.elu ? 1 : 0;
     a.B = B; a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K; a.S = w.S; a.T_out = T_out;
     a.T_magic = mmi_div_magic(T_out); a.K_magic = mmi_div_magic(w.K);
     a.Mt = w.Mt; a.Q = w.Q; a.Ntot = B * T_out;
@@ -381,6 +395,22 @@ int alloc_buf(mmi_mimi* m, int B, int C, int H, int T, Buf* b, hipStream_t s) {
     MMI_HIP_CHECK(m->st.alloc(&b->p, n));
     MMI_HIP_CHECK(hipMemsetAsync(b->p, 0, n * sizeof(float), s));
     return MMI_OK;
+}
+
+// ELU twin of a buffer (same geometry, zero history: ELU(0) = 0)
+int alloc_twin(mmi_mimi* m, int B, Buf* b, hipStream_t s) {
+    size_t n = (size_t)B * b->C * b->ld;
+    MMI_HIP_CHECK(m->st.alloc(&b->pe, n));
+    MMI_HIP_CHECK(hipMemsetAsync(b->pe, 0, n * sizeof(float), s));
+    return MMI_OK;
+}
+
+// the history a consumer conv reads lives in the buffer it reads: the ELU twin when there is one
+HistDesc hist_of(const Buf& b, int T);
+HistDesc hist_of_src(const Buf& b, int T) {
+    Buf c = b;
+    c.p = b.conv_src();
+    return hist_of(c, T);
 }
 
 int add_conv(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a, MmiArena* arena = nullptr) {
@@ -559,12 +589,16 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     hist.push_back(hist_of(m->enc_in, T));
     Buf cur = m->enc_in;
     int mult = 1;
+    // ELU hoisted into the producers (mimi_kernels.h ConvGemmArgs::elu_out / out2): a resblock input is kept raw (residual) AND
+    // ELU'd (its first conv reads that, history included); everything else a conv reads through ELU is stored ELU'd only
+    const bool hoist = !getenv("MMI_NO_ELU_HOIST");
     {   // conv0: channels -> n_filters, K = kernel_size; consumer = resblock conv (K = residual_kernel_size)
         Buf nxt;
         if ((rc = alloc_buf(m, B, c.n_filters, c.residual_kernel_size - 1, T, &nxt, s0))) return rc;
+        if (hoist && (rc = alloc_twin(m, B, &nxt, s0))) return rc;
         prog.site("enc.conv0");
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false)))) return rc;
-        hist.push_back(hist_of(nxt, T));
+        hist.push_back(hist_of_src(nxt, T));
         cur = nxt;
     }
     for (int i = 0; i < c.n_ratios; ++i) {
@@ -574,6 +608,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         Buf hid, nxt;
         if ((rc = alloc_buf(m, B, ch / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
+        hid.elu = nxt.elu = hoist;               // read only by the block's second conv / the strided conv, both behind an ELU
         prog.site("enc.res" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->enc_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
@@ -586,9 +621,11 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? c.residual_kernel_size - 1 : c.last_kernel_size - 1;
         Buf nx2;
         if ((rc = alloc_buf(m, B, 2 * ch, Hn, Tn, &nx2, s0))) return rc;
+        if (hoist && i + 1 < c.n_ratios) { if ((rc = alloc_twin(m, B, &nx2, s0))) return rc; }   // the next resblock's input
+        else nx2.elu = hoist;                                                                     // read by the final conv only
         prog.site("enc.down" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true)))) return rc;
-        hist.push_back(hist_of(nx2, Tn));
+        hist.push_back(hist_of_src(nx2, Tn));
         cur = nx2;
         T = Tn;
         mult *= 2;
@@ -681,8 +718,10 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     size_t ci = 0;
     int mult = 1 << c.n_ratios;
     Buf cur;
+    const bool hoist = !getenv("MMI_NO_ELU_HOIST");       // see build_encoder
     {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
         if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
+        cur.elu = hoist;
         prog.site("dec.conv0");
         if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false)))) return rc;
     }
@@ -694,6 +733,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         if ((rc = alloc_buf(m, B, cout * K, 0, T, &tmp, s0))) return rc;
         const int Tn = T * ratio;
         if ((rc = alloc_buf(m, B, cout, c.residual_kernel_size - 1, Tn, &up, s0))) return rc;
+        if (hoist && (rc = alloc_twin(m, B, &up, s0))) return rc;           // resblock input: raw for the residual, ELU'd for its conv
         const ConvW& wtr = m->dec_convs[ci++];
         prog.site("dec.convtr" + std::to_string(i));
         {
@@ -708,21 +748,22 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
             MMI_HIP_CHECK(hipMemsetAsync(part, 0, (size_t)B * pn * sizeof(float), s0));
             m->partials.push_back(part); m->partial_sizes.push_back(pn);
             const float* tp = tmp.p; const float* bias = wtr.bias; const uint8_t* ex = m->exec;
-            float* out = up.p; int old = up.ld, ooff = up.H; int Tin = T;
+            float* out = up.p; float* out2 = up.pe; int old = up.ld, ooff = up.H; int Tin = T;
             prog.add([=](hipStream_t s) {
                 MMI_LAUNCH(k_convtr_combine, (int)mmi_cdiv64((int64_t)B * cout * Tin * ratio, 256), 256, 0, s, tp, bias, part,
-                           ex, out, old, ooff, B, cout, K, ratio, Tin);
+                           ex, out, old, ooff, B, cout, K, ratio, Tin, out2);
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
         }
-        hist.push_back(hist_of(up, Tn));
+        hist.push_back(hist_of_src(up, Tn));
         T = Tn;
         // resblock; consumer = next conv-transpose GEMM (no history) or the final conv (last_kernel_size)
         Buf hid, nxt;
         const int Hn = (i + 1 < c.n_ratios) ? 0 : c.last_kernel_size - 1;
         if ((rc = alloc_buf(m, B, cout / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
+        hid.elu = nxt.elu = hoist;               // read only behind an ELU: by the block's second conv / the next layer
         prog.site("dec.res" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true)))) return rc;
         ConvGemmArgs a = conv_args(m->dec_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);

@@ -118,6 +118,13 @@ struct ConvGemmArgs {
     int Ntot;             // B * T_out
     int elu_in;           // apply ELU(alpha=1) to every loaded input (seanet.py:63,205,222)
     int act_out;          // MMI_ACT_*
+    // ELU hoisted out of the consumers: every SEANet conv but the first reads ELU(x) (seanet.py:63,205,222), and an audio-rate
+    // conv reads each input K * (Cout / 32) times, so the PRODUCER applies it once per element: elu_out = 1 stores ELU(result)
+    // instead of the result (buffers whose only readers are such convs), out2 != null additionally stores ELU(result) there
+    // (same geometry as `out`; block inputs, which the residual connection also needs raw).  Same function on the same values
+    // as applying it at the consumer's load - bit-identical.
+    int elu_out;
+    float* out2;
     // --- filled in by the engine's planner
     const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h; 0 past Cin*K (the weights there are 0)
     const float* bp;      // k_gemm_f32: packed activations [ceil(N/32)][Q][64][4]
@@ -171,11 +178,15 @@ __device__ __forceinline__ void mmi_conv_store_n(const ConvGemmArgs& a, const in
         else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
         if (a.scale) x *= scl[i];
         if (a.res) x = rsv[i] + x;
-        if (ok[i]) a.out[row[i] * a.out_ld + a.out_off + t[i]] = x;
+        if (ok[i]) {
+            const long at = row[i] * a.out_ld + a.out_off + t[i];
+            if (a.out2) { a.out[at] = x; a.out2[at] = mmi_elu(x); }
+            else a.out[at] = a.elu_out ? mmi_elu(x) : x;
+        }
     }
 }
 
-template <int MTB, int W, int U>
+template <int MTB, int W, int U, bool ELU_IN = true>
 __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int jl = lane & 31, kh = lane >> 5;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
         if ((qb) + u < q1) {                                                                        \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
-                const float v = a.elu_in ? mmi_elu(BV[u][e]) : BV[u][e];                            \
+                const float v = (ELU_IN && a.elu_in) ? mmi_elu(BV[u][e]) : BV[u][e];                \
                 _Pragma("unroll") for (int m = 0; m < MTB; ++m) acc[m] = mmi_mfma_f32_32x32x2(AV[u][m][e], v, acc[m]); \
             }                                                                                       \
         }                                                                                           \
@@ -468,9 +479,10 @@ __global__ void k_conv_finish(ConvGemmArgs a, int ksplit) {
 // transposed conv: overlap-add of the GEMM result with the streaming `partial` (conv.py:340-362)
 // tmp [B][Cout*K][T_in] holds tmp[b][co*K + k][t] = sum_ci Wtr[ci][co][k] * elu(x[b][ci][t]); K == 2*S.
 // ------------------------------------------------------------------------------------------------
+// out2: the ELU'd twin of `out` (same geometry) read by the next conv, or null (see ConvGemmArgs::out2)
 __global__ void k_convtr_combine(const float* __restrict__ tmp, const float* __restrict__ bias,
                                  float* __restrict__ partial, const uint8_t* __restrict__ exec, float* __restrict__ out,
-                                 int out_ld, int out_off, int B, int Cout, int K, int S, int T_in) {
+                                 int out_ld, int out_off, int B, int Cout, int K, int S, int T_in, float* __restrict__ out2) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Tout = T_in * S;
     if (idx >= (long)B * Cout * Tout) return;
@@ -490,6 +502,7 @@ __global__ void k_convtr_combine(const float* __restrict__ tmp, const float* __r
         if (exec[b]) partial[pi] = trow[(long)(r + S) * T_in + (T_in - 1)];  // tail, bias excluded (conv.py:354-360)
     }
     out[row * (long)out_ld + out_off + p] = v;
+    if (out2) out2[row * (long)out_ld + out_off + p] = mmi_elu(v);
 }
 
 // depthwise (groups == C) transposed conv, K == 2*S, no bias: ConvTrUpsample1d (resample.py:68-119)

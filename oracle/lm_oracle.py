@@ -100,8 +100,9 @@ class F8Weight:
         return w
 
 
-def linear(x: np.ndarray, w) -> np.ndarray:
-    """nn.Linear(bias=False) on bf16 tensors: fp32 accumulate, bf16 result."""
+def linear(x: np.ndarray, w, acc64: bool = False) -> np.ndarray:
+    """nn.Linear(bias=False) on bf16 tensors: fp32 accumulate, bf16 result.  acc64: accumulate in fp64 instead (see
+    LMOracle(accumulate64=...): the yardstick for how much the summation order of a GEMM moves the network's outputs)."""
     if isinstance(w, F8Weight):
         x8 = e4m3r((x * (f32(1.0) / w.input_scale)).astype(f32))
         acc = (x8 @ w.q.T).astype(f32)
@@ -113,6 +114,8 @@ def linear(x: np.ndarray, w) -> np.ndarray:
         return bf16r(((x @ w.q.T).astype(f32) * w.scale[None, :]).astype(f32))
     if isinstance(w, LazyWeight):
         w = w.numpy()
+    if acc64:
+        return bf16r((x.astype(np.float64) @ w.T.astype(np.float64)).astype(f32))
     return bf16r((x @ w.T).astype(f32))
 
 
@@ -126,12 +129,12 @@ def silu(x: np.ndarray) -> np.ndarray:
     return (x / (f32(1.0) + np.exp(-x))).astype(f32)
 
 
-def gated_ffn(x: np.ndarray, w_in: np.ndarray, w_out: np.ndarray) -> np.ndarray:
+def gated_ffn(x: np.ndarray, w_in: np.ndarray, w_out: np.ndarray, acc64: bool = False) -> np.ndarray:
     """gating.py:13-22 in eager bf16: linear_in -> silu(gate) * value -> linear_out."""
-    h = linear(x, w_in)
+    h = linear(x, w_in, acc64)
     H = h.shape[-1] // 2
     act = bf16r(silu(h[:, :H]))
-    return linear(bf16r(act * h[:, H:]), w_out)
+    return linear(bf16r(act * h[:, H:]), w_out, acc64)
 
 
 def rope_1(q: np.ndarray, k: np.ndarray, offset: np.ndarray, max_period: float):
@@ -170,12 +173,16 @@ def sample_token(logits: np.ndarray, use_sampling: bool, temp: float, top_k: int
 
 
 class LMOracle:
-    def __init__(self, state_dict, cfg, fp8_accumulate_noise: float = 0.0, noise_seed: int = 0):
+    def __init__(self, state_dict, cfg, fp8_accumulate_noise: float = 0.0, noise_seed: int = 0, accumulate64: bool = False):
         """fp8_accumulate_noise: relative perturbation applied to every fp8 GEMM accumulator.  The gfx950 fp8 dot-product unit
         does not sum its 8-product groups exactly: products below ~2^-13 of the group's largest are shifted out (measured by
         scripts/fp8_probe.hip: up to 2.7e-4 of sum|products|).  The tests use this knob to measure how far such a perturbation
         moves the fp8 network's own outputs (e4m3 re-quantisation of every activation amplifies it), which is the yardstick an
         fp8 implementation on that hardware can be held to."""
+        # accumulate64: every bf16 GEMM accumulates in fp64 instead of fp32 - the same network with a different (here: exact)
+        # summation; its distance from the fp32-accumulating oracle is how far ANY correct implementation may sit from either
+        # (bf16 rounding flips of a few GEMM outputs, amplified layer by layer): the yardstick of the full-depth parity test
+        self.acc64 = bool(accumulate64)
         self.cfg = cfg
         sd = {k: _np(v) for k, v in state_dict.items()}
         for k in [k for k in sd if k.endswith("_scb")]:          # int8 linears: `weight` (int8) + `weight_scb`
@@ -294,7 +301,7 @@ class LMOracle:
         off = self.tr_offset
         exec_rows = self._model_rows(self.exec_mask)
         for l, L in enumerate(self.layers):
-            qkv = linear(rms_norm(x, L["n1"]), L["in_proj"]).reshape(B, 3, H, Dh)
+            qkv = linear(rms_norm(x, L["n1"]), L["in_proj"], self.acc64).reshape(B, 3, H, Dh)
             q, k = rope_1(qkv[:, 0], qkv[:, 1], off, c.max_period)
             v = qkv[:, 2]
             cache = self.kv[l]
@@ -321,10 +328,10 @@ class LMOracle:
                 p = p / p.sum(-1, keepdims=True, dtype=f32)
                 att[b] = np.einsum("hn,hnd->hd", p, cache[1, b][:, ok]).astype(f32)
             att = bf16r(att.reshape(B, H * Dh))
-            x = bf16r(x + linear(att, L["out_proj"]))
-            x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"], L["w_out"]))
+            x = bf16r(x + linear(att, L["out_proj"], self.acc64))
+            x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"], L["w_out"], self.acc64))
         tout = rms_norm(x, self.out_norm)
-        return tout, linear(tout, self.text_linear)
+        return tout, linear(tout, self.text_linear, self.acc64)
 
     # ---- depformer (lm.py:450-493, 809-850) ------------------------------------------------------------
     def depformer_step(self, text_token, tout, use_sampling, temp, top_k, noise, forced):
@@ -336,9 +343,9 @@ class LMOracle:
         vals: List[List[np.ndarray]] = [[] for _ in self.dep_layers]
         tokens, logits_all = [], []
         for k in range(c.dep_q):
-            x = bf16r(linear(tout, self.dep_in[k]) + self._embed(self.dep_emb[k], prev))
+            x = bf16r(linear(tout, self.dep_in[k], self.acc64) + self._embed(self.dep_emb[k], prev))
             for l, L in enumerate(self.dep_layers):
-                qkv = linear(rms_norm(x, L["n1"]), L["in_proj"][k]).reshape(B, 3, Hd, Dhd)
+                qkv = linear(rms_norm(x, L["n1"]), L["in_proj"][k], self.acc64).reshape(B, 3, Hd, Dhd)
                 keys[l].append(qkv[:, 1]); vals[l].append(qkv[:, 2])
                 K = np.stack(keys[l], 2); V = np.stack(vals[l], 2)                       # [B, Hd, k+1, Dhd]
                 s = np.einsum("bhd,bhnd->bhn", qkv[:, 0], K).astype(f32) / f32(math.sqrt(Dhd))
@@ -346,9 +353,9 @@ class LMOracle:
                 p = np.exp(s).astype(f32)
                 p = p / p.sum(-1, keepdims=True, dtype=f32)
                 att = bf16r(np.einsum("bhn,bhnd->bhd", p, V).astype(f32).reshape(B, Hd * Dhd))
-                x = bf16r(x + linear(att, L["out_proj"][k]))
-                x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"][k], L["w_out"][k]))
-            lg = linear(x, self.linears[k])
+                x = bf16r(x + linear(att, L["out_proj"][k], self.acc64))
+                x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"][k], L["w_out"][k], self.acc64))
+            lg = linear(x, self.linears[k], self.acc64)
             if self.cfg_coef != 1.0:
                 lg = self._guide(lg)
             nz = None if noise is None else noise[:, 1 + k]

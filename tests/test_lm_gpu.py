@@ -190,6 +190,16 @@ def test_two_batch_tiles_at_full_width_match_oracle(gpu_lib, B):
     lm_cases.oracle_vs_engine(DEV, None, cfg, seed=300 + B, B=B, S=2, use_masks=True)
 
 
+@pytest.mark.parametrize("B", [18, 40])
+def test_lds_resident_gemm_is_the_default_at_full_width(gpu_lib, B):
+    """The default path of the wide temporal GEMMs at 17..64 sessions: k_gemm_xlds with the staggered tail (activations staged in
+    LDS, one workgroup per CU walking 1-3 n-tiles, each tile's epilogue under the last chunk's weight stream), one and two
+    batch tiles, against the oracle - and the engine reports that it took that kernel."""
+    st = {}
+    lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=15, B=B, S=2, use_masks=False, stats=st)
+    assert st["xlds_launches"] >= 2 * 2 + 1
+
+
 def test_ring_wraps_at_the_real_capacity(gpu_lib):
     lm_cases.ring_wrap_at_real_capacity(DEV, None)
 
@@ -226,26 +236,4 @@ def test_batch_rows_independent_and_graph_equals_eager(gpu_lib, monkeypatch):
 
 
 def test_rng_sampling_statistics(gpu_lib):
-    """On-device RNG path (no supplied noise): token frequencies follow softmax(logits/temp) restricted to the top-k
-    (the reference's own self-test is a frequency check too, sampling.py:109-127)."""
-    cfg = tiny_lm_config()
-    sd = random_lm_state_dict(cfg, seed=5)
-    B = 64
-    lm = LMModel(sd, cfg, device=DEV, max_batch=B)
-    gen = LMGen(lm, use_sampling=True, temp=1.0, temp_text=1.0, top_k=8, top_k_text=8, support_out_of_sync=True, seed=123)
-    codes = torch.zeros(B, 8, 1, dtype=torch.long, device=DEV)
-    counts = np.zeros(cfg.text_card)
-    with gen.streaming(B):
-        for it in range(40):
-            gen.reset_streaming()                      # every step is the first step: identical logits for all rows
-            out, tl, al = gen.step_with_taps(codes)
-            gen.set_exec_mask(torch.ones(B, dtype=torch.bool, device=DEV))
-            o2, _, _ = gen.step_with_taps(codes)       # the text token of step 0 is emitted at step 1 (delay ring)
-            for t in o2[:, 0, 0].cpu().numpy():
-                counts[t] += 1
-    p = torch.softmax(tl[0].double(), -1).cpu().numpy()
-    top = np.argsort(-p)[:8]
-    expect = np.zeros_like(p); expect[top] = p[top] / p[top].sum()
-    freq = counts / counts.sum()
-    assert counts.sum() == 40 * B and counts[[i for i in range(len(p)) if i not in top]].sum() == 0
-    assert np.abs(freq - expect).max() < 0.04
+    lm_cases.rng_sampling_statistics(DEV, None)

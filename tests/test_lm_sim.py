@@ -269,3 +269,8 @@ def test_full_depth_checker_plumbing_on_the_tiny_model(sim_lib):
     from dataclasses import replace
     log = lm_cases.full_depth_vs_oracle("cpu", sim_lib, B=3, S=2, seed=9, name="plumbing", cfg=replace(tiny_lm_config(), context=100))
     assert set(log.summary()) == {"text"} | {f"audio{k}" for k in range(tiny_lm_config().dep_q)}
+
+
+def test_rng_sampling_statistics(sim_lib):
+    """The sampler's production form (on-device RNG, no rank computation) on the simulator: a coarser frequency check."""
+    lm_cases.rng_sampling_statistics("cpu", sim_lib, iters=12, tol=0.07)
