@@ -250,6 +250,27 @@ int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* 
                 float* opt_text_logits, float* opt_audio_logits, const float* opt_noise, int32_t batch,
                 int32_t* valid, mmi_stream stream);
 
+/* LMGen's per-step hooks (lm.py:568-570, 734-747): host callbacks between the stages of a step, each of which may READ and
+ * MODIFY IN PLACE what the reference's hook receives (the TTS wrapper forces text tokens this way, models/tts.py):
+ *   on_text_logits   after the (guided) text logits are final, before the text token is sampled      (lm.py:734-735)
+ *   on_text_token    after the text token is sampled, before the depth transformer reads it          (lm.py:746-747)
+ *   on_audio_tokens  after the dep_q audio tokens are sampled (or replaced), before they enter the ring (lm.py:756-757)
+ * With any hook set, mmi_lm_step launches the step in segments (no graph replay) on `stream` and calls the hooks on the
+ * calling thread, without synchronising: a hook works on the same stream through mmi_lm_hook_io.  A non-zero return aborts the
+ * step with MMI_ERR_INVALID.  Pass NULL to clear. */
+typedef struct mmi_lm_hooks {
+    int (*on_text_logits)(void* user);
+    int (*on_text_token)(void* user);
+    int (*on_audio_tokens)(void* user);
+    void* user;
+} mmi_lm_hooks;
+int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks_or_null);
+/* Inside a hook: copy one of the step's tensors out (write = 0) or back in (write = 1), stream-ordered on `stream`:
+ *   which 0  text logits   bf16 [batch, text_card_out]   (the model dtype, as the reference's hook sees them)
+ *   which 1  text token    i64  [batch]
+ *   which 2  audio tokens  i64  [batch, dep_q] */
+int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, mmi_stream stream);
+
 /* Teacher forcing for the NEXT step only: tokens i64 [batch, 1 + dep_q] (text, then the dep_q audio codebooks);
  * entries >= 0 replace the sampled token at that site (the logits taps are still produced), entries < 0 keep
  * sampling.  Covers LMGen.step's `depformer_replace_tokens` argument (lm.py:751-755) and lets the parity tests

@@ -59,6 +59,13 @@ class Guidance(C.Structure):
                 ("condition_sum", C.c_void_p)]
 
 
+HOOK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class LMHooks(C.Structure):
+    _fields_ = [("on_text_logits", HOOK_FN), ("on_text_token", HOOK_FN), ("on_audio_tokens", HOOK_FN), ("user", C.c_void_p)]
+
+
 class BatcherCfg(C.Structure):
     _fields_ = [("slots", C.c_int32), ("reset_codec_after_first_frame", C.c_int32), ("max_buffered_frames", C.c_int32),
                 ("sampling", Sampling), ("guidance", Guidance)]
@@ -107,6 +114,8 @@ SIGNATURES = {
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),
     "mmi_lm_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     "mmi_lm_force_next_tokens": (C.c_int, [_P, _P, _P]),
+    "mmi_lm_set_hooks": (C.c_int, [_P, C.POINTER(LMHooks)]),
+    "mmi_lm_hook_io": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "mmi_mimi_get_cfg": (C.c_int, [_P, C.POINTER(MimiCfg)]),
     "mmi_lm_get_cfg": (C.c_int, [_P, C.POINTER(LMCfg)]),
     "mmi_batcher_create": (C.c_int, [_P, _P, C.POINTER(BatcherCfg), C.POINTER(_P)]),

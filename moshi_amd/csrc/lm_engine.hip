@@ -91,6 +91,11 @@ struct mmi_lm {
     int* use_forced = nullptr;
     bool forced_armed = false;
     unsigned long long* rng = nullptr;
+    // per-step host hooks (mmi_lm_set_hooks): the step is cut at these ops of the launch list
+    mmi_lm_hooks hooks{nullptr, nullptr, nullptr, nullptr};
+    bool in_hook = false;
+    size_t op_text_sample = 0, op_after_text_sample = 0, op_commit = 0;
+    SampleArgs text_sample_args;    // to rebuild the depth transformer's first input when a hook changed the text token
     long offset_cpu = 0;
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
     bool dominant_xlds = false;     // the profiled (dominant) GEMM ran on k_gemm_xlds
@@ -494,6 +499,11 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
     sa.B = lm->gen_batch;
     sa.forced = lm->forced + site; sa.forced_stride = 1 + lm->cfg.dep_q; sa.use_forced = lm->use_forced;
     const int B = lm->gen_batch;
+    if (text) {                     // hook boundaries: the guided logits are final here, the sampler is the next op
+        lm->op_text_sample = lm->prog.ops.size();
+        lm->op_after_text_sample = lm->op_text_sample + 1;
+        lm->text_sample_args = sa;
+    }
     lm->prog.add([=](hipStream_t s) {
         if (V <= 2048) MMI_LAUNCH((k_sample<256, 8, true>), B, 256, 0, s, sa);
         else if (V <= 8192) MMI_LAUNCH((k_sample<1024, 8, true>), B, 1024, 0, s, sa);
@@ -636,8 +646,10 @@ int build_program(mmi_lm* lm) {
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
             P.site("dep.attn");
+            const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8 && !getenv("MMI_DEP_ATTN_OLD");
             P.add([=](hipStream_t s) {
-                MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
+                if (attn8) MMI_LAUNCH((k_dep_attn8<4>), mmi_cdiv(B * Hd, 4), 256, 0, s, da);
+                else MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
@@ -656,6 +668,7 @@ int build_program(mmi_lm* lm) {
     }
     // ---- token ring out
     P.site("commit");
+    lm->op_commit = P.ops.size();
     {
         TokArgs t = tok_args(lm);
         const int *tt = lm->text_tok, *at = lm->audio_tok; int* out = lm->out_i32; unsigned long long* rng = lm->rng;
@@ -684,6 +697,34 @@ int check_cfg(const mmi_lm_cfg& c) {
     if (c.dim % 8 || c.depformer_dim % 8 || c.ffn_hidden % 8 || c.depformer_ffn_hidden % 8)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "feature sizes must be multiples of 8");
     return MMI_OK;
+}
+
+// LMGen's per-step hooks (lm.py:734-757): the launch list cut at the text sampler and at the ring commit, run eagerly, with
+// the host callbacks in between.  Nothing synchronises: the hooks enqueue their copies / kernels on the same stream.
+int run_step_with_hooks(mmi_lm* lm, hipStream_t s) {
+    MmiProgram& P = lm->prog;
+    auto call = [&](int (*fn)(void*)) -> int {
+        if (!fn) return MMI_OK;
+        lm->in_hook = true;
+        const int r = fn(lm->hooks.user);
+        lm->in_hook = false;
+        return r ? mmi_fail(MMI_ERR_INVALID, "a step hook reported an error") : MMI_OK;
+    };
+    int rc = P.run_range(s, 0, lm->op_text_sample);
+    if (rc || (rc = call(lm->hooks.on_text_logits))) return rc;
+    if ((rc = P.run_range(s, lm->op_text_sample, lm->op_after_text_sample))) return rc;
+    if (lm->hooks.on_text_token) {
+        if ((rc = call(lm->hooks.on_text_token))) return rc;
+        // the sampler also wrote the depth transformer's first input row from ITS token (fused, lm.py:465-470): redo that
+        // row from the token the hook left behind
+        if (lm->text_sample_args.nx_out) {
+            MMI_LAUNCH(k_dep_next_input, lm->gen_batch, 128, 0, s, lm->text_sample_args, (const int*)lm->text_tok);
+            MMI_CHECK_LAUNCH();
+        }
+    }
+    if ((rc = P.run_range(s, lm->op_after_text_sample, lm->op_commit))) return rc;
+    if (lm->cfg.dep_q > 0 && (rc = call(lm->hooks.on_audio_tokens))) return rc;      // no depformer, no audio tokens (lm.py:748-749)
+    return P.run_range(s, lm->op_commit, P.ops.size());
 }
 
 }  // namespace
@@ -989,7 +1030,10 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
         MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
     }
     MMI_CHECK_LAUNCH();
-    int rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
+    int rc;
+    const bool hooked = lm->hooks.on_text_logits || lm->hooks.on_text_token || lm->hooks.on_audio_tokens;
+    if (hooked) rc = run_step_with_hooks(lm, s);
+    else rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
     if (rc) return rc;
     MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(B * (c.dep_q + 1), 256), 256, 0, s, (const int*)lm->out_i32, (long*)out_tokens, B * (c.dep_q + 1));
     if (opt_text_logits)
@@ -1008,6 +1052,37 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     }
     lm->offset_cpu += 1;
     if (valid) *valid = lm->offset_cpu > lm->max_delay ? 1 : 0;   // lm.py:774-776
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (hooks) lm->hooks = *hooks;
+    else lm->hooks = mmi_lm_hooks{nullptr, nullptr, nullptr, nullptr};
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !buf) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming || !lm->in_hook) return mmi_fail(MMI_ERR_STATE, "mmi_lm_hook_io is only valid inside a step hook");
+    hipStream_t s = (hipStream_t)stream;
+    const mmi_lm_cfg& c = lm->cfg;
+    const int G = lm->gen_batch;
+    if (which == 0) {            // (guided) text logits, rows [0, G) of the model's logits buffer
+        const size_t n = (size_t)G * c.text_card_out * sizeof(uint16_t);
+        if (write) MMI_HIP_CHECK(hipMemcpyAsync(lm->text_logits, buf, n, hipMemcpyDeviceToDevice, s));
+        else MMI_HIP_CHECK(hipMemcpyAsync(buf, lm->text_logits, n, hipMemcpyDeviceToDevice, s));
+        return MMI_OK;
+    }
+    int* tok = which == 1 ? lm->text_tok : (which == 2 ? lm->audio_tok : nullptr);
+    if (!tok) return mmi_fail(MMI_ERR_INVALID, "mmi_lm_hook_io: which must be 0, 1 or 2");
+    const int cols = which == 1 ? 1 : c.dep_q;
+    if (cols == 0) return MMI_OK;
+    if (write) MMI_LAUNCH(k_i64_to_i32, mmi_cdiv(G * cols, 256), 256, 0, s, (const long*)buf, (long)cols, tok, G, cols);
+    else MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(G * cols, 256), 256, 0, s, (const int*)tok, (long*)buf, G * cols);
+    MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
 

@@ -1153,6 +1153,64 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
     if (on) a.out[mmi_xp_index(a.T, b, h * Dh + lane, a.out_ksteps)] = mmi_f32_to_bf16(o / den);
 }
 
+// The same attention for Dh a multiple of 8 (<= 64) and <= 8 positions per frame - Moshi's depth transformer - with far fewer
+// dependent instructions: one wave per (session, head), lane (j, c) = position j x 16-byte chunk c of the head: it loads its
+// chunk of q, of key row j and of value row j once (the newest row straight from the in_proj output, which the lanes of
+// position k also copy into the frame's cache), reduces the score over the 8 chunk lanes, the softmax and P.V over the 8
+// position groups (3 butterfly steps each), and the lanes of position 0 store 8 output features as one 16-byte vector.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int bh = (int)blockIdx.x * NW + wave;
+    if (bh >= a.B * a.H) return;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int Dh = a.Dh, HD = a.H * Dh, NC = Dh >> 3;
+    const int j = lane >> 3, c = lane & 7;
+    const int jc = j < a.k ? j : a.k, cc = c < NC ? c : 0;          // clamped: every lane loads from a valid address
+    const uint16_t* row = a.qkv + (long)b * 3 * HD + h * Dh + 8 * cc;
+    uint16_t* kcb = a.kc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
+    uint16_t* vcb = a.vc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
+    const bool newest = jc == a.k;
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(row);
+    const u32x4 kv = *reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh);
+    if (j == a.k && c < NC) {                                       // this frame's cache, position k (transformer.py:243-253)
+        *reinterpret_cast<u32x4*>(kcb + (long)a.k * Dh) = kv;
+        *reinterpret_cast<u32x4*>(vcb + (long)a.k * Dh) = vv;
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        d += __builtin_bit_cast(float, qv[e] << 16) * __builtin_bit_cast(float, kv[e] << 16);
+        d += __builtin_bit_cast(float, qv[e] & 0xffff0000u) * __builtin_bit_cast(float, kv[e] & 0xffff0000u);
+    }
+    if (c >= NC) d = 0.f;
+    d += mmi_shfl_xor(d, 1); d += mmi_shfl_xor(d, 2); d += mmi_shfl_xor(d, 4);
+    const bool live = j <= a.k;
+    const float sc = live ? d * (1.0f / sqrtf((float)Dh)) : -INFINITY;
+    float mx = sc;
+    mx = fmaxf(mx, mmi_shfl_xor(mx, 8)); mx = fmaxf(mx, mmi_shfl_xor(mx, 16)); mx = fmaxf(mx, mmi_shfl_xor(mx, 32));
+    const float p = live ? expf(sc - mx) : 0.f;
+    float den = p;
+    den += mmi_shfl_xor(den, 8); den += mmi_shfl_xor(den, 16); den += mmi_shfl_xor(den, 32);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[2 * e] = p * __builtin_bit_cast(float, vv[e] << 16);
+        o[2 * e + 1] = p * __builtin_bit_cast(float, vv[e] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += mmi_shfl_xor(o[e], 8); o[e] += mmi_shfl_xor(o[e], 16); o[e] += mmi_shfl_xor(o[e], 32);
+    }
+    if (j == 0 && c < NC) {
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
+        *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sampling (sampling.py:86-106): softmax(logits/temp) -> top-k -> argmax(p / Exp(1)); greedy when disabled
 // ------------------------------------------------------------------------------------------------
@@ -1201,6 +1259,11 @@ __device__ __forceinline__ void mmi_sample_next_input(const SampleArgs& a, int b
         }
         *reinterpret_cast<u32x4*>(a.nx_out + mmi_xp_index(a.nx_T, b, n0, a.nx_ksteps)) = ov;
     }
+}
+
+// the depth transformer's first input row rebuilt from tok[b] (a step hook changed the text token after the sampler ran)
+__global__ void k_dep_next_input(SampleArgs a, const int* __restrict__ tok) {
+    mmi_sample_next_input(a, (int)blockIdx.x, tok[(long)blockIdx.x * a.out_stride]);
 }
 
 __device__ __forceinline__ int mmi_apply_forced(const SampleArgs& a, int b, int tok) {

@@ -39,6 +39,13 @@ struct MmiProgram {
         return rc;
     }
 
+    // ops [i0, i1) launched eagerly (the step cut into segments around per-step host callbacks)
+    int run_range(hipStream_t s, size_t i0, size_t i1) {
+        int rc = MMI_OK;
+        for (size_t i = i0; i < i1 && i < ops.size() && !rc; ++i) rc = ops[i](s);
+        return rc;
+    }
+
     int run(hipStream_t s, bool use_graph, hipStream_t capture_stream) {
         if (!use_graph) return run_eager(s);
         if (!exec) {

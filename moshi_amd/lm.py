@@ -196,8 +196,9 @@ class LMModel:
 
 class LMGen:
     """Streaming generation (reference: lm.py:556-850), including classifier-free guidance (`cfg_coef`,
-    `cfg_is_masked_until`, `cfg_is_no_text`) and `sum` condition tensors through `lm_model.fuser`.  Per-step Python hooks
-    and cross-attention conditioning are rejected loudly rather than silently ignored."""
+    `cfg_is_masked_until`, `cfg_is_no_text`), `sum` condition tensors through `lm_model.fuser` and the per-step hooks
+    `on_text_logits_hook` / `on_text_hook` / `on_audio_hook` (the step then runs in segments with the callbacks in between,
+    mmi_lm_set_hooks).  Cross-attention conditioning is rejected loudly rather than silently ignored."""
 
     def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
                  top_k: int = 250, top_k_text: int = 25, cfg_coef: float = 1.0, check: bool = False,
@@ -212,8 +213,12 @@ class LMGen:
         self.condition_tensors = condition_tensors
         self.cfg_is_masked_until = cfg_is_masked_until
         self.cfg_is_no_text = cfg_is_no_text
-        if on_text_hook or on_text_logits_hook or on_audio_hook:
-            raise NotImplementedError("per-step hooks are not supported by the fused step (use step_with_taps)")
+        # per-step hooks (lm.py:568-570, 734-757): each may modify its tensor in place, like the reference's
+        self.on_text_hook = on_text_hook
+        self.on_text_logits_hook = on_text_logits_hook
+        self.on_audio_hook = on_audio_hook
+        self._hooks_keep = None
+        self._hook_error = None
         self.lm_model = lm_model
         self.use_sampling = use_sampling
         self.temp = temp
@@ -280,10 +285,51 @@ class LMGen:
         self._lib.check(self._lib.mmi_lm_streaming_start_guided(lm._handle, int(batch_size), C.byref(s), C.byref(g), self._stream()))
         del keep
         self._batch = int(batch_size)
+        self._install_hooks()
+
+    def _install_hooks(self) -> None:
+        """The reference calls `on_text_logits_hook(text_logits [B,1,1,card])`, `on_text_hook(text_token [B])` and
+        `on_audio_hook(audio_tokens [B,dep_q])` between the stages of a step and lets them write in place (lm.py:734-757).
+        Here each is a C callback of the segmented step: tensor out (mmi_lm_hook_io), Python hook, tensor back in - all
+        stream-ordered, nothing synchronises."""
+        lib, h = self._lib, self.lm_model._handle
+        if not (self.on_text_logits_hook or self.on_text_hook or self.on_audio_hook):
+            lib.check(lib.mmi_lm_set_hooks(h, None))
+            self._hooks_keep = None
+            return
+        cfg, B = self.lm_model.config, self._batch
+
+        def wrap(which, hook, make, view):
+            if hook is None:
+                return _capi.HOOK_FN()                      # NULL function pointer
+
+            def cb(_user):
+                try:
+                    t = make()
+                    lib.check(lib.mmi_lm_hook_io(h, which, 0, t.data_ptr(), self._stream()))
+                    hook(view(t))
+                    lib.check(lib.mmi_lm_hook_io(h, which, 1, t.data_ptr(), self._stream()))
+                    return 0
+                except BaseException as e:                  # never unwind through the C frames: report after the step
+                    self._hook_error = e
+                    return 1
+            return _capi.HOOK_FN(cb)
+        dev = self.device
+        hooks = _capi.LMHooks()
+        hooks.on_text_logits = wrap(0, self.on_text_logits_hook,
+                                    lambda: torch.empty(B, cfg.text_card, device=dev, dtype=torch.bfloat16),
+                                    lambda t: t.view(B, 1, 1, cfg.text_card))
+        hooks.on_text_token = wrap(1, self.on_text_hook, lambda: torch.empty(B, device=dev, dtype=torch.int64), lambda t: t)
+        hooks.on_audio_tokens = wrap(2, self.on_audio_hook, lambda: torch.empty(B, cfg.dep_q, device=dev, dtype=torch.int64),
+                                     lambda t: t)
+        self._hooks_keep = hooks                            # the callbacks must outlive the stream
+        lib.check(lib.mmi_lm_set_hooks(h, C.byref(hooks)))
 
     def _stop_streaming(self) -> None:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+        self._lib.mmi_lm_set_hooks(self.lm_model._handle, None)
+        self._hooks_keep = None
         self._lib.check(self._lib.mmi_lm_streaming_stop(self.lm_model._handle))
         self._batch = None
 
@@ -368,8 +414,13 @@ class LMGen:
             f = forced.to(device=self.device, dtype=torch.int64).contiguous().view(B, 1 + cfg.dep_q)
             self._lib.check(self._lib.mmi_lm_force_next_tokens(self.lm_model._handle, f.data_ptr(), self._stream()))
         valid = C.c_int32(0)
-        self._lib.check(self._lib.mmi_lm_step(self.lm_model._handle, codes.data_ptr(), Ki, out.data_ptr(), tlp, alp, npz, B,
-                                              C.byref(valid), self._stream()))
+        self._hook_error = None
+        rc = self._lib.mmi_lm_step(self.lm_model._handle, codes.data_ptr(), Ki, out.data_ptr(), tlp, alp, npz, B,
+                                   C.byref(valid), self._stream())
+        if rc and self._hook_error is not None:             # a Python hook raised: surface ITS exception
+            err, self._hook_error = self._hook_error, None
+            raise err
+        self._lib.check(rc)
         if not self.support_out_of_sync and not valid.value:
             return None, tl, al
         return out, tl, al

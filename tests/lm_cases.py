@@ -337,6 +337,58 @@ def ring_wrap_at_real_capacity(device, lib, B=2, S=14, seed=91):
     log.dump("ring_wrap_3000")
 
 
+def check_step_hooks(device, lib):
+    """LMGen(on_text_logits_hook, on_text_hook, on_audio_hook) (lm.py:568-570, 734-757): the hooks receive the reference's
+    tensors ([B,1,1,card] bf16 logits, [B] text tokens, [B,dep_q] audio tokens) and what they write in place is what the step
+    goes on with.  A hooked run - logits hook leaving row 1 one finite entry, text hook overwriting row 0's token, audio hook
+    overwriting the last codebook - must produce exactly the ring outputs of an un-hooked run that is teacher-forced with
+    those tokens (the forced text token reaches the depth transformer in both), and the logits hook must see the un-hooked
+    run's logits."""
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=21)
+    B, S = 2, 5
+    rng = np.random.default_rng(5)
+    codes = [torch.from_numpy(rng.integers(0, cfg.card, (B, 8, 1))).to(device) for _ in range(S)]
+    seen = {"logits": [], "text": [], "audio": []}
+
+    def on_logits(lg):
+        assert lg.shape == (B, 1, 1, cfg.text_card) and lg.dtype == torch.bfloat16
+        seen["logits"].append(lg.float().cpu().clone())
+        lg[1, 0, 0, :] = -float("inf")
+        lg[1, 0, 0, 7] = 0.0                      # row 1 can only pick token 7
+
+    def on_text(tok):
+        assert tok.shape == (B,) and tok.dtype == torch.int64
+        seen["text"].append(tok.cpu().clone())
+        tok[0] = 5                                # row 0's text token is overwritten after sampling
+
+    def on_audio(tok):
+        assert tok.shape == (B, cfg.dep_q) and tok.dtype == torch.int64
+        seen["audio"].append(tok.cpu().clone())
+        tok[:, cfg.dep_q - 1] = 3                 # the last codebook is overwritten before it enters the ring
+
+    lm = LMModel(sd, cfg, device=device, max_batch=B, lib=lib)
+    hooked = LMGen(lm, use_sampling=False, support_out_of_sync=True, on_text_logits_hook=on_logits, on_text_hook=on_text,
+                   on_audio_hook=on_audio)
+    outs_h = []
+    with hooked.streaming(B):
+        for s in range(S):
+            outs_h.append(hooked.step(codes[s]).cpu().numpy())
+    plain = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    forced = torch.full((B, 1 + cfg.dep_q), -1, dtype=torch.long)
+    forced[0, 0], forced[1, 0], forced[:, cfg.dep_q] = 5, 7, 3
+    with plain.streaming(B):
+        for s in range(S):
+            out, tl, al = plain.step_with_taps(codes[s], forced_tokens=forced.to(device))
+            assert np.array_equal(out.cpu().numpy(), outs_h[s]), f"step {s}: hooked run differs from the teacher-forced run"
+            assert torch.equal(seen["logits"][s][:, 0, 0], tl.cpu()), f"step {s}: the logits hook saw other logits"
+            assert int(seen["text"][s][1]) == 7                                   # the logits hook steered row 1's sampler
+            assert int(seen["text"][s][0]) == int(tl[0].argmax())                 # row 0: the model's own greedy token
+            for k in range(cfg.dep_q - 1):
+                assert int(seen["audio"][s][0, k]) == int(al[0, k].argmax()) and int(seen["audio"][s][1, k]) == int(al[1, k].argmax())
+    assert len(seen["logits"]) == len(seen["text"]) == len(seen["audio"]) == S
+
+
 def rng_sampling_statistics(device, lib, iters=40, tol=0.04):
     """On-device RNG path (no supplied noise; the sampler's production form: top-k by radix select, then the largest
     logit / temp - log(Exp(1)) of the set): token frequencies follow softmax(logits / temp) restricted to the top-k - the

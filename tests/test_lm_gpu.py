@@ -200,6 +200,10 @@ def test_lds_resident_gemm_is_the_default_at_full_width(gpu_lib, B):
     assert st["xlds_launches"] >= 2 * 2 + 1
 
 
+def test_step_hooks_see_and_modify_the_step_like_the_reference(gpu_lib):
+    lm_cases.check_step_hooks(DEV, None)
+
+
 def test_ring_wraps_at_the_real_capacity(gpu_lib):
     lm_cases.ring_wrap_at_real_capacity(DEV, None)
 

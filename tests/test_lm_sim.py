@@ -274,3 +274,20 @@ def test_full_depth_checker_plumbing_on_the_tiny_model(sim_lib):
 def test_rng_sampling_statistics(sim_lib):
     """The sampler's production form (on-device RNG, no rank computation) on the simulator: a coarser frequency check."""
     lm_cases.rng_sampling_statistics("cpu", sim_lib, iters=12, tol=0.07)
+
+
+def test_step_hooks_see_and_modify_the_step_like_the_reference(sim_lib):
+    lm_cases.check_step_hooks("cpu", sim_lib)
+
+
+def test_a_raising_hook_surfaces_its_exception(sim_lib):
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=22)
+    lm = lm_cases.LMModel(sd, cfg, device="cpu", max_batch=1, lib=sim_lib)
+
+    def bad(_):
+        raise ValueError("boom")
+    gen = lm_cases.LMGen(lm, use_sampling=False, on_text_hook=bad)
+    with gen.streaming(1):
+        with pytest.raises(ValueError, match="boom"):
+            gen.step(torch.zeros(1, 8, 1, dtype=torch.long))
