@@ -174,6 +174,8 @@ typedef struct mmi_lm_cfg {
     int32_t extra_heads_dim;          /* 6 */
     int32_t kv_cache_dtype;           /* 0 / MMI_BF16: the reference's bf16 ring (transformer.py:453-455); MMI_F8E4M3: e4m3 ring -
                                          half the attention stream and half the per-session state (SURVEY.md 8d C5 "fp8 KV") */
+    int32_t cross_attention;          /* 1: every temporal layer has a cross-attention block (`cross_attention.{in,out}_projs.0`,
+                                         `norm_cross.{weight,bias}`; transformer.py:727-732, 779-786) fed by mmi_guidance.condition_cross */
 } mmi_lm_cfg;
 
 /* LMGen constructor arguments that change what step computes (lm.py:557-574). */
@@ -207,12 +209,18 @@ int mmi_lm_streaming_start(mmi_lm* lm, int32_t batch, const mmi_sampling* sampli
  *   cfg_is_no_text       the unconditioned row never reads text tokens and the text logits stay unguided (lm.py:724-732)
  *   condition_sum        device bf16 [model rows, dim] or NULL: ConditionFuser.get_sum of the condition tensors, added to the
  *                        input embeddings of every step (lm.py:621-628, 399-400); model rows = batch, or 2 * batch when guided
- *                        (conditioned rows first).  Cross-attention conditioning is not implemented. */
+ *                        (conditioned rows first).
+ *   condition_cross      device bf16 [model rows, cross_len, dim] or NULL: ConditionFuser.get_cross of the condition tensors
+ *                        (conditioners/base.py:392-409), the source of every temporal layer's cross-attention block; required
+ *                        when the model was created with cfg.cross_attention.  Its keys / values are projected once, here
+ *                        (the reference caches them on the first step, transformer.py:521-531). */
 typedef struct mmi_guidance {
     float cfg_coef;
     int32_t cfg_is_no_text;
     const int64_t* cfg_is_masked_until;
     const void* condition_sum;
+    const void* condition_cross;
+    int32_t cross_len;
 } mmi_guidance;
 int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide_or_null,
                                   mmi_stream stream);

@@ -46,7 +46,8 @@ class LMCfg(C.Structure):
                 ("depformer_dim", C.c_int32), ("depformer_num_heads", C.c_int32),
                 ("depformer_num_layers", C.c_int32), ("depformer_ffn_hidden", C.c_int32),
                 ("delays", C.c_int32 * 64), ("existing_text_padding_id", C.c_int32),
-                ("extra_heads_num_heads", C.c_int32), ("extra_heads_dim", C.c_int32), ("kv_cache_dtype", C.c_int32)]
+                ("extra_heads_num_heads", C.c_int32), ("extra_heads_dim", C.c_int32), ("kv_cache_dtype", C.c_int32),
+                ("cross_attention", C.c_int32)]
 
 
 class Sampling(C.Structure):
@@ -56,7 +57,7 @@ class Sampling(C.Structure):
 
 class Guidance(C.Structure):
     _fields_ = [("cfg_coef", C.c_float), ("cfg_is_no_text", C.c_int32), ("cfg_is_masked_until", C.c_void_p),
-                ("condition_sum", C.c_void_p)]
+                ("condition_sum", C.c_void_p), ("condition_cross", C.c_void_p), ("cross_len", C.c_int32)]
 
 
 HOOK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)

@@ -62,6 +62,14 @@ class SessionBatcher:
                 cs = cs.to(device=lm_model.device, dtype=torch.bfloat16).contiguous().view(rows, lm_model.dim)
                 keep.append(cs)
                 cfg.guidance.condition_sum = cs.data_ptr()
+            cx = lm_model.fuser.get_cross(condition_tensors)
+            if cx is not None:
+                import torch
+                assert cx.shape[0] == rows, "one condition row per model row (2 per slot when guided)"
+                cx = cx.to(device=lm_model.device, dtype=torch.bfloat16).contiguous()
+                keep.append(cx)
+                cfg.guidance.condition_cross = cx.data_ptr()
+                cfg.guidance.cross_len = int(cx.shape[1])
         assert mimi.device == lm_model.device, "the codec and the LM of a batcher must live on the same GPU"
         self._handle = C.c_void_p()
         mimi._sync()

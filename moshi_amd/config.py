@@ -112,6 +112,7 @@ class LMConfig:
     extra_heads_num_heads: int = 0      # lm.py:101-102: linear heads on the transformer output (step_with_extra_heads)
     extra_heads_dim: int = 6
     kv_cache_dtype: str = "bf16"        # "fp8": e4m3 ring for the temporal transformer's keys / values (engine option)
+    cross_attention: bool = False       # every temporal layer attends to the fuser's `cross` condition (transformer.py:727-731, 779-786)
 
     @staticmethod
     def _gating_hidden(dim: int, dim_feedforward: int) -> int:
@@ -152,6 +153,7 @@ class LMConfig:
             "depformer_weights_per_step": True, "delays": list(self.delays),
             **({"extra_heads_num_heads": self.extra_heads_num_heads, "extra_heads_dim": self.extra_heads_dim}
                if self.extra_heads_num_heads else {}),
+            **({"cross_attention": True} if self.cross_attention else {}),
         }
 
 

@@ -166,7 +166,7 @@ int create_impl(mmi_batcher* b) {
     // streaming_forever(batch) on both models (server.py:59-60)
     if ((rc = mmi_mimi_streaming_start(b->mimi, B, b->stream))) return rc;
     b->models_streaming = true;
-    const mmi_guidance* guide = (b->cfg.guidance.cfg_coef != 0.f && b->cfg.guidance.cfg_coef != 1.f) || b->cfg.guidance.condition_sum
+    const mmi_guidance* guide = (b->cfg.guidance.cfg_coef != 0.f && b->cfg.guidance.cfg_coef != 1.f) || b->cfg.guidance.condition_sum || b->cfg.guidance.condition_cross
                                     ? &b->cfg.guidance : nullptr;
     if (guide && guide->cfg_coef == 0.f) b->cfg.guidance.cfg_coef = 1.f;    // condition only
     if ((rc = mmi_lm_streaming_start_guided(b->lm, B, &b->cfg.sampling, guide, b->stream))) return rc;

@@ -21,6 +21,10 @@ struct GemmW {              // one packed nn.Linear
 struct LayerW {
     GemmW in_proj, out_proj, ffn_in, ffn_out;
     uint16_t *n1 = nullptr, *n2 = nullptr;
+    // cross-attention block (cfg.cross_attention; transformer.py:727-732): `cross_attention.in_projs.0` packed whole, with two
+    // views of it - the query rows [0, dim) and the key / value rows [dim, 3 dim) - `out_projs.0`, and `norm_cross`
+    GemmW x_in, x_q, x_kv, x_out;
+    uint16_t *nx_w = nullptr, *nx_b = nullptr;
 };
 
 struct DepLayerW {
@@ -62,6 +66,8 @@ struct mmi_lm {
     int cfg_no_text = 0;
     int* masked_until = nullptr;    // [gen_batch] or null
     uint16_t* cond = nullptr;       // [batch][dim] summed `sum` conditions (lm.py:621-628) or null
+    uint16_t* xkv = nullptr;        // [layers][batch * cross_len][2 * dim] keys | values of the cross-attention source
+    int cross_len = 0;
     long* offsets_m = nullptr;      // [batch] offsets per model row (== offsets without guidance)
     std::vector<uint16_t*> extra_heads;   // nn.Linear(dim, extra_heads_dim) weights, row-major
     uint16_t* extra_heads_all = nullptr;
@@ -612,6 +618,36 @@ int build_program(mmi_lm* lm) {
         });
         P.site("L.out_proj");
         pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
+        if (c.cross_attention) {   // x = x + cross_attention(norm_cross(x), src, src) (transformer.py:779-786)
+            P.site("L.norm_cross");
+            {
+                const int T = lm->T, ksteps = packed_ksteps(lm, d), Pn = pending;
+                uint16_t *x = lm->x, *y = lm->xn; const float* partial = lm->partial;
+                const uint16_t *w = L.nx_w, *bb = L.nx_b;
+                P.add([=](hipStream_t s) {
+                    int nth = mmi_cdiv(d / 8, 64) * 64;
+                    if (nth > 1024) nth = 1024;
+                    MMI_LAUNCH(k_resid_layernorm, B, nth, 0, s, x, partial, Pn, B, w, bb, y, d, T, ksteps, 1e-5f);
+                    MMI_CHECK_LAUNCH();
+                    return (int)MMI_OK;
+                });
+            }
+            P.site("L.cross_q");
+            add_gemm(lm, L.x_q, lm->xn, lm->qrot, d, false, MMI_EPI_STORE, nullptr);
+            P.site("L.cross_attn");
+            {
+                CrossAttnArgs ca;
+                ca.q = lm->qrot; ca.kv = lm->xkv + (size_t)l * B * lm->cross_len * 2 * d; ca.out = lm->att;
+                ca.B = B; ca.H = H; ca.Dh = Dh; ca.Tc = lm->cross_len; ca.T = lm->T; ca.out_ksteps = packed_ksteps(lm, d);
+                P.add([=](hipStream_t s) {
+                    MMI_LAUNCH(k_lm_cross_attn, B * H, 64, 0, s, ca);
+                    MMI_CHECK_LAUNCH();
+                    return (int)MMI_OK;
+                });
+            }
+            P.site("L.cross_out");
+            pending = add_gemm_resid(lm, L.x_out, lm->att, lm->x, d);
+        }
         P.site("L.norm2");
         add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d);
         P.site("L.ffn_in");
@@ -678,6 +714,33 @@ int build_program(mmi_lm* lm) {
             return (int)MMI_OK;
         });
     }
+    return MMI_OK;
+}
+
+// keys | values of the cross-attention source for every temporal layer (transformer.py:495-505: `linear(src, in_proj.weight[dim:])`,
+// bf16), once per stream: the source's rows*T_c positions go through the weight-streaming GEMM as batches of T "sessions"
+int project_cross_source(mmi_lm* lm, const uint16_t* src, hipStream_t s) {
+    const mmi_lm_cfg& c = lm->cfg;
+    const int d = c.dim, T = lm->T, ncol = lm->batch * lm->cross_len, ksteps = packed_ksteps(lm, d);
+    uint16_t* xp = lm->xn;                                        // packed scratch of >= one batch tile
+    for (int col0 = 0; col0 < ncol; col0 += T) {
+        const int n = ncol - col0 < T ? ncol - col0 : T;
+        MMI_HIP_CHECK(hipMemsetAsync(xp, 0, (size_t)ksteps * 512 * sizeof(uint16_t), s));
+        MMI_LAUNCH(k_pack_rows, mmi_cdiv(n * d, 256), 256, 0, s, src + (size_t)col0 * d, n, d, xp, T, ksteps);
+        MMI_CHECK_LAUNCH();
+        for (int l = 0; l < c.num_layers; ++l) {
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = reinterpret_cast<const u32x4*>(xp);
+            a.out = lm->xkv + ((size_t)l * ncol + col0) * 2 * d;
+            a.epi = MMI_EPI_STORE; a.B = n; a.out_mode = MMI_OUT_ROWMAJOR; a.out_ld = 2 * d; a.out_ksteps = ksteps;
+            a.tok_rows = n;
+            int rc = launch_gemm(lm, s, lm->layers[l].x_kv, a, false);
+            if (rc) return rc;
+        }
+    }
+    // the packed scratch goes back to all-zero padding (the step's producers only write the live rows)
+    MMI_HIP_CHECK(hipMemsetAsync(xp, 0, packed_elems(lm, d) * sizeof(uint16_t), s));
     return MMI_OK;
 }
 
@@ -780,6 +843,19 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
         if ((rc = load_linear(lm, W, p + ".gating.linear_out.weight", d, c.ffn_hidden, 0, &L.ffn_out))) return fail(rc);
         if ((rc = load_copy(lm, W, p + ".norm1.alpha", 3, d, &L.n1))) return fail(rc);
         if ((rc = load_copy(lm, W, p + ".norm2.alpha", 3, d, &L.n2))) return fail(rc);
+        if (c.cross_attention) {
+            if (d % lm->T) return fail(mmi_fail(MMI_ERR_UNSUPPORTED, "cross-attention needs dim to be a multiple of the GEMM tile"));
+            if ((rc = load_linear(lm, W, p + ".cross_attention.in_projs.0.weight", 3 * d, d, 0, &L.x_in))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".cross_attention.out_projs.0.weight", d, d, 0, &L.x_out))) return fail(rc);
+            if (L.x_in.wq) return fail(mmi_fail(MMI_ERR_UNSUPPORTED, "cross-attention layers with quantised linears are not supported"));
+            if ((rc = load_copy(lm, W, p + ".norm_cross.weight", 1, d, &L.nx_w))) return fail(rc);
+            if ((rc = load_copy(lm, W, p + ".norm_cross.bias", 1, d, &L.nx_b))) return fail(rc);
+            const int ntq = d / lm->T;                               // n-tiles of the query rows; the rest are keys | values
+            L.x_q = L.x_in;  L.x_q.N = d;      L.x_q.NT = ntq;
+            L.x_kv = L.x_in; L.x_kv.N = 2 * d; L.x_kv.NT = 2 * ntq;
+            L.x_kv.wp = L.x_in.wp + (size_t)ntq * L.x_in.KSTEPS * 64;
+            L.x_q.bytes = L.x_in.bytes / 3; L.x_kv.bytes = L.x_in.bytes - L.x_q.bytes;
+        }
     }
     if ((rc = load_copy(lm, W, "out_norm.alpha", 3, d, &lm->out_norm))) return fail(rc);
     if ((rc = load_linear(lm, W, "text_linear.weight", c.text_card_out, d, 0, &lm->text_linear))) return fail(rc);
@@ -907,6 +983,16 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     if (guided) ok &= hipSuccess == A.alloc(&lm->offsets_m, (size_t)B);
     if (guided && guide->cfg_is_masked_until) ok &= hipSuccess == A.alloc(&lm->masked_until, (size_t)G);
     if (guide && guide->condition_sum) ok &= hipSuccess == A.alloc(&lm->cond, (size_t)B * d);
+    lm->xkv = nullptr;
+    lm->cross_len = 0;
+    if (c.cross_attention) {
+        if (!guide || !guide->condition_cross || guide->cross_len <= 0)
+            return fail(mmi_fail(MMI_ERR_INVALID, "the model has cross-attention layers: mmi_guidance.condition_cross is required"));   // transformer.py:793-795
+        lm->cross_len = guide->cross_len;
+        ok &= hipSuccess == A.alloc(&lm->xkv, (size_t)c.num_layers * B * lm->cross_len * 2 * d);
+    } else if (guide && guide->condition_cross) {
+        return fail(mmi_fail(MMI_ERR_INVALID, "a cross-attention condition was given to a model without cross-attention layers"));
+    }
     ok &= hipSuccess == A.alloc(&lm->cache, (size_t)G * lm->NC * lm->CT);
     ok &= hipSuccess == A.alloc(&lm->user_i32, (size_t)G * (c.n_q - c.dep_q));
     ok &= hipSuccess == A.alloc(&lm->tokens, (size_t)B * lm->NC);
@@ -968,7 +1054,9 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     unsigned long long r0[2] = {sampling->seed, 0ull};
     MMI_HIP_CHECK(hipMemcpyAsync(lm->rng, r0, sizeof(r0), hipMemcpyHostToDevice, s));
     MMI_CHECK_LAUNCH();
-    int rc = build_program(lm);
+    int rc = 0;
+    if (lm->xkv && (rc = project_cross_source(lm, reinterpret_cast<const uint16_t*>(guide->condition_cross), s))) return fail(rc);
+    rc = build_program(lm);
     if (rc) return fail(rc);
     MMI_HIP_CHECK(hipStreamSynchronize(s));
     lm->streaming = true;

@@ -865,6 +865,162 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
     }
 }
 
+// The cross-attention block's norm (transformer.py:731-732, 779-783: `norm_cross` is always an nn.LayerNorm with weight and
+// bias, eps 1e-5): same row handling as k_resid_rmsnorm - first fold the P pending split-K partials of the preceding out_proj
+// into the residual stream - then y = ((x - mean) * rsqrt(var + eps) * w + b).to(bf16), statistics in fp32 over the D features.
+__global__ __launch_bounds__(1024) void k_resid_layernorm(uint16_t* __restrict__ x, const float* __restrict__ partial, int P,
+                                                          int B, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
+                                                          uint16_t* __restrict__ y, int D, int T, int ksteps, float eps) {
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    float f[MMI_NORM_MAXP][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        const long at = mmi_xp_index(T, b, i, ksteps);
+        u32x4 v = *reinterpret_cast<const u32x4*>(x + at);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f[j][2 * q] = mmi_bf16_to_f32((uint16_t)(v[q] & 0xffffu));
+            f[j][2 * q + 1] = mmi_bf16_to_f32((uint16_t)(v[q] >> 16));
+        }
+        if (P > 0) {
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float* pp = partial + ((long)p * B + b) * D + i;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u[e] += lo[e]; u[4 + e] += hi[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[j][e] = mmi_round_bf16(mmi_round_bf16(u[e]) + f[j][e]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = mmi_pack_bf16x2(f[j][2 * q], f[j][2 * q + 1]);
+            *reinterpret_cast<u32x4*>(x + at) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += f[j][e];
+    }
+    MMI_SHARED float red[2][16];
+    const int nw = (nth + 63) / 64;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s1 += mmi_shfl_xor(s1, m);
+    if ((tid & 63) == 0) red[0][tid >> 6] = s1;
+    __syncthreads();
+    float tot = 0.f;
+    for (int wv = 0; wv < nw; ++wv) tot += red[0][wv];
+    const float mean = tot / (float)D;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dlt = f[j][e] - mean; s2 += dlt * dlt; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s2 += mmi_shfl_xor(s2, m);
+    if ((tid & 63) == 0) red[1][tid >> 6] = s2;
+    __syncthreads();
+    float var = 0.f;
+    for (int wv = 0; wv < nw; ++wv) var += red[1][wv];
+    const float rstd = mmi_rsqrtf(var / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i), bv = *reinterpret_cast<const u32x4*>(bias + i);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float wl = mmi_bf16_to_f32((uint16_t)(wv[q] & 0xffffu)), wh = mmi_bf16_to_f32((uint16_t)(wv[q] >> 16));
+            const float bl = mmi_bf16_to_f32((uint16_t)(bv[q] & 0xffffu)), bh = mmi_bf16_to_f32((uint16_t)(bv[q] >> 16));
+            o[q] = mmi_pack_bf16x2((f[j][2 * q] - mean) * rstd * wl + bl, (f[j][2 * q + 1] - mean) * rstd * wh + bh);
+        }
+        *reinterpret_cast<u32x4*>(y + mmi_xp_index(T, b, i, ksteps)) = o;
+    }
+}
+
+// rows of a row-major bf16 matrix [n][D] -> packed activation operand (columns col0 .. col0 + n of the source become the
+// GEMM's batch rows 0 .. n): used once per stream to run the cross-attention source through the key / value projection
+__global__ void k_pack_rows(const uint16_t* __restrict__ src, int n, int D, uint16_t* __restrict__ xp, int T, int ksteps) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= n * D) return;
+    const int r = idx / D, k = idx - r * D;
+    xp[mmi_xp_index(T, r, k, ksteps)] = src[idx];
+}
+
+// Cross-attention of the one new query per (model row, head) over the T_c projected condition positions (transformer.py:
+// 544-552, 584: no mask, no rope, keys / values fixed for the stream).  kv: [rows][T_c][2 * H * Dh] bf16 (keys, then values, as
+// the in_proj's rows dim.. produce them); q: [rows][H * Dh] bf16.  One wave per (row, head); lane (r, c) = position slot r x
+// 16-byte chunk c of the head; online softmax per slot, slots merged at the end.
+struct CrossAttnArgs {
+    const uint16_t* q;
+    const uint16_t* kv;
+    uint16_t* out;          // packed (T, out_ksteps) operand of the cross out_proj, feature = h*Dh + d
+    int B, H, Dh, Tc;
+    int T, out_ksteps;
+};
+
+__global__ __launch_bounds__(64) void k_lm_cross_attn(CrossAttnArgs a) {
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int lane = (int)threadIdx.x;
+    const int Dh = a.Dh, HD = a.H * Dh, NC = Dh >> 3;          // NC in {1, 2, 4, 8, 16}
+    const int RP = 64 / NC;                                     // position slots per pass
+    const int r = lane / NC, c = lane - r * NC;
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (long)b * HD + h * Dh + 8 * c);
+    float qf[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qf[2 * e] = __builtin_bit_cast(float, qv[e] << 16); qf[2 * e + 1] = __builtin_bit_cast(float, qv[e] & 0xffff0000u); }
+    const float scale = 1.0f / sqrtf((float)Dh);
+    float m_run = -INFINITY, l_run = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int t0 = 0; t0 < a.Tc; t0 += RP) {
+        const int t = t0 + r;
+        const bool live = t < a.Tc;
+        const uint16_t* row = a.kv + ((long)b * a.Tc + (live ? t : a.Tc - 1)) * 2 * HD + h * Dh + 8 * c;
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(row), vv = *reinterpret_cast<const u32x4*>(row + HD);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d += qf[2 * e] * __builtin_bit_cast(float, kv[e] << 16);
+            d += qf[2 * e + 1] * __builtin_bit_cast(float, kv[e] & 0xffff0000u);
+        }
+        for (int m = 1; m < NC; m <<= 1) d += mmi_shfl_xor(d, m);
+        const float sc = live ? d * scale : -INFINITY;
+        const float m_new = fmaxf(m_run, sc);
+        const float resc = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+        const float p = live ? expf(sc - m_new) : 0.f;
+        l_run = l_run * resc + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] = acc[2 * e] * resc + p * __builtin_bit_cast(float, vv[e] << 16);
+            acc[2 * e + 1] = acc[2 * e + 1] * resc + p * __builtin_bit_cast(float, vv[e] & 0xffff0000u);
+        }
+        m_run = m_new;
+    }
+    // merge the RP slots (lanes that share c): butterflies over the slot bits
+    for (int m = NC; m < 64; m <<= 1) {
+        const float mo = mmi_shfl_xor(m_run, m), lo = mmi_shfl_xor(l_run, m);
+        const float mn = fmaxf(m_run, mo);
+        const float sa = m_run == -INFINITY ? 0.f : expf(m_run - mn), sb = mo == -INFINITY ? 0.f : expf(mo - mn);
+        l_run = l_run * sa + lo * sb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * sa + mmi_shfl_xor(acc[e], m) * sb;
+        m_run = mn;
+    }
+    if (r == 0) {
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(acc[2 * e] / l_run, acc[2 * e + 1] / l_run);
+        *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // input embedding sum (lm.py:388-397): ((emb0[t1] + emb1[t2]) + ...) + text_emb[t0], each add rounded to bf16
 // ------------------------------------------------------------------------------------------------

@@ -42,20 +42,25 @@ def _lm_cfg_struct(cfg: LMConfig) -> _capi.LMCfg:
     if cfg.kv_cache_dtype not in ("bf16", "fp8"):
         raise ValueError("kv_cache_dtype must be 'bf16' or 'fp8'")
     s.kv_cache_dtype = _capi.MMI_F8E4M3 if cfg.kv_cache_dtype == "fp8" else _capi.MMI_BF16
+    s.cross_attention = 1 if cfg.cross_attention else 0
     return s
 
 
 class ConditionFuser:
     """The part of the reference's `ConditionFuser` that `LMGen` uses (conditioners/base.py:349-421): which named condition
-    tensors are summed into the model input.  Cross-attention conditioning is not implemented by the engine."""
+    tensors are summed into the model input (`sum`) and which are concatenated along time into the source every temporal
+    layer cross-attends to (`cross`).  `prepend` is not implemented by the reference's generation path either."""
 
-    def __init__(self, fuse2cond: Dict[str, List[str]]):
+    def __init__(self, fuse2cond: Dict[str, List[str]], cross_attention_pos_emb: bool = False,
+                 cross_attention_pos_emb_scale: float = 1.0):
         for method, names in fuse2cond.items():
             if method not in ("sum", "cross", "prepend"):
                 raise AssertionError(f"Got invalid fuse method {method}")
-            if method != "sum" and names:
-                raise RuntimeError(f"only `sum` conditioning is supported by the engine, got {method}.")
-        self.fuse2cond = {"sum": list(fuse2cond.get("sum", [])), "cross": [], "prepend": []}
+            if method == "prepend" and names:
+                raise RuntimeError(f"only `sum` and `cross` conditionings are supported for now, got {method}.")   # base.py:380-381
+        self.fuse2cond = {"sum": list(fuse2cond.get("sum", [])), "cross": list(fuse2cond.get("cross", [])), "prepend": []}
+        self.cross_attention_pos_emb = cross_attention_pos_emb
+        self.cross_attention_pos_emb_scale = cross_attention_pos_emb_scale
 
     def get_sum(self, conditions) -> Optional[torch.Tensor]:
         """conditioners/base.py:410-421: conditions[name] = (tensor [B, 1, dim], mask)."""
@@ -66,8 +71,21 @@ class ConditionFuser:
             total = cond if total is None else total + cond
         return total
 
-    def get_cross(self, conditions):
-        return None
+    def get_cross(self, conditions) -> Optional[torch.Tensor]:
+        """conditioners/base.py:392-409: the `cross` conditions concatenated along time, [B, T_c, dim] (+ a sinusoidal
+        position embedding when the fuser was built with `cross_attention_pos_emb`)."""
+        cross = None
+        for name in self.fuse2cond["cross"]:
+            cond = conditions[name][0]
+            cross = cond if cross is None else torch.cat([cross, cond], dim=1)
+        if self.cross_attention_pos_emb and cross is not None:
+            positions = torch.arange(cross.shape[1], device=cross.device).view(1, -1, 1)
+            half = cross.shape[-1] // 2                     # modules/transformer.py:139-164 create_sin_embedding
+            adim = torch.arange(half, device=cross.device, dtype=torch.float32).view(1, 1, -1)
+            phase = positions.to(torch.float32) / (torch.full([], 10000.0, device=cross.device) ** (adim / (half - 1)))
+            pos_emb = torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1).to(cross.dtype)
+            cross = cross + self.cross_attention_pos_emb_scale * pos_emb
+        return cross
 
 
 class LMModel:
@@ -198,7 +216,7 @@ class LMGen:
     """Streaming generation (reference: lm.py:556-850), including classifier-free guidance (`cfg_coef`,
     `cfg_is_masked_until`, `cfg_is_no_text`), `sum` condition tensors through `lm_model.fuser` and the per-step hooks
     `on_text_logits_hook` / `on_text_hook` / `on_audio_hook` (the step then runs in segments with the callbacks in between,
-    mmi_lm_set_hooks).  Cross-attention conditioning is rejected loudly rather than silently ignored."""
+    mmi_lm_set_hooks), and `cross` condition tensors for models built with cross-attention layers."""
 
     def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
                  top_k: int = 250, top_k_text: int = 25, cfg_coef: float = 1.0, check: bool = False,
@@ -275,6 +293,16 @@ class LMGen:
                 cs = cs.to(device=self.device, dtype=torch.bfloat16).contiguous().view(rows, lm.dim)
                 keep.append(cs)
                 g.condition_sum = cs.data_ptr()
+            cx = lm.fuser.get_cross(self.condition_tensors)                     # lm.py:623-627
+            if cx is not None:
+                assert cx.shape[0] == rows, "cfg requires 2x more conditions." if self.cfg_coef != 1. else "one condition row per session"
+                cx = cx.to(device=self.device, dtype=torch.bfloat16).contiguous()
+                assert cx.dim() == 3 and cx.shape[2] == lm.dim, cx.shape
+                keep.append(cx)
+                g.condition_cross = cx.data_ptr()
+                g.cross_len = int(cx.shape[1])
+        if lm.config.cross_attention:
+            assert g.condition_cross, "the model has cross-attention layers: a `cross` condition tensor is required"   # transformer.py:793-795
         if self.cfg_is_masked_until is not None and self.cfg_coef != 1.:
             assert len(self.cfg_is_masked_until) == int(batch_size)
             mu = (C.c_int64 * int(batch_size))(*[int(v) for v in self.cfg_is_masked_until])

@@ -73,7 +73,7 @@ def lm_config_from_kwargs(lm_kwargs: Optional[dict]) -> LMConfig:
     for key, allowed in (("causal", (True,)), ("layer_scale", (None,)), ("gating", ("silu",)), ("norm", ("rms_norm_f32",)),
                          ("positional_embedding", ("rope",)), ("depformer_layer_scale", (None,)), ("depformer_multi_linear", (True,)),
                          ("depformer_gating", ("silu",)), ("depformer_pos_emb", ("none",)), ("depformer_weights_per_step", (True,)),
-                         ("cross_attention", (False,)), ("demux_second_text_stream", (False,)), ("demux_second_stream", (False,)),
+                         ("demux_second_text_stream", (False,)), ("demux_second_stream", (False,)),
                          ("depformer_low_rank_embeddings", (None,)), ("text_card_out", (None, kw.get("text_card")))):
         _require(kw, key, allowed, "Moshi LM")
     if "depformer_context" in kw and kw["depformer_context"] < kw["dep_q"]:
@@ -87,7 +87,7 @@ def lm_config_from_kwargs(lm_kwargs: Optional[dict]) -> LMConfig:
         depformer_dim=kw["depformer_dim"], depformer_dim_feedforward=int(kw["depformer_dim_feedforward"]),
         depformer_num_heads=kw["depformer_num_heads"], depformer_num_layers=kw["depformer_num_layers"],
         delays=list(kw["delays"]), extra_heads_num_heads=kw.get("extra_heads_num_heads", 0),
-        extra_heads_dim=kw.get("extra_heads_dim", 6))
+        extra_heads_dim=kw.get("extra_heads_dim", 6), cross_attention=bool(kw.get("cross_attention", False)))
 
 
 def get_mimi(filename: str | Path | None, mimi_config: dict | None = None, device: torch.device | str = "cuda",
@@ -105,7 +105,9 @@ def get_mimi(filename: str | Path | None, mimi_config: dict | None = None, devic
 
 def get_condition_fuser(cfg: dict) -> ConditionFuser:    # loaders.py:476-483
     fuser_cfg = cfg["fuser"]
-    return ConditionFuser({k: fuser_cfg.get(k, []) for k in ("sum", "cross", "prepend")})
+    return ConditionFuser({k: fuser_cfg.get(k, []) for k in ("sum", "cross", "prepend")},
+                          cross_attention_pos_emb=bool(fuser_cfg.get("cross_attention_pos_emb", False)),
+                          cross_attention_pos_emb_scale=float(fuser_cfg.get("cross_attention_pos_emb_scale", 1.0)))
 
 
 def get_moshi_lm(filename: str | Path | None, lm_kwargs: Optional[Dict[str, Any]] = None, device: torch.device | str = "cuda",

@@ -106,6 +106,11 @@ def lm_state_spec(cfg: LMConfig) -> Spec:
         spec.append((p + ".norm2.alpha", (1, 1, d), "alpha"))
         spec.append((p + ".gating.linear_in.weight", (2 * h, d), f"fan:{d}"))
         spec.append((p + ".gating.linear_out.weight", (d, h), f"fan:{h}"))
+        if cfg.cross_attention:                # transformer.py:727-731: a second MHA + its own nn.LayerNorm (weight and bias)
+            spec.append((p + ".cross_attention.in_projs.0.weight", (3 * d, d), f"fan:{d}"))
+            spec.append((p + ".cross_attention.out_projs.0.weight", (d, d), f"fan:{d}"))
+            spec.append((p + ".norm_cross.weight", (d,), "norm_w"))
+            spec.append((p + ".norm_cross.bias", (d,), "norm_b"))
     for k in range(cfg.dep_q):
         spec.append((f"depformer_in.{k}.weight", (dd, d), f"fan:{d}"))
     for k in range(cfg.dep_q - 1):

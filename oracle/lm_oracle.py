@@ -125,6 +125,15 @@ def rms_norm(x: np.ndarray, alpha: np.ndarray, eps: float = 1e-8) -> np.ndarray:
     return bf16r(x * (alpha.reshape(1, -1) * (f32(1.0) / np.sqrt(var))).astype(f32))
 
 
+def layer_norm(x: np.ndarray, w: np.ndarray, b: np.ndarray, eps: float = 1e-5) -> np.ndarray:
+    """nn.LayerNorm on a bf16 tensor (the layer's `norm_cross`, transformer.py:731-732): statistics and affine in fp32, one
+    rounding to bf16 at the end."""
+    mean = np.mean(x, axis=-1, keepdims=True, dtype=f32)
+    var = np.mean((x - mean) * (x - mean), axis=-1, keepdims=True, dtype=f32)
+    y = (x - mean) * (f32(1.0) / np.sqrt(var + f32(eps))).astype(f32)
+    return bf16r((y * w.reshape(1, -1) + b.reshape(1, -1)).astype(f32))
+
+
 def silu(x: np.ndarray) -> np.ndarray:
     return (x / (f32(1.0) + np.exp(-x))).astype(f32)
 
@@ -206,6 +215,9 @@ class LMOracle:
             self.layers.append(dict(in_proj=sd[p + ".self_attn.in_projs.0.weight"], out_proj=sd[p + ".self_attn.out_projs.0.weight"],
                                     n1=sd[p + ".norm1.alpha"].reshape(-1), n2=sd[p + ".norm2.alpha"].reshape(-1),
                                     w_in=sd[p + ".gating.linear_in.weight"], w_out=sd[p + ".gating.linear_out.weight"]))
+            if getattr(c, "cross_attention", False):             # transformer.py:727-732
+                self.layers[-1].update(x_in=sd[p + ".cross_attention.in_projs.0.weight"], x_out=sd[p + ".cross_attention.out_projs.0.weight"],
+                                       nx_w=sd[p + ".norm_cross.weight"].reshape(-1), nx_b=sd[p + ".norm_cross.bias"].reshape(-1))
         self.dep_in = [sd[f"depformer_in.{k}.weight"] for k in range(c.dep_q)]
         self.dep_emb = ([sd["depformer_text_emb.weight"]] + [sd[f"depformer_emb.{k}.weight"] for k in range(c.dep_q - 1)]) if c.dep_q > 0 else []
         self.dep_layers = []
@@ -225,7 +237,7 @@ class LMOracle:
 
     # ---- streaming state (lm.py:605-666; transformer.py:448-486) -----------------------------------
     def streaming(self, B: int, cfg_coef: float = 1.0, cfg_is_no_text: bool = False, cfg_is_masked_until=None,
-                  condition_sum=None):
+                  condition_sum=None, condition_cross=None):
         """`condition_sum`: the fuser's summed condition [model rows, dim] (lm.py:621-628); with guidance (cfg_coef != 1) the
         model runs 2B rows, conditioned half first (lm.py:646-651)."""
         c = self.cfg
@@ -237,6 +249,19 @@ class LMOracle:
             B = 2 * B
         if self.condition_sum is not None:
             assert self.condition_sum.shape[0] == B, "cfg requires 2x more conditions."
+        # `condition_cross`: the fuser's cross-attention source [model rows, T_c, dim] (lm.py:623-627); every temporal layer
+        # projects it ONCE to keys / values (transformer.py:495-531: cached on the first step), bf16 like any nn.Linear output
+        self.cross_kv = None
+        if getattr(c, "cross_attention", False):
+            assert condition_cross is not None, "the model has cross-attention layers: a `cross` condition is required"
+            src = bf16r(_np(condition_cross))
+            assert src.shape[0] == B and src.shape[2] == c.dim, "cfg requires 2x more conditions."
+            H, Dh = c.num_heads, c.dim // c.num_heads
+            self.cross_kv = []
+            for L in self.layers:
+                w = L["x_in"]
+                kv = linear(src.reshape(-1, c.dim), w[c.dim:], self.acc64).reshape(B, src.shape[1], 2, H, Dh)
+                self.cross_kv.append((kv[:, :, 0].transpose(0, 2, 1, 3), kv[:, :, 1].transpose(0, 2, 1, 3)))   # [B, H, T_c, Dh]
         self._streaming_model(B)
         B = self.gen_B
         self.B = B
@@ -329,6 +354,15 @@ class LMOracle:
                 att[b] = np.einsum("hn,hnd->hd", p, cache[1, b][:, ok]).astype(f32)
             att = bf16r(att.reshape(B, H * Dh))
             x = bf16r(x + linear(att, L["out_proj"], self.acc64))
+            if self.cross_kv is not None:                        # _cross_attention_block (transformer.py:779-786): no mask, no rope
+                kc, vc = self.cross_kv[l]
+                q = linear(layer_norm(x, L["nx_w"], L["nx_b"]), L["x_in"][:c.dim], self.acc64).reshape(B, H, Dh)
+                s = np.einsum("bhd,bhtd->bht", q, kc).astype(f32) / f32(math.sqrt(Dh))
+                s = s - s.max(-1, keepdims=True)
+                p = np.exp(s).astype(f32)
+                p = p / p.sum(-1, keepdims=True, dtype=f32)
+                xa = bf16r(np.einsum("bht,bhtd->bhd", p, vc).astype(f32).reshape(B, H * Dh))
+                x = bf16r(x + linear(xa, L["x_out"], self.acc64))
             x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"], L["w_out"], self.acc64))
         tout = rms_norm(x, self.out_norm)
         return tout, linear(tout, self.text_linear, self.acc64)

@@ -517,6 +517,117 @@ def check_cfg_engine(device, lib, name):
             state["gen"]._stop_streaming()
 
 
+# ---- cross-attention conditioning (second half; tests/golden/lm_cross.npz) -----------------------------------------
+CROSS_SCENARIOS = {
+    "e": dict(cfg_coef=1.0, cross=["cross_e"], sum="sum_e"),
+    "f": dict(cfg_coef=2.0, cross=["cross_f1", "cross_f2"], pos_emb=0.5),
+}
+
+
+def load_cross_golden():
+    from dataclasses import replace
+    g = np.load(GOLDEN / "lm_cross.npz")
+    cfg = replace(tiny_lm_config(), cross_attention=True)
+    return g, cfg, random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+
+
+def cross_condition_tensors(g, name):
+    """The named condition tensors of scenario `name` as the reference's LMGen receives them, and the fuser built for them."""
+    from moshi_amd.lm import ConditionFuser
+    sc = CROSS_SCENARIOS[name]
+    conds, names = {}, []
+    for i, key in enumerate(sc["cross"]):
+        t = torch.from_numpy(g[key]).to(torch.bfloat16)
+        conds[f"x{i}"] = (t, torch.ones(t.shape[:2], dtype=torch.bool))
+        names.append(f"x{i}")
+    sums = []
+    if sc.get("sum"):
+        t = torch.from_numpy(g[sc["sum"]]).to(torch.bfloat16)
+        conds["s"] = (t, torch.ones(t.shape[:2], dtype=torch.bool))
+        sums = ["s"]
+    fuser = ConditionFuser({"sum": sums, "cross": names}, cross_attention_pos_emb="pos_emb" in sc,
+                           cross_attention_pos_emb_scale=sc.get("pos_emb", 1.0))
+    return conds, fuser
+
+
+def check_cross_scenario(g, cfg, name, start, step):
+    """Replays scenario `name` of tests/golden/lm_cross.npz, teacher-forced with the reference's tokens.
+    start(cfg_coef, condition_sum [rows, dim] or None, condition_cross [rows, T_c, dim]); step as in check_cfg_scenario."""
+    sc = CROSS_SCENARIOS[name]
+    S, B = g["masks"].shape
+    wd = GUIDED_WIDEN if sc["cfg_coef"] != 1.0 else 1.0
+    conds, fuser = cross_condition_tensors(g, name)
+    cs, cx = fuser.get_sum(conds), fuser.get_cross(conds)
+    start(cfg_coef=sc["cfg_coef"], condition_sum=None if cs is None else cs[:, 0].float().numpy(), condition_cross=cx.float().numpy())
+    for s in range(S):
+        reset = g["reset_mask"] if s == int(g["reset_step"][0]) else None
+        forced = np.concatenate([g[f"{name}_text_tok"][s][:, None], g[f"{name}_audio_tok"][s]], 1)
+        out, tl, al = step(g["codes"][s], forced, g["masks"][s], reset)
+        for b in range(B):
+            if not g["masks"][s, b]:
+                continue
+            assert np.array_equal(out[b], g[f"{name}_tokens"][s, b]), f"{name} step {s} row {b}: ring output differs"
+            assert logits_close(tl[b], g[f"{name}_text_logits"][s, b], wd), f"{name} step {s} row {b}: text logits"
+            for k in range(cfg.dep_q):
+                assert logits_close(al[b, k], g[f"{name}_audio_logits"][s, b, k], wd), f"{name} step {s} row {b} cb {k}: audio logits"
+
+
+def check_cross_engine(device, lib, name):
+    """The engine's cross-attention path against the reference's run: LMModel(cross_attention) + ConditionFuser(cross) + LMGen."""
+    g, cfg, sd = load_cross_golden()
+    sc = CROSS_SCENARIOS[name]
+    B = g["masks"].shape[1]
+    rows = 2 * B if sc["cfg_coef"] != 1.0 else B
+    conds, fuser = cross_condition_tensors(g, name)
+    lm = LMModel(sd, cfg, device=device, max_batch=rows, lib=lib, fuser=fuser)
+    state = {}
+
+    def start(cfg_coef, condition_sum, condition_cross):
+        gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, cfg_coef=cfg_coef, condition_tensors=conds)
+        gen.streaming_forever(B)
+        state["gen"] = gen
+
+    def step(codes, forced, mask, reset):
+        gen = state["gen"]
+        if reset is not None:
+            gen.reset_streaming(torch.from_numpy(reset).to(device))
+        gen.set_exec_mask(torch.from_numpy(mask).to(device))
+        out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+        return out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+    try:
+        check_cross_scenario(g, cfg, name, start, step)
+    finally:
+        if "gen" in state:
+            state["gen"]._stop_streaming()
+
+
+def cross_vs_oracle(device, lib, cfg, B, S, Tc, seed):
+    """Engine against the oracle on a cross-attention model of any width (the golden covers the tiny one): T_c condition
+    positions, rows at different depths of the ring."""
+    from moshi_amd.lm import ConditionFuser
+    sd = random_lm_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    cx = (0.7 * torch.randn(B, Tc, cfg.dim, generator=g)).to(torch.bfloat16)
+    conds = {"x": (cx, torch.ones(B, Tc, dtype=torch.bool))}
+    lm = LMModel(sd, cfg, device=device, max_batch=B, lib=lib, fuser=ConditionFuser({"sum": [], "cross": ["x"]}))
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, condition_tensors=conds)
+    orc = LMOracle(sd, cfg)
+    orc.streaming(B, condition_cross=cx.float().numpy())
+    rng = np.random.default_rng(seed)
+    with gen.streaming(B):
+        for s in range(S):
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            assert np.array_equal(out, oo), f"step {s}: ring output differs"
+            for b in range(B):
+                assert logits_close(tl[b], otl[b]), f"step {s} row {b}: text logits {np.abs(tl[b]-otl[b]).max()}"
+                for k in range(cfg.dep_q):
+                    assert logits_close(al[b, k], oal[b, k]), f"step {s} row {b} cb {k}"
+
+
 # ---- fp8 on hardware ------------------------------------------------------------------------------------------------------------
 # The gfx950 fp8 dot-product unit sums each group of 8 products with the small ones aligned to the largest (products below
 # ~2^-13 of it are shifted out): scripts/fp8_probe.hip measures up to 2.7e-4 of sum|products| (the conversion v_cvt_pk_fp8_f32 is

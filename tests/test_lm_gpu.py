@@ -241,3 +241,18 @@ def test_batch_rows_independent_and_graph_equals_eager(gpu_lib, monkeypatch):
 
 def test_rng_sampling_statistics(gpu_lib):
     lm_cases.rng_sampling_statistics(DEV, None)
+
+
+@pytest.mark.parametrize("name", ["e", "f"])
+def test_cross_attention_conditioning_matches_reference_golden(gpu_lib, name):
+    """A model with cross-attention layers (transformer.py:727-732, 779-797) fed by ConditionFuser.get_cross (base.py:392-409):
+    `e` cross + sum conditions, `f` guidance with two concatenated cross tensors and the sinusoidal position embedding."""
+    lm_cases.check_cross_engine(DEV, None, name)
+
+
+@pytest.mark.parametrize("B,Tc", [(3, 7), (20, 37)])
+def test_cross_attention_at_full_width_matches_oracle(gpu_lib, B, Tc):
+    """Cross-attention layers at the 7B layer shapes (head dim 128: 16 chunk lanes x 4 position slots per pass; the condition's
+    keys / values projected through the weight-streaming GEMM in batches) against the oracle, both batch tilings."""
+    from dataclasses import replace
+    lm_cases.cross_vs_oracle(DEV, None, replace(LMConfig(num_layers=2, context=64), cross_attention=True), B=B, S=2, Tc=Tc, seed=77 + B)

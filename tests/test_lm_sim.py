@@ -291,3 +291,17 @@ def test_a_raising_hook_surfaces_its_exception(sim_lib):
     with gen.streaming(1):
         with pytest.raises(ValueError, match="boom"):
             gen.step(torch.zeros(1, 8, 1, dtype=torch.long))
+
+
+@pytest.mark.parametrize("name", ["e", "f"])
+def test_cross_attention_conditioning_matches_reference_golden(sim_lib, name):
+    """A model with cross-attention layers (transformer.py:727-732, 779-797) fed by ConditionFuser.get_cross (base.py:392-409):
+    `e` cross + sum conditions, `f` guidance with two concatenated cross tensors and the sinusoidal position embedding."""
+    lm_cases.check_cross_engine("cpu", sim_lib, name)
+
+
+def test_cross_attention_more_positions_than_slots(sim_lib):
+    """T_c larger than the 16 position slots of one pass (head dim 32), 18 sessions (32-row tiles): the online softmax across
+    passes and the batched key / value projection at stream start."""
+    from dataclasses import replace
+    lm_cases.cross_vs_oracle("cpu", sim_lib, replace(tiny_lm_config(), cross_attention=True), B=18, S=2, Tc=41, seed=8)

@@ -124,6 +124,26 @@ def test_lm_oracle_guidance_conditioning_and_extra_heads_match_reference(name):
     lm_cases.check_cfg_scenario(g, cfg, name, lambda **kw: o.streaming(B, **kw), step, o.extra_head_probs)
 
 
+@pytest.mark.parametrize("name", ["e", "f"])
+def test_lm_oracle_cross_attention_conditioning_matches_reference(name):
+    """oracle/lm_oracle.py against the reference's LMGen on a model with cross-attention layers fed by the fuser's `cross`
+    condition (with a `sum` condition; under guidance, two named tensors concatenated, sinusoidal position embedding):
+    tests/golden/lm_cross.npz (make_golden_lm_cross.py)."""
+    from oracle.lm_oracle import LMOracle
+    from tests import lm_cases
+    g, cfg, sd = lm_cases.load_cross_golden()
+    o = LMOracle(sd, cfg)
+    B = g["masks"].shape[1]
+
+    def step(codes, forced, mask, reset):
+        if reset is not None:
+            o.reset_streaming(reset)
+        o.set_exec_mask(mask)
+        out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+        return out, tl, al
+    lm_cases.check_cross_scenario(g, cfg, name, lambda **kw: o.streaming(B, **kw), step)
+
+
 def test_lm_oracle_matches_reference_for_an_asr_style_model():
     """dep_q = 0 (no depformer), text delayed behind 8 input codebooks, two extra heads: tests/golden/lm_stt.npz."""
     from moshi_amd.config import tiny_stt_config
