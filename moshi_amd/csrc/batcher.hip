@@ -139,7 +139,8 @@ int create_impl(mmi_batcher* b) {
     b->NTOK = 1 + lc.dep_q;
     if (b->K < lc.n_q - lc.dep_q)
         return mmi_fail(MMI_ERR_SHAPE, "the codec produces fewer codebooks than the LM expects from the user stream");   // lm.py:683-686
-    if (lc.dep_q > 0 && b->K != lc.dep_q) return mmi_fail(MMI_ERR_SHAPE, "the codec must decode exactly the dep_q codebooks the LM generates");
+    // the encoder produces K = max(dep_q, n_q - dep_q) codebooks (loaders.py:284-291); the decoder takes the dep_q the LM generates
+    if (lc.dep_q > mc.q_n_q) return mmi_fail(MMI_ERR_SHAPE, "the LM generates more codebooks than the codec has");
     if (mc.q_bins != lc.card) return mmi_fail(MMI_ERR_SHAPE, "codec cardinality != LM card");
     const int B = b->B;
     MMI_HIP_CHECK(hipStreamCreate(&b->stream));

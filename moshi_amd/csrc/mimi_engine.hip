@@ -33,6 +33,8 @@ struct Buf {            // activation buffer [B][C][ld]; first H columns = causa
 
 struct mmi_mimi {
     int device = -1;                // HIP device the handle lives on (current at create); see MmiDeviceGuard
+    int* dec_k_dev = nullptr;       // number of codebooks of the current decode call (read by the captured decoder program)
+    int dec_k_host = 0, dec_k_cur = 0;
     mmi_mimi_cfg cfg;
     int max_batch = 0;
     int n_codebooks = 8;
@@ -453,12 +455,14 @@ int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat
 }
 
 // codes_i32 [B][n_q] (first K used) -> latent written to out buffer column out_off
-int add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B) {
+// k_from_device: the streaming decoder's captured program (K of each call comes from m->dec_k_dev); the one-shot programs of
+// decode_latent bake their K in
+int add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B, bool k_from_device = false) {
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins, nq = c.q_n_q, nsem = c.q_n_q_semantic;
-    float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all;
+    float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all; const int* kdev = k_from_device ? m->dec_k_dev : nullptr;
     prog.add([=](hipStream_t s) {
-        MMI_LAUNCH(k_rvq_gather, mmi_cdiv(B * D, 256), 256, 0, s, codes, nq, K, E, bins, D, nsem, q2, B);
+        MMI_LAUNCH(k_rvq_gather, mmi_cdiv(B * D, 256), 256, 0, s, codes, nq, K, E, bins, D, nsem, q2, B, kdev);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -684,7 +688,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     // dequantised latent [B][dim][1]
     if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->dec_codes_lat, s0))) return rc;
     prog.site("dec.dequant");
-    if ((rc = add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B))) return rc;
+    if ((rc = add_dequant_ops(m, prog, m->n_codebooks, m->dec_codes_lat, 0, B, /*k_from_device=*/true))) return rc;
     prog.site("dec.upsample");
     // upsample (depthwise transposed conv) into the decoder transformer buffer = input of decoder conv0
     int T = stride;
@@ -967,14 +971,18 @@ extern "C" int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream s
     int rc = MMI_OK;
     auto fail = [&](int code) { m->streaming = true; mmi_mimi_streaming_stop(m); return code; };
     if (hipSuccess != m->st.alloc(&m->exec, (size_t)batch) || hipSuccess != m->st.alloc(&m->first, (size_t)batch) ||
-        hipSuccess != m->st.alloc(&m->counters, (size_t)2 * batch))
+        hipSuccess != m->st.alloc(&m->counters, (size_t)2 * batch) || hipSuccess != m->st.alloc(&m->dec_k_dev, (size_t)1))
         return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (state)"));
-    MMI_HIP_CHECK(hipMemsetAsync(m->exec, 1, batch, s));
-    MMI_HIP_CHECK(hipMemsetAsync(m->first, 1, batch, s));
-    MMI_HIP_CHECK(hipMemsetAsync(m->counters, 0, (size_t)2 * batch * sizeof(long), s));
+    // every failure from here on goes through fail(): what was allocated / appended so far is released again
+    m->dec_k_host = m->n_codebooks;
+    m->dec_k_cur = m->n_codebooks;
+    if (hipMemsetAsync(m->exec, 1, batch, s) != hipSuccess || hipMemsetAsync(m->first, 1, batch, s) != hipSuccess ||
+        hipMemsetAsync(m->counters, 0, (size_t)2 * batch * sizeof(long), s) != hipSuccess ||
+        hipMemcpyAsync(m->dec_k_dev, &m->dec_k_host, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(mmi_fail(MMI_ERR_HIP, "initialising the streaming state failed"));
     if ((rc = build_encoder(m, batch, s))) return fail(rc);
     if ((rc = build_decoder(m, batch, s))) return fail(rc);
-    MMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "hipStreamSynchronize failed"));
     m->streaming = true;
     return MMI_OK;
 }
@@ -1122,10 +1130,17 @@ extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pc
     int rc = frame_count_ok(m, batch, n_frames);
     if (rc) return rc;
     if (!codes || !pcm) return mmi_fail(MMI_ERR_INVALID, "null argument");
-    if (n_codebooks != m->n_codebooks) return mmi_fail(MMI_ERR_SHAPE, "codes must carry num_codebooks rows");
+    // any 1 <= K <= n_q: "the split RVQ decodes however many codebooks it is given" (compression.py:406-429, vq.py:281-287)
+    if (n_codebooks < 1 || n_codebooks > m->cfg.q_n_q) return mmi_fail(MMI_ERR_SHAPE, "codes must carry between 1 and n_q codebooks");
     hipStream_t s = (hipStream_t)stream;
     const mmi_mimi_cfg& c = m->cfg;
     const int F = c.frame_size;
+    if (n_codebooks != m->dec_k_cur) {                  // the captured program reads K from device memory
+        m->dec_k_host = n_codebooks;
+        MMI_HIP_CHECK(hipMemcpyAsync(m->dec_k_dev, &m->dec_k_host, sizeof(int), hipMemcpyHostToDevice, s));
+        MMI_HIP_CHECK(hipStreamSynchronize(s));         // the host word is reused; K changes at most once per model in practice
+        m->dec_k_cur = n_codebooks;
+    }
     for (int f = 0; f < n_frames; ++f) {
         MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
         MMI_CHECK_LAUNCH();

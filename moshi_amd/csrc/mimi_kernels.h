@@ -1036,10 +1036,14 @@ __global__ __launch_bounds__(256) void k_rvq_select(const double* __restrict__ b
 }
 
 // decode: q[b][0:D] = E_0[c_0]; q[b][D:2D] = ((0 + E_1[c_1]) + E_2[c_2]) + ...   (core_vq.py:521-528)
+// n_codes_dev (optional): the number of codebooks of THIS call, read from device memory so that the captured decoder program
+// serves `decode` calls with any K <= n_q (the split RVQ decodes however many codebooks it is given, vq.py:281-287)
 __global__ void k_rvq_gather(const int* __restrict__ codes, int codes_rstride, int n_codes,
-                             const float* __restrict__ Eall, int bins, int D, int n_sem, float* __restrict__ q, int Bn) {
+                             const float* __restrict__ Eall, int bins, int D, int n_sem, float* __restrict__ q, int Bn,
+                             const int* __restrict__ n_codes_dev) {
     int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (idx >= Bn * D) return;
+    if (n_codes_dev) n_codes = *n_codes_dev;
     int r = idx / D, d = idx % D;
     float first = 0.f, rest = 0.f;
     for (int k = 0; k < n_codes; ++k) {

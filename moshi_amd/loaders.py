@@ -168,7 +168,18 @@ def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8", lm_kwa
     state = _load_state(src, ("fsdp_best_state", "model"))
     # released checkpoints fuse the per-step attention projections (`self_attn.in_proj_weight`): split them first, as the
     # reference's load hook does before `replace_linear_with_qlinear` sees the modules (transformer.py:422-446)
-    state = normalize_lm_state_dict(state, lm_config_from_kwargs(lm_kwargs))
+    cfg = lm_config_from_kwargs(lm_kwargs)
+    if lm_kwargs is None:                               # no config: the fused depformer projections tell the number of steps
+        for key, val in state.items():
+            if key.startswith("depformer.") and key.endswith(".self_attn.in_proj_weight"):
+                dd = val.shape[1]
+                assert val.shape[0] % (3 * dd) == 0, f"{key}: unexpected fused shape {tuple(val.shape)}"
+                mult = val.shape[0] // (3 * dd)
+                if mult != cfg.dep_q:
+                    raise ValueError(f"{src}: the checkpoint fuses {mult} depformer steps but no lm_kwargs were given "
+                                     f"(default dep_q = {cfg.dep_q}): pass the model's lm_kwargs")
+                break
+    state = normalize_lm_state_dict(state, cfg)
     if fmt == "int8":
         out = quantize_lm_state_dict(state)
     elif fmt == "fp8":

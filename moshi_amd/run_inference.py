@@ -67,6 +67,13 @@ class InferenceState:
         """in_pcms float [B, channels, T] -> per item (text tokens [n], pcm [channels, n * frame_size]).  `max_steps` bounds the
         Hibiki wait-for-EOS loop (not in the reference, which trusts the model to emit EOS)."""
         B, lm = self.batch_size, self.lm_gen.lm_model
+        if self.model_type == "stt":
+            # the text stream runs `audio_delay_seconds` behind the audio: pad the input so that the last words still come out
+            # (run_inference.py:121-127: left = audio_silence_prefix_seconds, right = audio_delay_seconds + 1 s, at 24 kHz)
+            stt = getattr(self.checkpoint_info, "stt_config", None) or {}
+            pad_left = int(stt.get("audio_silence_prefix_seconds", 0.0) * 24000)
+            pad_right = int((stt.get("audio_delay_seconds", 0.0) + 1.0) * 24000)
+            in_pcms = torch.nn.functional.pad(in_pcms, (pad_left, pad_right), mode="constant")
         texts: List[List[torch.Tensor]] = [[] for _ in range(B)]
         audio: List[List[torch.Tensor]] = [[] for _ in range(B)]
         done = [False] * B

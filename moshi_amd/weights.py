@@ -185,12 +185,21 @@ def normalize_lm_state_dict(sd: Dict[str, torch.Tensor], cfg: LMConfig) -> Dict[
     (modules/transformer.py:422-446; `scripts/import_rust.py:91-101` shows the depformer layout).  Same mapping here, so a
     checkpoint's state dict can be handed to `LMModel` as is.  mult = 1 for the temporal transformer, dep_q for the depformer."""
     out: Dict[str, torch.Tensor] = {}
-    sources = {"in_proj_weight": "in_projs.{i}.weight", "in_proj.weight": "in_projs.{i}.weight", "out_proj.weight": "out_projs.{i}.weight"}
+    sources = {"in_proj_weight": "in_projs.{i}.weight", "in_proj.weight": "in_projs.{i}.weight",
+               "in_proj.lora_A.weight": "in_projs.{i}.lora_A.weight", "in_proj.lora_B.weight": "in_projs.{i}.lora_B.weight",
+               "out_proj.weight": "out_projs.{i}.weight",
+               "out_proj.lora_A.weight": "out_projs.{i}.lora_A.weight", "out_proj.lora_B.weight": "out_projs.{i}.lora_B.weight"}
     for key, val in sd.items():
         hit = None
-        for src, dst in sources.items():
-            if key.endswith(".self_attn." + src):
-                hit = (key[: -len(src)], dst)
+        for suffix in ("", "_scb"):                       # `_scb`: the row scales of a quantised checkpoint travel with their weight
+            for src, dst in sources.items():
+                for attn in (".self_attn.", ".cross_attention."):
+                    if key.endswith(attn + src + suffix):
+                        hit = (key[: -len(src + suffix)], dst + suffix)
+                        break
+                if hit:
+                    break
+            if hit:
                 break
         if hit is None:
             out[key] = val

@@ -89,3 +89,28 @@ def test_properties_mirror_reference(factory):
     assert (m.num_codebooks, m.total_codebooks, m.cardinality) == (4, 5, 48)
     m.set_num_codebooks(2)
     assert m.encode(torch.zeros(1, 1, cfg.frame_size)).shape == (1, 2, 1)
+
+
+def test_decode_takes_any_number_of_codebooks(sim_lib):
+    """`mimi.decode` with fewer codebooks than the encoder produces (the reference's split RVQ decodes however many it is given,
+    compression.py:406-429, vq.py:281-287): models whose LM generates dep_q != n_q - dep_q codebooks need it.  Against the
+    oracle, switching K between calls of one stream."""
+    import numpy as np
+    import torch
+    from moshi_amd import MimiModel, tiny_mimi_config
+    from moshi_amd.weights import random_mimi_state_dict
+    from oracle.mimi_oracle import MimiOracle
+    cfg = tiny_mimi_config()
+    sd = random_mimi_state_dict(cfg, seed=11)
+    m = MimiModel(sd, cfg, device="cpu", max_batch=2, num_codebooks=4, lib=sim_lib)
+    orc = MimiOracle(sd, cfg, num_codebooks=4)
+    rng = np.random.default_rng(2)
+    orc.streaming(2)
+    with m.streaming(2):
+        for K in (4, 2, 3, 4):
+            codes = rng.integers(0, cfg.q_bins, (2, K, 1))
+            got = m.decode(torch.from_numpy(codes)).numpy()
+            want = orc.decode(codes)
+            assert np.abs(got - want).max() < 1e-4, K
+        with pytest.raises(AssertionError):
+            m.decode(torch.zeros(2, cfg.q_n_q + 1, 1, dtype=torch.long))

@@ -111,8 +111,12 @@ def test_asr_style_model_prints_text_only(sim_lib, tmp_path):
     mcfg = replace(tiny_mimi_config(), q_bins=lcfg.card, q_n_q=lcfg.n_q)
     save_file(random_lm_state_dict(lcfg, seed=3), str(tmp_path / "model.safetensors"))
     save_file(random_mimi_state_dict(mcfg, seed=4), str(tmp_path / "mimi.safetensors"))
+    # model_type "stt": the input is padded by `audio_silence_prefix_seconds` on the left and `audio_delay_seconds` + 1 s on the
+    # right (at 24 kHz, run_inference.py:121-127); a negative delay keeps the tiny model's padding to 1 + 2.5 frames
+    F = mcfg.frame_size
     conf = {**lcfg.reference_kwargs(), "moshi_name": "model.safetensors", "mimi_name": "mimi.safetensors", "model_type": "stt",
-            "mimi_config": mcfg.reference_kwargs()}
+            "mimi_config": mcfg.reference_kwargs(),
+            "stt_config": {"audio_silence_prefix_seconds": F / 24000.0, "audio_delay_seconds": 2.5 * F / 24000.0 - 1.0}}
     (tmp_path / "config.json").write_text(json.dumps(conf))
     info = loaders.CheckpointInfo.from_local(tmp_path)
     mimi = info.get_mimi("cpu", max_batch=1, lib=sim_lib)
@@ -124,5 +128,6 @@ def test_asr_style_model_prints_text_only(sim_lib, tmp_path):
     n = 6
     pcm = torch.from_numpy((0.3 * np.random.default_rng(2).standard_normal((1, 1, n * mcfg.frame_size))).astype(np.float32))
     (text, audio), = st.run(pcm)
-    assert audio.numel() == 0 and len(text) == n + 1 - lcfg.max_delay      # n frames + the doubled first step - the text delay
+    # 1 (left pad) + n + 2 (whole frames of the 2.5-frame right pad) frames + the doubled first step - the text delay
+    assert audio.numel() == 0 and len(text) == (1 + n + 2) + 1 - lcfg.max_delay
     assert len(said) == sum(int(t) not in (0, 3) for t in text)

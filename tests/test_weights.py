@@ -37,3 +37,23 @@ def test_mimi_legacy_codebook_names():
     assert set(legacy) != set(sd)
     back = normalize_mimi_state_dict(legacy)
     assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+
+
+def test_fused_quantised_and_lora_keys_are_split_with_their_weights():
+    """The reference's load hook also splits the `_scb` row scales of a quantised checkpoint and fused LoRA factors
+    (transformer.py:423-446); so does normalize_lm_state_dict."""
+    import torch
+    from moshi_amd.config import tiny_lm_config
+    cfg = tiny_lm_config()
+    dd, q = cfg.depformer_dim, cfg.dep_q
+    p = "depformer.layers.0.self_attn."
+    sd = {p + "in_proj_weight": torch.zeros(q * 3 * dd, dd, dtype=torch.int8), p + "in_proj_weight_scb": torch.arange(q * 3 * dd, dtype=torch.float32),
+          p + "out_proj.weight": torch.zeros(q * dd, dd, dtype=torch.int8), p + "out_proj.weight_scb": torch.arange(q * dd, dtype=torch.float32),
+          p + "in_proj.lora_A.weight": torch.ones(q * 4, dd), p + "in_proj.lora_B.weight": torch.ones(q * 3 * dd, 4)}
+    out = normalize_lm_state_dict(sd, cfg)
+    for i in range(q):
+        assert out[p + f"in_projs.{i}.weight"].shape == (3 * dd, dd)
+        assert torch.equal(out[p + f"in_projs.{i}.weight_scb"], torch.arange(i * 3 * dd, (i + 1) * 3 * dd, dtype=torch.float32))
+        assert torch.equal(out[p + f"out_projs.{i}.weight_scb"], torch.arange(i * dd, (i + 1) * dd, dtype=torch.float32))
+        assert out[p + f"in_projs.{i}.lora_A.weight"].shape == (4, dd) and out[p + f"in_projs.{i}.lora_B.weight"].shape == (3 * dd, 4)
+    assert not any(k.endswith("in_proj_weight") or k.endswith("in_proj_weight_scb") or ".in_proj.lora" in k for k in out)
