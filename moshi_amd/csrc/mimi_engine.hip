@@ -17,6 +17,7 @@ struct ConvW {          // one conv / linear as an implicit GEMM: rows = Cout, r
 struct TrLayerW {
     ConvW in_proj, out_proj, lin1, lin2;
     float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+    float *n1w_pk = nullptr, *n1b_pk = nullptr, *n2w_pk = nullptr, *n2b_pk = nullptr;   // operand order, for k_gemm_f32_ln
 };
 
 struct Buf {            // activation buffer [B][C][ld]; first H columns = causal history of its consumer
@@ -182,6 +183,14 @@ int load_transformer(mmi_mimi* m, const MmiWeights& W, const std::string& prefix
         if ((rc = load_vec(m, W, p + ".norm2.bias", d, &L.n2b))) return rc;
         if ((rc = load_vec(m, W, p + ".layer_scale_1.scale", d, &L.ls1))) return rc;
         if ((rc = load_vec(m, W, p + ".layer_scale_2.scale", d, &L.ls2))) return rc;
+        if (d % 8 == 0) {               // the norms' weight / bias in the packed operand's element order (k_gemm_f32_ln)
+            struct { const float* src; float** dst; } pk[] = {{L.n1w, &L.n1w_pk}, {L.n1b, &L.n1b_pk}, {L.n2w, &L.n2w_pk}, {L.n2b, &L.n2b_pk}};
+            for (auto& e : pk) {
+                MMI_HIP_CHECK(m->wts.alloc(e.dst, (size_t)d));
+                MMI_LAUNCH(k_pack_ln, mmi_cdiv(d, 256), 256, 0, (hipStream_t)0, e.src, *e.dst, d);
+            }
+            MMI_CHECK_LAUNCH();
+        }
     }
     return MMI_OK;
 }
@@ -240,6 +249,7 @@ int load_rvq(mmi_mimi* m, const MmiWeights& W) {
 //   N = B*T_out > 128 columns : k_conv_wide
 //   N <= 128                  : [k_pack_b_f32] -> k_gemm_f32 [-> k_conv_finish when K is split over workgroups]
 struct ConvPlan {
+    bool ln = false;                  // k_gemm_f32_ln: LayerNorm fused in front of the linear
     bool wide = false;
     int MTB = 1, W = 1, U = 1;        // wide
     int NSUB = 1, waves = 4, ksplit = 1, nz = 1;
@@ -270,6 +280,11 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
             case 2: launch_wide_w<2, 4>(s, a, p.W, grid); break;
             default: launch_wide_w<4, 2>(s, a, p.W, grid); break;
         }
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
+    if (p.ln) {
+        MMI_LAUNCH((k_gemm_f32_ln<8, 8>), dim3(a.Mt, 1, p.nz), 512, 0, s, a);
         MMI_CHECK_LAUNCH();
         return MMI_OK;
     }
@@ -333,6 +348,15 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
     }
     p->wide = false;
     const int nsub = mmi_cdiv(N, 32);
+    if (a.ln_w) {                       // fused LayerNorm + linear: one 32-column subtile per workgroup, the whole K in registers
+        if (!a.x_packed || a.Q > 64 || a.Q * 8 != a.Cin || a.K != 1 || a.out_mode == MMI_GOUT_PARTIAL)
+            return mmi_fail(MMI_ERR_UNSUPPORTED, "fused LayerNorm linear: unsupported shape");
+        p->ln = true;
+        p->NSUB = 1;
+        p->nz = nsub;
+        a.Npad = 32;
+        return MMI_OK;
+    }
     p->NSUB = nsub <= 1 ? 1 : (nsub == 2 ? 2 : 4);
     a.Npad = p->NSUB * 32;
     if (!a.x_packed) {
@@ -510,12 +534,26 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
             return (int)MMI_OK;
         });
     };
+    // LayerNorm fused into the linear that consumes it (k_gemm_f32_ln): the producers of the residual stream inside the
+    // transformer (out_proj, linear2) also store it in packed operand order (xrp); only the very first norm, whose input
+    // comes from the conv stack, stays a launch of its own.  32 -> 2 norm launches per frame for the two transformers.
+    const bool fuse_ln = packed && d % 8 == 0 && Qd <= 64 && layers.size() > 0 && layers[0].n1w_pk && !getenv("MMI_MIMI_NO_LN_FUSION");
+    float* xrp = nullptr;
+    if (fuse_ln) {
+        MMI_HIP_CHECK(m->st.alloc(&xrp, (size_t)nsub * Qd * 256));
+        MMI_HIP_CHECK(hipMemsetAsync(xrp, 0, (size_t)nsub * Qd * 256 * sizeof(float), init_stream));
+    }
+    bool x_is_packed = false;           // xrp holds the current residual stream
     for (size_t l = 0; l < layers.size(); ++l) {
         const TrLayerW& L = layers[l];
         {   // x = x + ls1 * out_proj(attn(norm1(x)))
-            add_norm(L.n1w, L.n1b);
             ConvGemmArgs ai = conv_args(L.in_proj, y, 0, T, qkv, 0, B, false);
-            if (packed) { ai.x_packed = 1; ai.bp = yp; }
+            if (fuse_ln && x_is_packed) {
+                ai.x_packed = 1; ai.bp = xrp; ai.ln_w = L.n1w_pk; ai.ln_b = L.n1b_pk; ai.ln_eps = 1e-5f;
+            } else {
+                add_norm(L.n1w, L.n1b);
+                if (packed) { ai.x_packed = 1; ai.bp = yp; }
+            }
             if ((rc = add_conv(m, prog, ai))) return rc;
             MimiAttnArgs aa;
             aa.qkv = qkv.p; aa.kc = kv + (2 * l) * kv_layer; aa.vc = kv + (2 * l + 1) * kv_layer;
@@ -541,17 +579,24 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
             ConvGemmArgs a = conv_args(L.out_proj, att, 0, T, xb, off, B, false);
             a.res = xb.p; a.res_ld = xb.ld; a.res_off = off; a.scale = L.ls1;
             if (packed) { a.x_packed = 1; a.bp = attp; }
+            if (fuse_ln) { a.outp = xrp; a.outQ = Qd; x_is_packed = true; }      // dual store: [B][C][T] and packed
             if ((rc = add_conv(m, prog, a))) return rc;
         }
         {   // x = x + ls2 * linear2(gelu(linear1(norm2(x))))
-            add_norm(L.n2w, L.n2b);
             ConvGemmArgs a1 = conv_args(L.lin1, y, 0, T, hb, 0, B, false);
             a1.act_out = MMI_ACT_GELU;
-            if (packed) { a1.x_packed = 1; a1.bp = yp; a1.out_mode = MMI_GOUT_PACKED; a1.outp = hbp; a1.outQ = Qff; }
+            if (fuse_ln && x_is_packed) {
+                a1.x_packed = 1; a1.bp = xrp; a1.ln_w = L.n2w_pk; a1.ln_b = L.n2b_pk; a1.ln_eps = 1e-5f;
+                a1.out_mode = MMI_GOUT_PACKED; a1.outp = hbp; a1.outQ = Qff;
+            } else {
+                add_norm(L.n2w, L.n2b);
+                if (packed) { a1.x_packed = 1; a1.bp = yp; a1.out_mode = MMI_GOUT_PACKED; a1.outp = hbp; a1.outQ = Qff; }
+            }
             if ((rc = add_conv(m, prog, a1))) return rc;
             ConvGemmArgs a2 = conv_args(L.lin2, hb, 0, T, xb, off, B, false);
             a2.res = xb.p; a2.res_ld = xb.ld; a2.res_off = off; a2.scale = L.ls2;
             if (packed) { a2.x_packed = 1; a2.bp = hbp; }
+            if (fuse_ln) { a2.outp = xrp; a2.outQ = Qd; x_is_packed = true; }
             if ((rc = add_conv(m, prog, a2))) return rc;
         }
     }

@@ -125,6 +125,12 @@ struct ConvGemmArgs {
     // as applying it at the consumer's load - bit-identical.
     int elu_out;
     float* out2;
+    // k_gemm_f32_ln: nn.LayerNorm over the Cin channels of every column fused in front of the linear (the Mimi transformer's
+    // norm1 -> in_proj and norm2 -> linear1): `bp` then holds the RAW residual stream in packed order, ln_w / ln_b the norm's
+    // weight and bias in the operand's element order (k_pack_ln), ln_eps its epsilon
+    const float* ln_w;
+    const float* ln_b;
+    float ln_eps;
     // --- filled in by the engine's planner
     const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h; 0 past Cin*K (the weights there are 0)
     const float* bp;      // k_gemm_f32: packed activations [ceil(N/32)][Q][64][4]
@@ -182,6 +188,8 @@ __device__ __forceinline__ void mmi_conv_store_n(const ConvGemmArgs& a, const in
             const long at = row[i] * a.out_ld + a.out_off + t[i];
             if (a.out2) { a.out[at] = x; a.out2[at] = mmi_elu(x); }
             else a.out[at] = a.elu_out ? mmi_elu(x) : x;
+            // the residual stream of the Mimi transformers is also kept as the packed operand of the next fused norm + linear
+            if (a.outp && a.out_mode == MMI_GOUT_NATURAL) a.outp[mmi_bp_index(co[i], b[i] * a.T_out + t[i], a.outQ)] = x;
         }
     }
 }
@@ -339,6 +347,62 @@ __global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {
     reinterpret_cast<f32x4*>(bp)[idx] = o;
 }
 
+// split-K reduction over the workgroup's waves (fixed order) + the epilogue of k_gemm_f32 / k_gemm_f32_ln
+template <int NSUB, int WAVES>
+__device__ __forceinline__ void mmi_gemm_f32_finish(const ConvGemmArgs& a, f32x16 (&acc)[NSUB], int mt, int s0, int wave, int lane) {
+    constexpr int NE = NSUB * 16 * 64;
+    MMI_SHARED float red[WAVES * NE];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * NE + (s * 16 + r) * 64 + lane] = acc[s][r];
+    __syncthreads();
+    constexpr int NV = NE / (WAVES * 64);
+    int co[NV], nn[NV];
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (int)threadIdx.x + i * WAVES * 64;
+        const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
+        nn[i] = (s0 + s) * 32 + (le & 31);
+        co[i] = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) x += red[w * NE + e];
+        v[i] = x;
+    }
+    if (a.out_mode == MMI_GOUT_PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a.partial[((long)blockIdx.y * a.Mt * 32 + co[i]) * a.Npad + nn[i]] = v[i];   // padded rows / columns included
+        return;
+    }
+    if (a.out_mode == MMI_GOUT_PACKED) {
+        float bia[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bia[i] = a.bias ? a.bias[co[i] < a.Cout ? co[i] : 0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (nn[i] >= a.Ntot || co[i] >= a.Cout) continue;
+            float x = v[i];
+            if (a.bias) x += bia[i];
+            if (a.act_out == MMI_ACT_GELU) x = mmi_gelu_erf(x);
+            else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
+            a.outp[mmi_bp_index(co[i], nn[i], a.outQ)] = x;
+        }
+        return;
+    }
+    int bb[NV], tt[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ok[i] = nn[i] < a.Ntot && co[i] < a.Cout;
+        const int n3 = ok[i] ? nn[i] : 0;
+        bb[i] = mmi_fast_div(n3, a.T_magic);
+        tt[i] = n3 - bb[i] * a.T_out;
+    }
+    mmi_conv_store_n<NV>(a, co, bb, tt, ok, v);
+}
+
 // grid (Mt, ksplit, n-subtile groups); a workgroup covers NSUB n-subtiles of 32 columns starting at blockIdx.z*NSUB; its
 // WAVES waves split the workgroup's k-quads.  The fp32 MFMA takes 64 cycles, so these GEMMs are matrix-core-latency
 // bound unless they are spread over many waves: small weight matrices give each n-subtile its own workgroup.
@@ -404,57 +468,84 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_f32(ConvGemmArgs a) {
 #undef MMI_F_LOAD
 #undef MMI_F_MMA
 
-    constexpr int NE = NSUB * 16 * 64;
-    MMI_SHARED float red[WAVES * NE];
+    mmi_gemm_f32_finish<NSUB, WAVES>(a, acc, mt, s0, wave, lane);
+}
+
+// LayerNorm fused in front of a Mimi transformer linear (norm1 -> in_proj, norm2 -> linear1; transformer.py:125-126,
+// 752-776): grid (Mt, 1, n-subtiles), one 32-column subtile per workgroup; the 8 waves split the Cin / 8 <= 8 * KQ k-quads and
+// hold their whole slice - raw residual-stream fragments, weight fragments, the norm's weight / bias - in registers (everything
+// in flight at once: these GEMMs are latency bound).  Column statistics: per-wave partial sums of the lane's column, the two
+// lane halves folded by one shuffle, the 8 waves through LDS; mean first, then sum (x - mean)^2 (two-pass, like
+// k_layernorm_ct), y = (x - mean) * rsqrt(var + eps) * w + b, then the MFMAs.  Needs Q * 8 == Cin (no padded channels).
+template <int WAVES, int KQ>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_f32_ln(ConvGemmArgs a) {
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int mt = blockIdx.x, s0 = blockIdx.z;
+    const int qper = (a.Q + WAVES - 1) / WAVES;            // <= KQ (checked by the planner)
+    const int q0 = min(a.Q, wave * qper);
+    const int nq = min(a.Q, q0 + qper) - q0;
+    const int kh = lane >> 5;
+    const int ql = min(q0, a.Q - 1);
+    f32x4 wv[KQ], xv[KQ], gv[KQ], bv[KQ];
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpk) + ((long)mt * a.Q + ql) * 64 + lane;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(a.bp) + ((long)s0 * a.Q + ql) * 64 + lane;
+    const f32x4* gp = reinterpret_cast<const f32x4*>(a.ln_w) + (long)ql * 2 + kh;
+    const f32x4* hp = reinterpret_cast<const f32x4*>(a.ln_b) + (long)ql * 2 + kh;
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s)
+    for (int u = 0; u < KQ; ++u) {                         // unconditional loads from clamped (valid) quads, masked afterwards
+        const int uu = min(u, nq > 0 ? nq - 1 : 0);
+        xv[u] = bp[(long)uu * 64];
+        wv[u] = mmi_load_nt(wp + (long)uu * 64);
+        gv[u] = gp[(long)uu * 2];
+        bv[u] = hp[(long)uu * 2];
+    }
+    MMI_SHARED float stat[2][WAVES][32];
+    float s1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave * NE + (s * 16 + r) * 64 + lane] = acc[s][r];
+    for (int u = 0; u < KQ; ++u)
+        if (u < nq) s1 += (xv[u][0] + xv[u][1]) + (xv[u][2] + xv[u][3]);
+    s1 += mmi_shfl_xor(s1, 32);
+    if (lane < 32) stat[0][wave][lane] = s1;
     __syncthreads();
-    constexpr int NV = NE / (WAVES * 64);
-    int co[NV], nn[NV];
-    float v[NV];
+    float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int e = (int)threadIdx.x + i * WAVES * 64;
-        const int le = e & 63, r = (e >> 6) & 15, s = e >> 10;
-        nn[i] = (s0 + s) * 32 + (le & 31);
-        co[i] = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
-        float x = 0.f;
+    for (int w = 0; w < WAVES; ++w) tot += stat[0][w][lane & 31];
+    const float mean = tot / (float)a.Cin;
+    float s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) x += red[w * NE + e];
-        v[i] = x;
-    }
-    if (a.out_mode == MMI_GOUT_PARTIAL) {
+    for (int u = 0; u < KQ; ++u)
+        if (u < nq) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) a.partial[((long)blockIdx.y * a.Mt * 32 + co[i]) * a.Npad + nn[i]] = v[i];   // padded rows / columns included
-        return;
-    }
-    if (a.out_mode == MMI_GOUT_PACKED) {
-        float bia[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) bia[i] = a.bias ? a.bias[co[i] < a.Cout ? co[i] : 0] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (nn[i] >= a.Ntot || co[i] >= a.Cout) continue;
-            float x = v[i];
-            if (a.bias) x += bia[i];
-            if (a.act_out == MMI_ACT_GELU) x = mmi_gelu_erf(x);
-            else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
-            a.outp[mmi_bp_index(co[i], nn[i], a.outQ)] = x;
+            for (int e = 0; e < 4; ++e) { const float dlt = xv[u][e] - mean; s2 += dlt * dlt; }
         }
-        return;
-    }
-    int bb[NV], tt[NV];
-    bool ok[NV];
+    s2 += mmi_shfl_xor(s2, 32);
+    if (lane < 32) stat[1][wave][lane] = s2;
+    __syncthreads();
+    float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        ok[i] = nn[i] < a.Ntot && co[i] < a.Cout;
-        const int n3 = ok[i] ? nn[i] : 0;
-        bb[i] = mmi_fast_div(n3, a.T_magic);
-        tt[i] = n3 - bb[i] * a.T_out;
-    }
-    mmi_conv_store_n<NV>(a, co, bb, tt, ok, v);
+    for (int w = 0; w < WAVES; ++w) var += stat[1][w][lane & 31];
+    const float rstd = mmi_rsqrtf(var / (float)a.Cin + a.ln_eps);
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KQ; ++u)
+        if (u < nq) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (xv[u][e] - mean) * rstd * gv[u][e] + bv[u][e];
+                acc[0] = mmi_mfma_f32_32x32x2(wv[u][e], y, acc[0]);
+            }
+        }
+    mmi_gemm_f32_finish<1, WAVES>(a, acc, mt, s0, wave, lane);
+}
+
+// LayerNorm weight / bias [C] -> the element order of the packed operand: out[(q * 2 + kh) * 4 + e] = v[(q * 4 + e) * 2 + kh]
+__global__ void k_pack_ln(const float* __restrict__ v, float* __restrict__ out, int C) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= C) return;
+    const int e = i & 3, kh = (i >> 2) & 1, q = i >> 3;
+    out[i] = v[(q * 4 + e) * 2 + kh];
 }
 
 // sum of the split-K partials + epilogue -> [B][Cout][out_ld]
