@@ -113,12 +113,14 @@ def roofline_lm(lm_gen, step_fn, args, sync):
     # process), so the figure is the committed measurement of the same kernel, shape and batch.
     pmc = Path(__file__).resolve().parent / "profiles" / "pmc_dominant_kernel.json"
     if pmc.exists() and lm_gen._batch == 32:
-        rec = json.loads(pmc.read_text())
-        if rec["kernel"] in kname and rec["algorithmic_bytes_per_launch"] == nbytes.value:
-            out["traffic"] = rec["traffic_bytes_per_launch"]
-            out["traffic_source"] = ("profiles/pmc_dominant_kernel.json: a COMMITTED measurement of this kernel, shape and batch (rocprofv3 --pmc "
-                                     "FETCH_SIZE x2 + WRITE_SIZE, separate passes, standalone launcher) - not collected in this run")
-            out["traffic_measured_in_this_run"] = False
+        doc = json.loads(pmc.read_text())
+        for rec in doc.get("kernels", [doc]):
+            if rec["kernel"] in kname and rec["algorithmic_bytes_per_launch"] == nbytes.value:
+                out["traffic"] = rec["traffic_bytes_per_launch"]
+                out["traffic_source"] = ("profiles/pmc_dominant_kernel.json: a COMMITTED measurement of this kernel, shape and batch (rocprofv3 --pmc "
+                                         "FETCH_SIZE x2 + WRITE_SIZE, separate passes, standalone launcher) - not collected in this run")
+                out["traffic_measured_in_this_run"] = False
+                break
     return out
 
 

@@ -1122,19 +1122,17 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     for (int c0 = (int)blockIdx.y * CH; c0 < L; c0 += (int)gridDim.y * CH) {     // block-uniform trip count
         // ---- scores of this chunk: all of the wave's key rows are requested up front (unconditional loads from a clamped
         // slot; a load under `if (valid)` would be serialised behind s_waitcnt vmcnt(0)), then reduced
-        constexpr int NIT = PER_WAVE / RPW;
-        constexpr int NB = NIT < 8 ? NIT : 8;             // rows in flight per lane: 8 x 16 bytes keeps the kernel at <= 96 VGPRs
-#pragma unroll 1
-        for (int h0 = 0; h0 < NIT; h0 += NB) {
-            u32x4 kk[NB];
+        constexpr int NIT = PER_WAVE / RPW;               // rows per lane per chunk (16 at Dh = 128 bf16: 64 VGPRs in flight)
+        {
+            u32x4 kk[NIT];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
+            for (int i = 0; i < NIT; ++i) {
+                const int slot = min(c0 + wave * PER_WAVE + i * RPW + rsub, L - 1);
                 kk[i] = *reinterpret_cast<const u32x4*>(kbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
+            for (int i = 0; i < NIT; ++i) {
+                const int rl = wave * PER_WAVE + i * RPW + rsub;
                 const int slot = c0 + rl;
                 bool valid = slot < L;
                 if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
@@ -1152,6 +1150,14 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
                 for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
                 if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
             }
+        }
+        // the chunk's value rows are requested NOW, before the softmax's barriers: their HBM latency runs under the reductions
+        // (rows past L carry p = 0 and finite ring contents)
+        u32x4 vv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int slot = min(c0 + wave * PER_WAVE + i * RPW + rsub, L - 1);
+            vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
         }
         __syncthreads();
         // ---- online softmax update
@@ -1176,24 +1182,15 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] *= resc;
-        // ---- P.V (value rows requested up front as well; rows past L carry p = 0 and finite ring contents)
-#pragma unroll 1
-        for (int h0 = 0; h0 < NIT; h0 += NB) {
-            u32x4 vv[NB];
+        // ---- P.V
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
-                vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
-            }
+        for (int i = 0; i < NIT; ++i) {
+            const int rl = wave * PER_WAVE + i * RPW + rsub;
+            const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
+            float vf[EPL];
+            widen(vv[i], vf);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
-                const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
-                float vf[EPL];
-                widen(vv[i], vf);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] += pr * vf[e];
-            }
+            for (int e = 0; e < EPL; ++e) acc[e] += pr * vf[e];
         }
         __syncthreads();     // sc / wred are rewritten by the next chunk
     }
