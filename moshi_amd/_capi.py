@@ -7,6 +7,7 @@ CPU or PyTorch fallback behind this API.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Dict, Optional, Sequence
 
@@ -178,6 +179,10 @@ def load(path: Optional[Path] = None) -> Lib:
     if path is not None:
         return Lib(Path(path))
     if _default is None:
+        override = os.environ.get("MMI_LIB_PATH")          # same-box A/B of two builds of the engine (scripts/gpu_*.sh)
+        if override:
+            _default = Lib(Path(override))
+            return _default
         if not DEFAULT_LIB.exists():
             raise RuntimeError(
                 f"{DEFAULT_LIB} is missing: build the HIP extension first (python -m moshi_amd.build). "

@@ -310,6 +310,12 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     else return p;
     p.grid = g.NT < cus ? g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
+    if (a.epi != MMI_EPI_GATE && !a.whole_tiles) {   // the kernel shares the tiles out in row octets: no workgroup may touch more than 3 tiles
+        for (long b = 0; b < p.grid; ++b) {
+            const long u0 = b * 4L * g.NT / p.grid, u1 = (b + 1) * 4L * g.NT / p.grid;
+            if (u1 > u0 && ((u1 + 3) >> 2) - (u0 >> 2) > 3) return p;
+        }
+    }
     p.stagger = mode == '2' && g.wq == 0;                     // per-tile epilogues under the last chunk's stream (bf16)
     const size_t chunks = (size_t)2 * mt * p.kc * xs * 1024, red = mt == 1 ? 40960 : 65536;   // red: the epilogue's reduction scratch
     p.smem = chunks > red ? chunks : red;
@@ -351,6 +357,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     a.wq = g.wq; a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
+    a.whole_tiles = getenv("MMI_XLDS_WHOLE_TILES") ? 1 : 0;
     const XldsPlan xl = plan_xlds(lm, g, a, mt);
     EvPair* ev = nullptr;
     if (lm->profiling && is_dominant) {

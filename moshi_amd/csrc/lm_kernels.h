@@ -176,6 +176,7 @@ struct GemmArgs {
     const uint16_t* alpha;  // [D]
     int D;                  // features of a row (the mean is over D, not the padded K)
     float eps;
+    int whole_tiles;        // k_gemm_xlds: share the n-tiles out whole (A/B switch MMI_XLDS_WHOLE_TILES=1) instead of in row octets
 };
 
 // The residual (or embedding) vector the thread's FIRST epilogue task will add, requested before the weight stream starts
@@ -208,9 +209,11 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 // kernels: one task = 8 consecutive output features of one session, written as one 16-byte vector.
 // EXT: the reduction scratch is handed in (`red_ext`, WAVES * NTW * MT * 64 * LS floats) instead of a static LDS array - for
 // kernels that own all of the LDS themselves (k_gemm_xlds).
+// g_lo / g_hi: only the tile's 8-feature groups [g_lo, g_hi) are written (k_gemm_xlds hands a tile's row octets to two
+// workgroups when that balances the chip: 384 in_proj tiles over 256 CUs = 6 octets each); default = the whole tile.
 template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
-                                                  int nt0, u32x4 pre, float* red_ext = nullptr) {
+                                                  int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4) {
     constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic).  LDS layout [wave][tile][lane][LS]:
     // a lane's accumulators are contiguous, so they go out and come back as 16-byte vectors; LS = 20 floats (80 B)
@@ -249,7 +252,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         const int nt = nt0 + t;
         const int b = m * TN + bl;
         const int n0 = nt * rows_out + 8 * gi;
-        if (nt >= a.NT || b >= a.B || n0 >= a.N) continue;
+        if (nt >= a.NT || b >= a.B || n0 >= a.N || gi < g_lo || gi >= g_hi) continue;
         const float* rb = red + (t * MT + m) * 64 * LS;
         // features 8*gi .. 8*gi+7 of the tile live in two lanes' accumulator quads (MFMA C layout, lm_kernels.h header):
         //   T = 32: rows i = 8gi+e -> register (e&3) + 4gi of lane bl + 32*(e>>2);  gate partner rows i+16 -> registers + 8
@@ -670,8 +673,20 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     const bool active = ACTIVE == 8 || wave < ACTIVE;
     const int wk = active ? wave : 0;           // idle waves point at valid addresses and never load
     const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int t0 = (int)((long)bid * a.NT / G), t1 = (int)((long)(bid + 1) * a.NT / G);
-    const int ntiles = t1 - t0;                 // <= NTMAX (the launcher sizes the grid)
+    // The workgroup's share of the n-tiles, in row OCTETS (8 of a tile's 32 weight rows) when the epilogue writes 8-feature
+    // groups that map one to one onto them (everything but the gated linear_in, whose tiles interleave gate and value rows):
+    // 384 in_proj tiles over 256 workgroups are 6 octets = 1.5 tiles each instead of 1 or 2 whole tiles, i.e. every CU streams
+    // the same number of bytes.  A workgroup that owns only part of a tile loads only those octets' lanes (the other lanes
+    // repeat a valid lane's address: rows of the MFMA are independent, their results are simply not written).
+    const bool by_octet = a.epi != MMI_EPI_GATE && !a.whole_tiles;
+    const long units = by_octet ? 4L * a.NT : (long)a.NT;
+    const long u0 = (long)bid * units / G, u1 = (long)(bid + 1) * units / G;          // [u0, u1) octets or tiles
+    const int t0 = by_octet ? (int)(u0 >> 2) : (int)u0;
+    const int t1 = by_octet ? (int)((u1 + 3) >> 2) : (int)u1;
+    const int ntiles = u1 > u0 ? t1 - t0 : 0;   // <= NTMAX (the launcher sizes the grid)
+    // octet window of tile t0 + t
+    auto oct_lo = [&](int t) { return by_octet ? (int)max(0L, u0 - 4L * (t0 + t)) : 0; };
+    auto oct_hi = [&](int t) { return by_octet ? (int)min(4L, u1 - 4L * (t0 + t)) : 4; };
     const int nchunks = a.KSTEPS / KC;
     acc_t acc[NTMAX][MT];
 #pragma unroll
@@ -694,7 +709,11 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < XPT; ++j)
         if (j * 512 + tid < XE) xs[j * 512 + tid] = xpre[j];
-    auto wsrc = [&](int c, int t) { return a.wp + ((long)min(t0 + t, a.NT - 1) * a.KSTEPS + (long)c * KC + wk * KPW) * 64 + lane; };
+    auto wsrc = [&](int c, int t) {
+        const int ro = (lane >> 3) & 3, lo = oct_lo(t), hi = oct_hi(t);
+        const int ln = (ro >= lo && ro < hi) ? lane : ((lane & ~0x18) | (lo << 3));       // lanes of octets it does not own
+        return a.wp + ((long)min(t0 + t, a.NT - 1) * a.KSTEPS + (long)c * KC + wk * KPW) * 64 + ln;
+    };
     u32x4 cur[KPW], nxt[KPW];
     if (active) {
         const u32x4* wp = wsrc(0, 0);
@@ -760,7 +779,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
-                    mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
+                    mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
                 }
             }
         }
@@ -784,7 +803,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
-            mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red);
+            mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
         }
     }
 }

@@ -59,11 +59,13 @@ def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=72, B=34, S=2)
 
 
-@pytest.mark.parametrize("B,grid,mode", [(18, 8, "1"), (34, 8, "1"), (20, 64, "1"), (18, 8, "2"), (34, 8, "2")])
+@pytest.mark.parametrize("B,grid,mode", [(18, 8, "1"), (34, 8, "1"), (20, 64, "1"), (18, 8, "2"), (34, 8, "2"), (18, 5, "2"), (18, 7, "1")])
 def test_gemm_with_activations_resident_in_lds(sim_lib, monkeypatch, B, grid, mode):
     """k_gemm_xlds (one workgroup walking several n-tiles with the activation chunks staged in LDS) on the tiny
     shapes: gated FFN input, in_proj with RoPE / ring write and the row-major heads, one and two batch tiles, 1..3 tiles per
-    workgroup (grid 8: 22 / 12 tiles -> 2-3 / 1-2 per workgroup; grid 64 > tiles: one tile each)."""
+    workgroup (grid 8: 22 gated tiles -> 2-3 whole tiles per workgroup, 12 in_proj tiles -> 6 row octets = 1.5 tiles each, the
+    shared tile written half by each owner; grids 5 / 7: uneven octet shares, ranges that would span 4 tiles fall back to
+    k_gemm_xp; grid 64 > tiles: one tile each)."""
     monkeypatch.setenv("MMI_GEMM_LDS", mode)     # "2": each tile's epilogue under the last chunk's weight stream
     monkeypatch.setenv("MMI_GEMM_LDS_GRID", str(grid))
     st = {}
