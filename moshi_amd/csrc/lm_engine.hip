@@ -214,7 +214,7 @@ int load_copy(mmi_lm* lm, const MmiWeights& W, const std::string& name, int ndim
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-struct GemmPlan { int waves, ntw, ksplit, u; };
+struct GemmPlan { int waves, ntw, ksplit, u, osplit; };
 
 // How a GEMM is cut into workgroups (measured on MI355X with scripts/gemm_microbench.hip): enough workgroups to
 // cover the 256 CUs, K split over the waves of a workgroup, more waves per workgroup when there are few n-tiles.
@@ -241,7 +241,27 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     if (e && atoi(e) > 0) p.waves = atoi(e);
     e = getenv("MMI_GEMM_NTW");
     if (e && atoi(e) > 0) p.ntw = atoi(e);
+    p.osplit = 1;
     return p;
+}
+
+// Octet sharing of k_gemm_xp (GemmArgs::osplit): GEMMs with so few n-tiles that most CUs would idle while each busy one is
+// bound by what a single CU can pull (~25 GB/s) - the depth transformer's N = 1024 linears: 32 tiles of 64-180 KB.
+// MMI_GEMM_OSPLIT: "0" = off, "2" / "4" = force (test hook / A-B), default = as many parts as bring the launch to >= 128 workgroups.
+int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T) {
+    if (epi == MMI_EPI_GATE || g.wq != 0 || p.ntw != 1 || (T != 32 && T != 16)) return 1;
+    const int octs = T / 8;
+    int os = 1;
+    const char* e = getenv("MMI_GEMM_OSPLIT");
+    if (e && e[0]) {
+        const int v = atoi(e);
+        if (v <= 1) return 1;
+        os = v < octs ? v : octs;
+        if (e[1] == 'a') return os;            // "4a": every eligible GEMM (tests)
+        return (long)g.NT * p.ksplit <= 64 ? os : 1;
+    }
+    while (os < octs && (long)g.NT * p.ksplit * os < 128) os *= 2;
+    return (long)g.NT * p.ksplit <= 64 ? os : 1;
 }
 
 template <int TN, int MT, int NTW, int WQ>
@@ -278,7 +298,7 @@ int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, int wq, const Ge
 
 template <int TN>
 int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
-    const dim3 groups(mmi_cdiv(NT, p.ntw), p.ksplit);
+    const dim3 groups(mmi_cdiv(NT, p.ntw) * (a.osplit > 1 ? a.osplit : 1), p.ksplit);
     const int w8 = a.wq;
     if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, w8, a);
     if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, w8, a);
@@ -357,6 +377,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     a.wq = g.wq; a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
+    a.osplit = plan_osplit(g, p, a.epi, lm->T);
     a.whole_tiles = getenv("MMI_XLDS_WHOLE_TILES") ? 1 : 0;
     const XldsPlan xl = plan_xlds(lm, g, a, mt);
     EvPair* ev = nullptr;

@@ -177,6 +177,11 @@ struct GemmArgs {
     int D;                  // features of a row (the mean is over D, not the padded K)
     float eps;
     int whole_tiles;        // k_gemm_xlds: share the n-tiles out whole (A/B switch MMI_XLDS_WHOLE_TILES=1) instead of in row octets
+    int osplit;             // k_gemm_xp: > 1 = every n-tile is shared by `osplit` workgroups, each owning TN / 8 / osplit of its row octets
+                            // (grid.x = NT * osplit).  For GEMMs with few n-tiles (N = 1024 of the depth transformer: 32 tiles on
+                            // 256 CUs), where one CU cannot pull its 64-180 KB of weights faster than ~25 GB/s: a workgroup's lanes of
+                            // octets it does not own repeat an owned lane's address (no extra HBM traffic; those MFMA rows are garbage
+                            // that nobody writes), the epilogue writes only the owned 8-feature groups.  Not for gated epilogues.
 };
 
 // The residual (or embedding) vector the thread's FIRST epilogue task will add, requested before the weight stream starts
@@ -388,7 +393,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     constexpr int XS = WQ ? 2 : 1;                // activation fragments per weight entry
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = (int)blockIdx.x * NTW;
+    // octet sharing (a.osplit > 1, NTW == 1): workgroup = (n-tile, part); part owns the 8-feature groups [g_lo, g_hi)
+    const int os = (NTW == 1 && a.osplit > 1) ? a.osplit : 1;
+    const int bx = (int)blockIdx.x / os, part = (int)blockIdx.x - bx * os;
+    const int nt0 = bx * NTW;
+    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
+    // weight fragments are stored [k-step][lane], lane = (k-group, row): rows of octets the workgroup does not own are read
+    // from the first owned octet instead
+    const int ro = (lane >> 3) & (TN / 8 - 1);
+    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
     const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW>(a, nt0);
 
     // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     const u32x4* wp[NTW];
     const u32x4* xp[MT];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + lane;
+    for (int t = 0; t < NTW; ++t) wp[t] = a.wp + ((long)min(nt0 + t, a.NT - 1) * a.KSTEPS + ks0) * 64 + wlane;
 #pragma unroll
     for (int m = 0; m < MT; ++m) xp[m] = a.xp + ((long)m * a.KSTEPS + ks0) * XS * 64 + lane;
 
@@ -441,8 +454,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
             }                                                                                 \
         }                                                                                     \
     }
-#define MMI_G_MMA(W_, X_)                                                                     \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                             \
+#define MMI_G_MMA1(W_, X_, u)                                                                 \
         if constexpr (WQ == 2) MMI_G_MMA8(W_, X_, u)                                          \
         else {                                                                                \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                     \
@@ -458,6 +470,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
             }                                                                                 \
         }                                                                                     \
         }
+#define MMI_G_MMA(W_, X_)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) MMI_G_MMA1(W_, X_, u)
     const int nfull = nks / U;
     if (nfull > 0) {
         // steady state has no conditional loads, so that the compiler's s_waitcnt vmcnt(N) before each MFMA only waits
@@ -478,34 +492,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
             MMI_G_MMA(wA, xA);
         }
     }
-    for (int ks = nfull * U; ks < nks; ++ks) {       // remainder of the slice (fewer than U entries)
+    // remainder of the slice (fewer than U entries): requested together - one memory round trip, not one per entry - from
+    // clamped (valid) entries, and only the live ones meet the matrix core
+    const int rem = nks - nfull * U;
+    if (rem > 0) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) wA[0][t] = mmi_load_nt(wp[t] + ks * 64);
+        for (int u = 0; u < U - 1; ++u) {
+            const int ks = nfull * U + min(u, rem - 1);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int t = 0; t < NTW; ++t) wA[u][t] = mmi_load_nt(wp[t] + ks * 64);
 #pragma unroll
-            for (int x = 0; x < XS; ++x) xA[0][m][x] = xp[m][(ks * XS + x) * 64];
-        if constexpr (WQ == 2) MMI_G_MMA8(wA, xA, 0)
-        else {
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            if constexpr (W8) {
-                u32x4 wlo_, whi_;
-                mmi_i8x16_to_bf16(wA[0][t], wlo_, whi_);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    MMI_G_MFMA(wlo_, xA[0][m][0], acc[t][m])
-                    MMI_G_MFMA(whi_, xA[0][m][XS - 1], acc[t][m])
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) { MMI_G_MFMA(wA[0][t], xA[0][m][0], acc[t][m]) }
-            }
+                for (int x = 0; x < XS; ++x) xA[u][m][x] = xp[m][(ks * XS + x) * 64];
         }
-        }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < rem) { MMI_G_MMA1(wA, xA, u) }
     }
 #undef MMI_G_LOAD
 #undef MMI_G_MMA
+#undef MMI_G_MMA1
 #undef MMI_G_MMA8
 #undef MMI_G_MFMA
 #undef MMI_G_MFMA8
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < R; ++r) accv[t][m][r] = acc[t][m][r];
-    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre);
+    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
 
 // RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
@@ -1141,17 +1148,19 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     for (int c0 = (int)blockIdx.y * CH; c0 < L; c0 += (int)gridDim.y * CH) {     // block-uniform trip count
         // ---- scores of this chunk: all of the wave's key rows are requested up front (unconditional loads from a clamped
         // slot; a load under `if (valid)` would be serialised behind s_waitcnt vmcnt(0)), then reduced
-        constexpr int NIT = PER_WAVE / RPW;               // rows per lane per chunk (16 at Dh = 128 bf16: 64 VGPRs in flight)
-        {
-            u32x4 kk[NIT];
+        constexpr int NIT = PER_WAVE / RPW;
+        constexpr int NB = NIT < 8 ? NIT : 8;             // rows in flight per lane: 8 x 16 bytes keeps the kernel at <= 96 VGPRs
+#pragma unroll 1
+        for (int h0 = 0; h0 < NIT; h0 += NB) {
+            u32x4 kk[NB];
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int slot = min(c0 + wave * PER_WAVE + i * RPW + rsub, L - 1);
+            for (int i = 0; i < NB; ++i) {
+                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
                 kk[i] = *reinterpret_cast<const u32x4*>(kbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int rl = wave * PER_WAVE + i * RPW + rsub;
+            for (int i = 0; i < NB; ++i) {
+                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
                 const int slot = c0 + rl;
                 bool valid = slot < L;
                 if (valid) {   // absolute position of the slot (transformer.py:258-286) and the causal/context mask (:574-582)
@@ -1169,14 +1178,6 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
                 for (int m = LPR / 2; m >= 1; m >>= 1) dot += mmi_shfl_xor(dot, m);
                 if (seg == 0) sc[rl] = valid ? dot * scale : -INFINITY;
             }
-        }
-        // the chunk's value rows are requested NOW, before the softmax's barriers: their HBM latency runs under the reductions
-        // (rows past L carry p = 0 and finite ring contents)
-        u32x4 vv[NIT];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int slot = min(c0 + wave * PER_WAVE + i * RPW + rsub, L - 1);
-            vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
         }
         __syncthreads();
         // ---- online softmax update
@@ -1201,15 +1202,24 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] *= resc;
-        // ---- P.V
+        // ---- P.V (value rows requested up front as well; rows past L carry p = 0 and finite ring contents)
+#pragma unroll 1
+        for (int h0 = 0; h0 < NIT; h0 += NB) {
+            u32x4 vv[NB];
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int rl = wave * PER_WAVE + i * RPW + rsub;
-            const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
-            float vf[EPL];
-            widen(vv[i], vf);
+            for (int i = 0; i < NB; ++i) {
+                const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
+                vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
+            }
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += pr * vf[e];
+            for (int i = 0; i < NB; ++i) {
+                const int rl = wave * PER_WAVE + (h0 + i) * RPW + rsub;
+                const float pr = (c0 + rl < L) ? sc[rl] : 0.f;
+                float vf[EPL];
+                widen(vv[i], vf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[e] += pr * vf[e];
+            }
         }
         __syncthreads();     // sc / wred are rewritten by the next chunk
     }

@@ -51,6 +51,18 @@ def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=78, B=3, S=3)
 
 
+@pytest.mark.parametrize("mode", ["0", "2a", "4a"])
+def test_small_gemms_shared_in_row_octets(sim_lib, monkeypatch, mode):
+    """GemmArgs::osplit: an n-tile shared by 2 / 4 workgroups, each loading and writing only its row octets (the depth
+    transformer's N = 1024 linears, 32 tiles on 256 CUs).  The default (no variable) already shares every GEMM of <= 64 tiles;
+    here: off, and 2 / 4 parts forced on every eligible GEMM, at the 32-row tile (18 sessions), with two batch tiles (34) and at
+    the 16-row tile (3 sessions: two octets per tile)."""
+    monkeypatch.setenv("MMI_GEMM_OSPLIT", mode)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=91, B=18, S=2)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=92, B=34, S=2)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=93, B=3, S=2)
+
+
 def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
     """Two n-tiles per workgroup (`MMI_GEMM_NTW=2`, the variant the 64-session experiments use), forced onto the tiny shapes,
     with one and two batch tiles."""
