@@ -333,6 +333,17 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         if (const char* e = getenv("MMI_CONV_W")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) W = v; }
         while (W * MTB > 16) W >>= 1;          // split-K reduction buffer: W * MTB * 4 KiB of LDS, keep it within 64 KiB
         p->MTB = MTB; p->W = W;
+        std::vector<int> tab((size_t)a.Q * 8);
+        for (int q = 0; q < a.Q; ++q)
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 4; ++e) {
+                    const int kd = (q * 4 + e) * 2 + h;
+                    tab[((size_t)q * 2 + h) * 4 + e] = kd < a.Cin * a.K ? (kd / a.K) * a.x_ld + kd % a.K : 0;
+                }
+        int* dev = nullptr;
+        MMI_HIP_CHECK(arena.alloc(&dev, tab.size()));
+        MMI_HIP_CHECK(hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        a.koff = dev;
         return MMI_OK;
     }
     p->wide = false;

@@ -132,6 +132,7 @@ struct ConvGemmArgs {
     const float* ln_b;
     float ln_eps;
     // --- filled in by the engine's planner
+    const int* koff;      // k_conv_wide: [Q][2][4] input offset of kd = (q*4+e)*2 + h; 0 past Cin*K (the weights there are 0)
     const float* bp;      // k_gemm_f32: packed activations [ceil(N/32)][Q][64][4]
     int x_packed;         // the producer already wrote `bp` (no k_pack_b_f32 launch)
     int out_mode;         // MMI_GOUT_*
@@ -214,21 +215,8 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     const f32x4* wp[MTB];
 #pragma unroll
     for (int m = 0; m < MTB; ++m) wp[m] = reinterpret_cast<const f32x4*>(a.wpk) + (long)min(mt0 + m, a.Mt - 1) * a.Q * 64 + lane;
-    // reduction index -> input offset (ci * x_ld + k), kept incrementally per lane: the lane's four indices of a k-quad are
-    // kd = 8q + 2e + kh, and a step of one quad adds 8 to each.  (A per-layer table of these offsets was a second dependent
-    // memory round trip in front of every group of gathers; removed.)
-    const int kdmax = a.Cin * a.K;
-    const int d8 = mmi_fast_div(8, a.K_magic), r8 = 8 - d8 * a.K;
-    const int ostep = d8 * a.x_ld + r8, owrap = a.x_ld - a.K;
-    int okd = q0 * 8 + kh;                     // kd of element e = 0 of the next quad to load
-    int ooff[4], okk[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int kd = min(okd + 2 * e, (1 << 17) - 1);
-        const int ci = mmi_fast_div(kd, a.K_magic);
-        okk[e] = kd - ci * a.K;
-        ooff[e] = ci * a.x_ld + okk[e];
-    }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* ko = reinterpret_cast<const i32x4*>(a.koff) + kh;
 
     // groups of U k-quads, double buffered: the gathers / weight fragments of group g+1 are in flight while group g
     // runs on the matrix core.  Loads past the slice are clamped to its last quad and their MFMAs skipped.
@@ -237,15 +225,10 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
 #define MMI_W_LOAD(AV, BV, qb)                                                                      \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
         const int qq = min((qb) + u, q1 - 1);                                                       \
+        const i32x4 o = ko[qq * 2];                                                                 \
         /* plain unconditional gathers (a conditional load would be serialised behind s_waitcnt vmcnt(0)): reduction   \
-           indices past Cin*K point at offset 0 and meet zero weights (or belong to quads past the slice, whose MFMAs   \
-           are skipped); columns past Ntot are computed and discarded */                            \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-            BV[u][e] = xb[okd + 2 * e < kdmax ? ooff[e] : 0];                                       \
-            ooff[e] += ostep; okk[e] += r8;                                                         \
-            if (okk[e] >= a.K) { okk[e] -= a.K; ooff[e] += owrap; }                                 \
-        }                                                                                           \
-        okd += 8;                                                                                   \
+           indices past Cin*K point at offset 0 and meet zero weights; columns past Ntot are computed and discarded */  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) BV[u][e] = xb[o[e]];                          \
         _Pragma("unroll") for (int m = 0; m < MTB; ++m) AV[u][m] = wp[m][(long)qq * 64];           \
     }
 #define MMI_W_MMA(AV, BV, qb)                                                                       \
