@@ -245,6 +245,16 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     return p;
 }
 
+int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T);
+// the fused-norm GEMMs: share when that brings the launch from under 128 workgroups to at most ~256
+int plan_osplit_norm(const GemmW& g, const GemmPlan& p, int epi, int T) {
+    if (epi == MMI_EPI_GATE || g.wq != 0 || (T != 32 && T != 16)) return 1;
+    if (const char* e = getenv("MMI_GEMM_OSPLIT")) { if (e[0]) return plan_osplit(g, p, epi, T); }
+    int os = 1;
+    while (os < T / 8 && (long)g.NT * os < 128) os *= 2;
+    return os;
+}
+
 // Octet sharing of k_gemm_xp (GemmArgs::osplit): GEMMs with so few n-tiles that most CUs would idle while each busy one is
 // bound by what a single CU can pull (~25 GB/s) - the depth transformer's N = 1024 linears: 32 tiles of 64-180 KB.
 // MMI_GEMM_OSPLIT: "0" = off, "2" / "4" = force (test hook / A-B), default = as many parts as bring the launch to >= 128 workgroups.
@@ -481,7 +491,14 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
-    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT;
+    // octet sharing for the non-gated fused-norm GEMMs too (the depth transformer's in_proj: 96 tiles -> 192 workgroups);
+    // MMI_GEMM_OSPLIT_NORM=0 switches it off (A/B)
+    {
+        GemmPlan pp; pp.ntw = 1; pp.ksplit = 1;
+        const char* e = getenv("MMI_GEMM_OSPLIT_NORM");
+        a.osplit = (e && atoi(e) == 0) ? 1 : plan_osplit_norm(g, pp, epi, lm->T);
+    }
+    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     lm->prog.add([=](hipStream_t s) {
         if (wq == 1) {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);

@@ -541,7 +541,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = (int)blockIdx.x;
+    // octet sharing (GemmArgs::osplit, see k_gemm_xp): workgroup = (n-tile, part)
+    const int os = a.osplit > 1 ? a.osplit : 1;
+    const int nt0 = (int)blockIdx.x / os, part = (int)blockIdx.x - nt0 * os;
+    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
+    const int ro = (lane >> 3) & (TN / 8 - 1);
+    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
     const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
     const int ks0 = min(a.KSTEPS, wave * kper);
     const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         const int uu = min(u, nks > 0 ? nks - 1 : 0);
-        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + lane);
+        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + wlane);
 #pragma unroll
         for (int x = 0; x < XS; ++x) {
             const int k = ((ksl + uu) * XS + x) * KS + 8 * kq;
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
-    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u});
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ namespace {
 
 struct ConvW {          // one conv / linear as an implicit GEMM: rows = Cout, reduction = Cin*K
     float* wpk = nullptr;
+    float* wpk_h = nullptr;   // 1x1 convs: the same matrix packed in the hidden-tile order of k_resblock's second stage
     float* bias = nullptr;
     int Cin = 0, Cout = 0, K = 1, S = 1, Mt = 0, Q = 0;
 };
@@ -118,6 +119,13 @@ int load_conv(mmi_mimi* m, const MmiWeights& W, const std::string& prefix, int C
     cw->Cin = Cin; cw->Cout = Cout; cw->K = K; cw->S = S;
     rc = pack_matrix(m, (const float*)w->data, Cout, Cin * K, (long)Cin * K, 1, cw);
     if (rc) return rc;
+    if (K == 1) {   // the second conv of a residual block (k_resblock reads its reduction index permuted)
+        const size_t n = (size_t)cw->Mt * cw->Q * 256;
+        MMI_HIP_CHECK(m->wts.alloc(&cw->wpk_h, n));
+        MMI_LAUNCH(k_pack_a_f32_hperm, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const float*)w->data, cw->wpk_h, Cout, Cin,
+                   cw->Mt, cw->Q);
+        MMI_CHECK_LAUNCH();
+    }
     if (bias) {
         const mmi_tensor_desc* b;
         rc = need(W, prefix + ".bias", 1, &b);
@@ -447,6 +455,48 @@ int add_conv(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a, MmiArena* arena = nu
     return MMI_OK;
 }
 
+// SEANet residual block (conv K -> hidden, conv 1x1 -> channels, + input): ONE launch (k_resblock) at audio rate when the block
+// has the shape the kernel is built for and enough columns to fill the chip with 32-column workgroups; else the two convs.
+int add_resblock(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a1, ConvGemmArgs a2, const ConvW& w2) {
+    const int nblk = mmi_cdiv(a1.Ntot, 32);
+    long min_waves = 256;                        // below that the two-launch path (split-K over waves) fills the chip better
+    if (const char* e = getenv("MMI_MIMI_RES_FUSION_MIN")) min_waves = atol(e);      // test hook: the tiny shapes
+    // Measured on MI355X (profiles/r02_logs/resblock_*): the 64-channel blocks (one hidden tile, 1920 one-wave workgroups) gain
+    // 8-13 us each over two launches; the 128 / 256-channel blocks (480 / 96 workgroups of 2 / 4 waves: one wave per SIMD on part of
+    // the chip) lose 2-15 us to the two-launch path's split-K over waves - they take the fused kernel only when asked
+    // (MMI_MIMI_RES_FUSION_ALL=1: tests, experiments).
+    const bool all_widths = getenv("MMI_MIMI_RES_FUSION_ALL") != nullptr;
+    const bool fuse = a1.Ntot > 128 && a1.S == 1 && a2.K == 1 && a2.S == 1 && a1.Cout == a2.Cin && a1.Ntot == a2.Ntot &&
+                      a1.T_out == a2.T_out && (a1.Mt == 1 || ((a1.Mt == 2 || a1.Mt == 4) && all_widths)) && w2.wpk_h && a2.Q <= 4 * a1.Mt &&
+                      a2.Mt >= a1.Mt && (long)nblk * a1.Mt >= min_waves && !a1.first && !a2.first && !a1.res && !a1.scale && !a2.scale &&
+                      a1.T_out % 32 == 0 && a1.Cin <= 64 * a1.Mt && a1.K <= 33 &&
+                      a1.act_out == MMI_ACT_NONE && a2.act_out == MMI_ACT_NONE && !getenv("MMI_MIMI_NO_RES_FUSION");
+    if (!fuse) {
+        int rc = add_conv(m, prog, a1);
+        if (rc) return rc;
+        return add_conv(m, prog, a2);
+    }
+    a2.wpk = w2.wpk_h;
+    a2.elu_in = 0;                               // the hidden tensor never exists un-activated
+    ResBlockArgs ra;
+    ra.a1 = a1; ra.a2 = a2;
+    ra.dbg = getenv("MMI_RES_DBG") ? atoi(getenv("MMI_RES_DBG")) : 0;
+    const int mt1 = a1.Mt;
+    // LDS: input window Cin x (32 + K - 1) | offset table | the waves' hand-off mailbox
+    const size_t smem = ((size_t)((a1.Cin * (32 + a1.K - 1) + 3) & ~3) + (size_t)a1.Q * 8 + (mt1 > 1 ? (size_t)mt1 * 1024 : 0)) * sizeof(float);
+    if (smem > 65536) return mmi_fail(MMI_ERR_UNSUPPORTED, "k_resblock: input window does not fit in LDS");
+    prog.add([ra, mt1, nblk, smem](hipStream_t s) {
+        switch (mt1) {
+            case 1: MMI_LAUNCH((k_resblock<1, 4>), nblk, 64, smem, s, ra); break;
+            case 2: MMI_LAUNCH((k_resblock<2, 4>), nblk, 128, smem, s, ra); break;
+            default: MMI_LAUNCH((k_resblock<4, 4>), nblk, 256, smem, s, ra); break;
+        }
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+    return MMI_OK;
+}
+
 // residual vector quantiser: latent [B][dim] (column `lat_off` of rows of length lat_ld) -> codes_i32 [B][n_q]
 int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B) {
     const mmi_mimi_cfg& c = m->cfg;
@@ -659,10 +709,11 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
         hid.elu = nxt.elu = hoist;               // read only by the block's second conv / the strided conv, both behind an ELU
         prog.site("enc.res" + std::to_string(i));
-        if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true)))) return rc;
-        ConvGemmArgs a = conv_args(m->enc_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
+        const ConvGemmArgs a1 = conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true);
+        const ConvW& w2 = m->enc_convs[ci++];
+        ConvGemmArgs a = conv_args(w2, hid, 0, T, nxt, nxt.H, B, true);
         a.res = cur.p; a.res_ld = cur.ld; a.res_off = cur.H;
-        if ((rc = add_conv(m, prog, a))) return rc;
+        if ((rc = add_resblock(m, prog, a1, a, w2))) return rc;
         hist.push_back(hist_of(nxt, T));
         cur = nxt;
         // strided conv: ch -> 2ch ; consumer = next resblock conv (K3) or the final conv (last_kernel_size)
@@ -814,10 +865,11 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
         hid.elu = nxt.elu = hoist;               // read only behind an ELU: by the block's second conv / the next layer
         prog.site("dec.res" + std::to_string(i));
-        if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true)))) return rc;
-        ConvGemmArgs a = conv_args(m->dec_convs[ci++], hid, 0, T, nxt, nxt.H, B, true);
+        const ConvGemmArgs a1 = conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true);
+        const ConvW& w2 = m->dec_convs[ci++];
+        ConvGemmArgs a = conv_args(w2, hid, 0, T, nxt, nxt.H, B, true);
         a.res = up.p; a.res_ld = up.ld; a.res_off = up.H;
-        if ((rc = add_conv(m, prog, a))) return rc;
+        if ((rc = add_resblock(m, prog, a1, a, w2))) return rc;
         if (Hn > 0) hist.push_back(hist_of(nxt, T));
         cur = nxt;
         mult /= 2;

@@ -314,6 +314,216 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SEANet residual block in ONE launch (seanet.py:31-77 SEANetResnetBlock, true_skip):
+//     y = x + conv1x1(ELU(convK(ELU(x))))        convK: C -> C/2 (K = residual_kernel_size, dilation 1), conv1x1: C/2 -> C
+// at audio rate (N = B*T > 128 columns).  As two k_conv_wide launches the block writes the hidden tensor to HBM and reads it
+// back, and pays two launches for ~1 GFLOP; here a workgroup owns 32 columns and MT1 = ceil((C/2) / 32) waves:
+//   stage 0  the tile's input window (Cin x (32 + K - 1) floats of ONE session: T % 32 == 0) is staged in LDS with coalesced row
+//            loads that are all in flight at once - one memory round trip for the whole tile, where the gather loop of
+//            k_conv_wide pays one per group of k-quads (measured: ~4 us per group at one wave per SIMD)
+//   stage 1  wave w computes hidden m-tile w over the whole reduction, B operand from LDS (ds_read at table offsets): acc1
+//   hand-off h = ELU(acc1 + b1) stays in the accumulator layout: lane (j, hh) holds hidden rows 32w + 8(r>>2) + 4hh + (r&3),
+//            r = 0..15, of its own column j.  The second conv's reduction index is free to be ANY order, so its weights are packed
+//            (k_pack_a_f32_hperm) such that MFMA k-slot (qq, hh) of the 32x32x2 B operand IS hidden row 32(qq/16) + 8((qq%16)>>2)
+//            + 4hh + (qq&3): the B operand of stage 2 is the lane's own registers.  MT1 > 1: the waves swap their tiles through
+//            a per-lane LDS mailbox [MT1][4][64] x 16 bytes (conflict free, one barrier).
+//   stage 2  wave w computes output m-tiles w, w + MT1, ... : 16 * MT1 MFMAs each, weights streamed from L2, then the usual
+//            epilogue (bias, residual x, ELU'd store / twin).
+// a1 / a2 are the ConvGemmArgs the two launches would get (a2.wpk replaced by the permuted packing).
+struct ResBlockArgs {
+    ConvGemmArgs a1, a2;
+    int dbg;   // timing ablations (MMI_RES_DBG, results are wrong): 1 no stage-0 loads, 2 no stage-1 MFMAs, 4 no stage 2, 8 no epilogue
+};
+
+// P[mt][q][lane][e] = W[m][kperm], m = mt*32 + (lane&31), k-slot qq = q*4+e, hh = lane>>5, kperm as above (K = 1 convs only)
+__global__ void k_pack_a_f32_hperm(const float* __restrict__ W, float* __restrict__ P, int M, int Kd, int Mt, int Q) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)Mt * Q * 256;
+    if (idx >= total) return;
+    int e = (int)(idx & 3);
+    int lane = (int)((idx >> 2) & 63);
+    long rest = idx >> 8;
+    int q = (int)(rest % Q);
+    int mt = (int)(rest / Q);
+    int m = mt * 32 + (lane & 31);
+    int qq = q * 4 + e, hh = lane >> 5;
+    int kd = 32 * (qq >> 4) + 8 * ((qq & 15) >> 2) + 4 * hh + (qq & 3);
+    float v = 0.f;
+    if (m < M && kd < Kd) v = W[(long)m * Kd + kd];
+    P[idx] = v;
+}
+
+template <int MT1, int U>
+__global__ __launch_bounds__(MT1 * 64) void k_resblock(ResBlockArgs ra) {
+    const ConvGemmArgs& a = ra.a1;
+    const ConvGemmArgs& c = ra.a2;
+    constexpr int NTH = MT1 * 64;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jl = lane & 31, kh = lane >> 5;
+    // the tile's 32 columns belong to ONE session (T_out % 32 == 0, checked by the engine): b, t0 are uniform
+    const int n0 = (int)blockIdx.x * 32;
+    const int b = mmi_fast_div(n0, a.T_magic), t0 = n0 - b * a.T_out;
+    const int LD = 32 + a.K - 1;                 // input columns the tile's windows cover (stride 1)
+    MMI_DYN_SHARED(float, smem);                 // Xs[Cin][LD] | offs[Q][2][4] | mailbox[MT1][4][64][4]
+    float* Xs = smem;
+    int* offs = reinterpret_cast<int*>(smem + ((a.Cin * LD + 3) & ~3));
+    float* hs = reinterpret_cast<float*>(offs + a.Q * 8);
+
+    // ---- stage 0: the input window -> LDS in ONE memory round trip: wave w stages channels w, w + MT1, ..., one row of LD
+    // consecutive floats per load instruction (coalesced; Cin <= 64 * MT1), all requested before the first one is used
+    constexpr int NR = 64;
+    float xr[NR];
+    {
+        const float* xw = a.x + (long)b * a.x_bstride + a.x_off + t0;
+        const int jj = lane < LD ? lane : LD - 1;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int ci = min(wave + i * MT1, a.Cin - 1);
+            xr[i] = (ra.dbg & 1) ? 0.f : xw[(long)ci * a.x_ld + jj];
+        }
+    }
+    // meanwhile: the weight fragments of this wave's first output tile, the hidden tile's bias, the first stage-1 fragments
+    constexpr int Q2 = 4 * MT1;
+    f32x4 w2v[Q2], w2n[Q2];
+    {
+        const f32x4* w2 = reinterpret_cast<const f32x4*>(c.wpk) + (long)min(wave, c.Mt - 1) * c.Q * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) w2v[q] = w2[(long)min(q, c.Q - 1) * 64];
+    }
+    float b1v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+        b1v[r] = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.f;
+        if (row >= a.Cout) b1v[r] = 0.f;
+    }
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpk) + (long)min(wave, a.Mt - 1) * a.Q * 64 + lane;
+    const int q1 = a.Q;
+    f32x4 avA[U], avB[U];
+#define MMI_R_LOAD(AV, qb)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) AV[u] = wp[(long)min((qb) + u, q1 - 1) * 64];
+    MMI_R_LOAD(avA, 0);
+    // reduction index -> LDS offset of its window start: kd = (q*4+e)*2 + hh -> (ci, k) -> ci * LD + k; 0 past Cin*K (zero weights)
+    for (int i = tid; i < a.Q * 8; i += NTH) {
+        const int e = i & 3, hh = (i >> 2) & 1, q = i >> 3;
+        const int kd = (q * 4 + e) * 2 + hh;
+        const int ci = mmi_fast_div(kd, a.K_magic), k = kd - ci * a.K;
+        offs[i] = kd < a.Cin * a.K ? ci * LD + k : 0;
+    }
+    if (lane < LD) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int ci = wave + i * MT1;
+            if (ci < a.Cin) Xs[ci * LD + lane] = a.elu_in ? mmi_elu(xr[i]) : xr[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: hidden m-tile `wave` = W1[32 rows][Cin*K] . Xs windows; weights one group of U quads ahead, B operand from LDS
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* ko = reinterpret_cast<const i32x4*>(offs) + kh;
+    const float* xl = Xs + jl;
+#define MMI_R_MMA(AV, qb)                                                                           \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                 \
+        if ((qb) + u < q1) {                                                                        \
+            const i32x4 o = ko[((qb) + u) * 2];                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc1 = mmi_mfma_f32_32x32x2(AV[u][e], xl[o[e]], acc1); \
+        }                                                                                           \
+    }
+    if (!(ra.dbg & 2)) {
+        const int G = (q1 + U - 1) / U;
+        int g = 0;
+        for (; g + 2 < G; g += 2) {
+            MMI_R_LOAD(avB, (g + 1) * U);
+            MMI_R_MMA(avA, g * U);
+            MMI_R_LOAD(avA, (g + 2) * U);
+            MMI_R_MMA(avB, (g + 1) * U);
+        }
+        if (G - g == 2) {
+            MMI_R_LOAD(avB, (g + 1) * U);
+            MMI_R_MMA(avA, g * U);
+            MMI_R_MMA(avB, (g + 1) * U);
+        } else {
+            MMI_R_MMA(avA, g * U);
+        }
+    }
+#undef MMI_R_LOAD
+#undef MMI_R_MMA
+    // ---- hand-off: h = ELU(acc1 + b1) in the accumulator layout (rows past Cout1 have zero weights on both sides)
+    f32x4 hb[MT1][4];
+    {
+        float h[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = mmi_elu(acc1[r] + b1v[r]);
+        if constexpr (MT1 == 1) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) hb[0][c4] = f32x4{h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]};
+        } else {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+                *reinterpret_cast<f32x4*>(hs + ((wave * 4 + c4) * 64 + lane) * 4) = f32x4{h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]};
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MT1; ++m)
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) hb[m][c4] = *reinterpret_cast<const f32x4*>(hs + ((m * 4 + c4) * 64 + lane) * 4);
+        }
+    }
+    // ---- stage 2: output m-tiles wave, wave + MT1, ...; the epilogue is this block's own (bias, + x, ELU'd store and / or twin),
+    // with none of the generic epilogue's per-value branches on launch-uniform flags: these kernels are instruction bound
+    const int t = t0 + jl;
+    const float* resb = c.res + (long)b * c.Cout * c.res_ld + c.res_off + t;
+    float* outb = c.out + (long)b * c.Cout * c.out_ld + c.out_off + t;
+    float* out2b = c.out2 ? c.out2 + (long)b * c.Cout * c.out_ld + c.out_off + t : nullptr;
+    for (int mt2 = wave; mt2 < c.Mt && !(ra.dbg & 4); mt2 += MT1) {
+        {   // the next tile's fragments are requested before this tile's MFMAs and epilogue
+            const f32x4* w2 = reinterpret_cast<const f32x4*>(c.wpk) + (long)min(mt2 + MT1, c.Mt - 1) * c.Q * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) w2n[q] = w2[(long)min(q, c.Q - 1) * 64];
+        }
+        // this tile's bias and residual values travel under the MFMAs (rows clamped into the tensor, masked at the store)
+        const int row0 = mt2 * 32 + 4 * kh;
+        float b2v[16], rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2), c.Cout - 1);
+            b2v[r] = c.bias ? c.bias[row] : 0.f;
+            rv[r] = resb[(long)row * c.res_ld];
+        }
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) {
+            if (q < c.Q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = q * 4 + e;                 // k-slot: hidden tile qq / 16, accumulator register qq % 16
+                    acc2 = mmi_mfma_f32_32x32x2(w2v[q][e], hb[qq >> 4][(qq & 15) >> 2][qq & 3], acc2);
+                }
+            }
+        }
+        if (!(ra.dbg & 8)) {
+            const bool full = mt2 * 32 + 32 <= c.Cout;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (!full && row >= c.Cout) continue;
+                const float x = rv[r] + (acc2[r] + b2v[r]);             // x_orig + (conv + bias)  (seanet.py:76-77)
+                const long at = (long)row * c.out_ld;
+                if (out2b) { outb[at] = x; out2b[at] = mmi_elu(x); }
+                else outb[at] = c.elu_out ? mmi_elu(x) : x;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) w2v[q] = w2n[q];
+    }
+}
+
 // natural [B][Cin][x_ld] -> packed B operand: im2col (K, S), ELU, replicate padding of the first frame.
 // One thread per (n-subtile, k-quad, lane): 4 elements kd = (q*4+e)*2 + (lane>>5), column n = nt*32 + (lane&31).
 __global__ void k_pack_b_f32(ConvGemmArgs a, float* __restrict__ bp) {

@@ -36,6 +36,38 @@ def test_conv_kernel_variants(factory, monkeypatch, mtb, w, ks):
     mimi_cases.oracle_vs_engine(factory, "cpu", tiny_mimi_config(), seed=90 + mtb, B=6, F=3, K=5)
 
 
+def test_fused_residual_block_on_the_tiny_codec(factory, monkeypatch):
+    """k_resblock (both convs of a SEANet residual block in one launch, the hidden tensor handed over in the accumulator layout)
+    forced onto the tiny codec's first block (96 columns per session: 32-column tiles inside one session; the other blocks' tiles
+    would straddle sessions and stay on two launches) - one hidden m-tile - with exec masks, a mid-run reset and the reference's
+    golden schedule."""
+    monkeypatch.setenv("MMI_MIMI_RES_FUSION_MIN", "1")
+    mimi_cases.check_tiny_against_golden(factory, "cpu")
+    mimi_cases.oracle_vs_engine(factory, "cpu", tiny_mimi_config(), seed=31, B=6, F=4, K=5)
+
+
+def test_fused_residual_block_with_one_two_and_four_hidden_tiles(factory, monkeypatch):
+    """Blocks of 64 / 128 / 256 channels (hidden 32 / 64 / 128 rows = 1 / 2 / 4 waves per workgroup, the LDS mailbox between
+    the stages) at 128 / 64 / 32 columns per session, against the oracle; and the same codec on the two-launch path."""
+    from dataclasses import replace
+    cfg = replace(tiny_mimi_config(), n_filters=64, ratios=[16, 2, 2], sample_rate=1600)    # frame = 128 samples, hop 64
+    made = []
+    def big(sd, c, K):
+        made.append(factory(sd, c, K, max_batch=5))
+        return made[-1]
+    monkeypatch.setenv("MMI_MIMI_RES_FUSION_MIN", "1")
+    monkeypatch.setenv("MMI_MIMI_RES_FUSION_ALL", "1")      # the 2- and 4-tile forms are off by default (slower than two launches)
+    mimi_cases.oracle_vs_engine(big, "cpu", cfg, seed=32, B=5, F=3, K=5)
+    def res_kernels(m):
+        x = torch.zeros(5, 1, cfg.frame_size)
+        with m.streaming(5):
+            m.decode(m.encode(x))
+            return [k for w in ("encode", "decode") for site, k in m.launch_list(w) if ".res" in site]
+    assert [k.count("k_resblock") for k in res_kernels(made[-1])] == [1] * 6
+    monkeypatch.setenv("MMI_MIMI_NO_RES_FUSION", "1")
+    mimi_cases.oracle_vs_engine(big, "cpu", cfg, seed=32, B=5, F=3, K=5)
+    assert not any("k_resblock" in k for k in res_kernels(made[-1])) and len(res_kernels(made[-1])) == 12
+
 @pytest.mark.parametrize("heads,two_pass", [(2, False), (4, False), (2, True)])
 def test_attention_head_dims_and_ring_wrap(factory, monkeypatch, heads, two_pass):
     """Head dims 64 / 32 (the tiny codec has 16) through the one-round-trip attention kernel and its two-pass fallback,
