@@ -492,11 +492,11 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
     // octet sharing for the non-gated fused-norm GEMMs too (the depth transformer's in_proj: 96 tiles -> 192 workgroups);
-    // MMI_GEMM_OSPLIT_NORM=0 switches it off (A/B)
+    // MMI_GEMM_OSPLIT_NORM=1 switches it on (A/B)
     {
         GemmPlan pp; pp.ntw = 1; pp.ksplit = 1;
-        const char* e = getenv("MMI_GEMM_OSPLIT_NORM");
-        a.osplit = (e && atoi(e) == 0) ? 1 : plan_osplit_norm(g, pp, epi, lm->T);
+        const char* e = getenv("MMI_GEMM_OSPLIT_NORM");   // measured neutral at 32 sessions (profiles/r02_logs/ab_osplit_norm*): opt-in
+        a.osplit = (e && atoi(e) != 0) || getenv("MMI_GEMM_OSPLIT") ? plan_osplit_norm(g, pp, epi, lm->T) : 1;
     }
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     lm->prog.add([=](hipStream_t s) {
@@ -856,6 +856,10 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     lm->cfg = norm_cfg;
     lm->max_batch = max_batch;
     lm->T = max_batch <= 16 ? 16 : 32;
+    if (const char* e = getenv("MMI_LM_TILE")) {      // A/B hook: the 32-row tile (and with it k_gemm_xlds / the octet sharing) at small batches
+        const int v = atoi(e);
+        if (v == 32 || (v == 16 && max_batch <= 16)) lm->T = v;
+    }
     lm->use_graph = mmi_graphs_enabled();
     const mmi_lm_cfg& c = lm->cfg;
     lm->NC = c.n_q + 1;
