@@ -176,21 +176,48 @@ __device__ __forceinline__ void mmi_conv_store_n(const ConvGemmArgs& a, const in
 #pragma unroll
         for (int i = 0; i < NV; ++i) rsv[i] = a.res[row[i] * a.res_ld + a.res_off + (ok[i] ? t[i] : 0)];
     }
+    // launch-uniform flags are tested once per group of NV values, not per value: these kernels are instruction bound, and a
+    // per-value maze of scalar branches (with the erf and expm1 bodies in line) was a third of a residual block's time
+    if (a.bias) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        float x = v[i];
-        if (a.bias) x += bia[i];
-        if (a.act_out == MMI_ACT_GELU) x = mmi_gelu_erf(x);
-        else if (a.act_out == MMI_ACT_ELU) x = mmi_elu(x);
-        if (a.scale) x *= scl[i];
-        if (a.res) x = rsv[i] + x;
-        if (ok[i]) {
-            const long at = row[i] * a.out_ld + a.out_off + t[i];
-            if (a.out2) { a.out[at] = x; a.out2[at] = mmi_elu(x); }
-            else a.out[at] = a.elu_out ? mmi_elu(x) : x;
-            // the residual stream of the Mimi transformers is also kept as the packed operand of the next fused norm + linear
-            if (a.outp && a.out_mode == MMI_GOUT_NATURAL) a.outp[mmi_bp_index(co[i], b[i] * a.T_out + t[i], a.outQ)] = x;
-        }
+        for (int i = 0; i < NV; ++i) v[i] += bia[i];
+    }
+    if (a.act_out == MMI_ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = mmi_gelu_erf(v[i]);
+    } else if (a.act_out == MMI_ACT_ELU) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = mmi_elu(v[i]);
+    }
+    if (a.scale) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] *= scl[i];
+    }
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = rsv[i] + v[i];
+    }
+    long at[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) at[i] = row[i] * a.out_ld + a.out_off + (ok[i] ? t[i] : 0);
+    if (a.out2) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) { a.out[at[i]] = v[i]; a.out2[at[i]] = mmi_elu(v[i]); }
+    } else if (a.elu_out) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) a.out[at[i]] = mmi_elu(v[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) a.out[at[i]] = v[i];
+    }
+    // the residual stream of the Mimi transformers is also kept as the packed operand of the next fused norm + linear
+    if (a.outp && a.out_mode == MMI_GOUT_NATURAL) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) a.outp[mmi_bp_index(co[i], b[i] * a.T_out + t[i], a.outQ)] = v[i];
     }
 }
 
