@@ -558,7 +558,8 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
     lm->prog.add([=](hipStream_t s) {
         if (V <= 2048) MMI_LAUNCH((k_sample<256, 8, true>), B, 256, 0, s, sa);
         else if (V <= 8192) MMI_LAUNCH((k_sample<1024, 8, true>), B, 1024, 0, s, sa);
-        else MMI_LAUNCH((k_sample<1024, 32, false>), B, 1024, 0, s, sa);
+        else if (getenv("MMI_SAMPLE_TEXT_NOCACHE")) MMI_LAUNCH((k_sample<1024, 32, false>), B, 1024, 0, s, sa);
+        else MMI_LAUNCH((k_sample<1024, 32, true>), B, 1024, 0, s, sa);   // 32 logits per thread = 16 VGPRs: read once, not once per pass
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
