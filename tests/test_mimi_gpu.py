@@ -53,6 +53,15 @@ def test_rvq_indices_bit_exact_on_many_vectors(factory):
     co = orc.quantize(lat)
     assert ce.shape == co.shape == (64, 32, 64)
     bad = np.argwhere((ce != co).any(1))
+    # the observed count goes on record: printed, and written next to the other parity summaries
+    n_dec = int((ce != co).sum())
+    print(f"[parity] rvq_indices: {len(bad)} of 4096 vectors ({n_dec} of {ce.size} index decisions) differ from the fp32 cdist restatement")
+    import json
+    from pathlib import Path
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out.is_dir():
+        (out / "parity_rvq_indices.json").write_text(json.dumps({"case": "rvq_indices", "vectors": 4096, "vectors_differing": len(bad),
+                                                                  "decisions": int(ce.size), "decisions_differing": n_dec}, indent=1))
     assert len(bad) <= 4, f"{len(bad)} of 4096 vectors differ from the oracle - more than near-ties can explain"
     for b, t in bad:
         k = int(np.argmax(ce[b, :, t] != co[b, :, t]))          # first level that differs; the prefix is identical
