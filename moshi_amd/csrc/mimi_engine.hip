@@ -480,7 +480,6 @@ int add_resblock(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a1, ConvGemmArgs a2
     a2.elu_in = 0;                               // the hidden tensor never exists un-activated
     ResBlockArgs ra;
     ra.a1 = a1; ra.a2 = a2;
-    ra.dbg = getenv("MMI_RES_DBG") ? atoi(getenv("MMI_RES_DBG")) : 0;
     const int mt1 = a1.Mt;
     // LDS: input window Cin x (32 + K - 1) | offset table | the waves' hand-off mailbox
     const size_t smem = ((size_t)((a1.Cin * (32 + a1.K - 1) + 3) & ~3) + (size_t)a1.Q * 8 + (mt1 > 1 ? (size_t)mt1 * 1024 : 0)) * sizeof(float);

@@ -360,7 +360,6 @@ __global__ __launch_bounds__(W * 64) void k_conv_wide(ConvGemmArgs a) {
 // a1 / a2 are the ConvGemmArgs the two launches would get (a2.wpk replaced by the permuted packing).
 struct ResBlockArgs {
     ConvGemmArgs a1, a2;
-    int dbg;   // timing ablations (MMI_RES_DBG, results are wrong): 1 no stage-0 loads, 2 no stage-1 MFMAs, 4 no stage 2, 8 no epilogue
 };
 
 // P[mt][q][lane][e] = W[m][kperm], m = mt*32 + (lane&31), k-slot qq = q*4+e, hh = lane>>5, kperm as above (K = 1 convs only)
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(MT1 * 64) void k_resblock(ResBlockArgs ra) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int ci = min(wave + i * MT1, a.Cin - 1);
-            xr[i] = (ra.dbg & 1) ? 0.f : xw[(long)ci * a.x_ld + jj];
+            xr[i] = xw[(long)ci * a.x_ld + jj];
         }
     }
     // meanwhile: the weight fragments of this wave's first output tile, the hidden tile's bias, the first stage-1 fragments
@@ -461,7 +460,7 @@ __global__ __launch_bounds__(MT1 * 64) void k_resblock(ResBlockArgs ra) {
             _Pragma("unroll") for (int e = 0; e < 4; ++e) acc1 = mmi_mfma_f32_32x32x2(AV[u][e], xl[o[e]], acc1); \
         }                                                                                           \
     }
-    if (!(ra.dbg & 2)) {
+    {
         const int G = (q1 + U - 1) / U;
         int g = 0;
         for (; g + 2 < G; g += 2) {
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(MT1 * 64) void k_resblock(ResBlockArgs ra) {
     const float* resb = c.res + (long)b * c.Cout * c.res_ld + c.res_off + t;
     float* outb = c.out + (long)b * c.Cout * c.out_ld + c.out_off + t;
     float* out2b = c.out2 ? c.out2 + (long)b * c.Cout * c.out_ld + c.out_off + t : nullptr;
-    for (int mt2 = wave; mt2 < c.Mt && !(ra.dbg & 4); mt2 += MT1) {
+    for (int mt2 = wave; mt2 < c.Mt; mt2 += MT1) {
         {   // the next tile's fragments are requested before this tile's MFMAs and epilogue
             const f32x4* w2 = reinterpret_cast<const f32x4*>(c.wpk) + (long)min(mt2 + MT1, c.Mt - 1) * c.Q * 64 + lane;
 #pragma unroll
@@ -534,7 +533,7 @@ __global__ __launch_bounds__(MT1 * 64) void k_resblock(ResBlockArgs ra) {
                 }
             }
         }
-        if (!(ra.dbg & 8)) {
+        {
             const bool full = mt2 * 32 + 32 <= c.Cout;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
