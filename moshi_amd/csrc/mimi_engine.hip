@@ -337,6 +337,48 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         auto wmax = [&](int mtb) { int w = 1; while (w < 8 && w * 2 * mtb <= 16 && a.Q / (w * 2) >= 4) w <<= 1; return w; };
         while (MTB > 1 && waves(MTB, wmax(MTB)) < 1024) MTB >>= 1;
         while (W < wmax(MTB) && waves(MTB, W) < 1024) W <<= 1;
+        // Measured tilings of the codec's own layer shapes (profiles/r02_logs/conv_wide_tiling_sweep_b{8,32,64}.txt: every
+        // (MTB, W) forced on every layer, per-site times from the kernel trace).  The rule above is within a few percent of the
+        // best at 8 sessions but leaves 72 us per frame at 32 sessions and 114 us at 64: what it does not see is the workgroup
+        // count against the 256 CUs (a strided conv of 16 column tiles at MTB = 2 is 128 workgroups - half the chip) and the
+        // 64-value epilogue of an unsplit MTB = 4 wave.  Shapes not listed (other codecs, other batch classes) keep the rule.
+        // Same fp32 results up to summation order (W waves split the reduction), like any other tiling.
+        {
+            struct Tune { int Cin, Cout, K, S, nsub, MTB, W; };
+            static const Tune kTune[] = {
+                // 32 sessions (column tiles of the layer at 32 sessions)
+                {128, 256, 10, 5, 96, 4, 4},    // enc.down1   45.9 -> 34.1 us
+                {256, 512, 12, 6, 16, 1, 8},    // enc.down2   47.4 -> 30.8
+                {128, 64, 3, 1, 480, 1, 4},     // resblock 128 ch (enc.res1 / dec.res2), first conv
+                {64, 128, 1, 1, 480, 1, 4},     //   second conv                      32.9 -> 31.9, 32.7 -> 31.2
+                {256, 128, 3, 1, 96, 1, 4},     // resblock 256 ch (enc.res2 / dec.res1)
+                {128, 256, 1, 1, 96, 1, 4},     //                                    24.6 -> 23.3, 26.0 -> 23.0
+                {512, 256, 3, 1, 16, 1, 8},     // resblock 512 ch (enc.res3 / dec.res0)
+                {256, 512, 1, 1, 16, 1, 8},     //                                    21.4 -> 19.4, 21.9 -> 20.1
+                {512, 3072, 1, 1, 16, 1, 8},    // dec.convtr1 (rows = Cout * K)      41.5 -> 34.2 (with its combine)
+                {256, 1280, 1, 1, 96, 4, 4},    // dec.convtr2                        49.1 -> 47.0
+                {128, 512, 1, 1, 480, 1, 2},    // dec.convtr3                        76.6 -> 55.6
+                {64, 1, 7, 1, 1920, 1, 4},      // dec.final                          18.9 -> 16.6
+                // 64 sessions
+                {128, 256, 10, 5, 192, 2, 8},   // enc.down1   78.2 -> 64.1
+                {256, 512, 12, 6, 32, 2, 8},    // enc.down2   54.8 -> 49.0
+                {256, 128, 3, 1, 192, 1, 4},    // resblock 256 ch                    42.3 -> 34.9, 41.4 -> 34.1
+                {128, 256, 1, 1, 192, 1, 4},
+                {512, 256, 3, 1, 32, 1, 8},     // resblock 512 ch                    34.1 -> 22.5, 36.3 -> 22.5
+                {256, 512, 1, 1, 32, 1, 8},
+                {512, 3072, 1, 1, 32, 1, 8},    // dec.convtr1                        61.1 -> 58.9
+                {256, 1280, 1, 1, 192, 4, 4},   // dec.convtr2                       100.2 -> 82.3
+                {128, 512, 1, 1, 960, 1, 2},    // dec.convtr3                       128.8 -> 99.5
+                {64, 1, 7, 1, 3840, 1, 4},      // dec.final                          31.5 -> 28.1
+            };
+            if (!getenv("MMI_CONV_NO_TUNE_TABLE"))
+                for (const Tune& t : kTune)
+                    if (t.Cin == a.Cin && t.Cout == a.Cout && t.K == a.K && t.S == a.S && 4 * nsub >= 3 * t.nsub && 2 * nsub < 3 * t.nsub) {
+                        MTB = t.MTB; W = t.W;
+                        while (MTB > a.Mt) MTB >>= 1;
+                        break;
+                    }
+        }
         if (const char* e = getenv("MMI_CONV_MTB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) MTB = v; }   // test hooks
         if (const char* e = getenv("MMI_CONV_W")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) W = v; }
         while (W * MTB > 16) W >>= 1;          // split-K reduction buffer: W * MTB * 4 KiB of LDS, keep it within 64 KiB
