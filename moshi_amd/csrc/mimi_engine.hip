@@ -24,6 +24,7 @@ struct TrLayerW {
 struct Buf {            // activation buffer [B][C][ld]; first H columns = causal history of its consumer
     float* p = nullptr;
     int C = 0, ld = 0, H = 0;
+    int lead = 0;          // floats in front of row 0 (alloc_buf: alignment of the new columns)
     // ELU hoisted into the producers (ConvGemmArgs::elu_out / out2, mimi_kernels.h):
     float* pe = nullptr;   // twin of the same geometry holding ELU(values) - what the ELU-fronted consumer conv reads
     bool elu = false;      // `p` itself holds ELU(values) (no reader wants the raw ones)
@@ -465,19 +466,32 @@ ConvGemmArgs conv_args(const ConvW& w, const Buf& in, int x_off, int T_out, cons
     return a;
 }
 
+// Audio-rate buffers (T >= 32 new columns per row): the row stride is a multiple of 32 floats and the allocation leads with
+// `lead` floats so that the T NEW columns of every row start on a 128-byte line (the H history columns sit right in front of
+// them).  A 32-column tile of a conv's output is then exactly one cache line per row: consecutive workgroups run on different
+// XCDs (different L2s), and with rows starting at arbitrary 8-byte offsets every line was written in part by two of them.
+// MMI_MIMI_NO_ALIGN=1 keeps the dense layout (A/B).  Nothing else knows: every kernel takes (pointer, row stride, H).
 int alloc_buf(mmi_mimi* m, int B, int C, int H, int T, Buf* b, hipStream_t s) {
-    b->C = C; b->H = H; b->ld = H + T;
-    size_t n = (size_t)B * C * b->ld;
-    MMI_HIP_CHECK(m->st.alloc(&b->p, n));
-    MMI_HIP_CHECK(hipMemsetAsync(b->p, 0, n * sizeof(float), s));
+    b->C = C; b->H = H; b->ld = H + T; b->lead = 0;
+    if (T >= 32 && !getenv("MMI_MIMI_NO_ALIGN")) {
+        b->lead = (32 - H % 32) % 32;
+        b->ld = ((b->lead + H + T + 31) / 32) * 32;
+    }
+    size_t n = (size_t)B * C * b->ld + b->lead;
+    float* base = nullptr;
+    MMI_HIP_CHECK(m->st.alloc(&base, n));
+    MMI_HIP_CHECK(hipMemsetAsync(base, 0, n * sizeof(float), s));
+    b->p = base + b->lead;
     return MMI_OK;
 }
 
 // ELU twin of a buffer (same geometry, zero history: ELU(0) = 0)
 int alloc_twin(mmi_mimi* m, int B, Buf* b, hipStream_t s) {
-    size_t n = (size_t)B * b->C * b->ld;
-    MMI_HIP_CHECK(m->st.alloc(&b->pe, n));
-    MMI_HIP_CHECK(hipMemsetAsync(b->pe, 0, n * sizeof(float), s));
+    size_t n = (size_t)B * b->C * b->ld + b->lead;
+    float* base = nullptr;
+    MMI_HIP_CHECK(m->st.alloc(&base, n));
+    MMI_HIP_CHECK(hipMemsetAsync(base, 0, n * sizeof(float), s));
+    b->pe = base + b->lead;
     return MMI_OK;
 }
 
@@ -889,10 +903,10 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
             MMI_HIP_CHECK(hipMemsetAsync(part, 0, (size_t)B * pn * sizeof(float), s0));
             m->partials.push_back(part); m->partial_sizes.push_back(pn);
             const float* tp = tmp.p; const float* bias = wtr.bias; const uint8_t* ex = m->exec;
-            float* out = up.p; float* out2 = up.pe; int old = up.ld, ooff = up.H; int Tin = T;
+            float* out = up.p; float* out2 = up.pe; int old = up.ld, ooff = up.H; int Tin = T; const int tld = tmp.ld;
             prog.add([=](hipStream_t s) {
                 MMI_LAUNCH(k_convtr_combine, (int)mmi_cdiv64((int64_t)B * cout * Tin * ratio, 256), 256, 0, s, tp, bias, part,
-                           ex, out, old, ooff, B, cout, K, ratio, Tin, out2);
+                           ex, out, old, ooff, B, cout, K, ratio, Tin, out2, tld);
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
@@ -1283,7 +1297,7 @@ extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pc
         MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
         MMI_CHECK_LAUNCH();
         if ((rc = m->dec_prog.run(s, m->use_graph, m->cap_stream))) return rc;
-        MMI_LAUNCH(k_copy2d_f32, (int)mmi_cdiv64((int64_t)batch * c.channels * F, 256), 256, 0, s, (const float*)m->dec_out.p, (long)F,
+        MMI_LAUNCH(k_copy2d_f32, (int)mmi_cdiv64((int64_t)batch * c.channels * F, 256), 256, 0, s, (const float*)m->dec_out.p, (long)m->dec_out.ld,
                    pcm + (long)f * F, (long)n_frames * F, batch * c.channels, F);
         MMI_CHECK_LAUNCH();
     }

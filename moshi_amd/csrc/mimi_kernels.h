@@ -804,12 +804,13 @@ __global__ void k_conv_finish(ConvGemmArgs a, int ksplit) {
 
 // ------------------------------------------------------------------------------------------------
 // transposed conv: overlap-add of the GEMM result with the streaming `partial` (conv.py:340-362)
-// tmp [B][Cout*K][T_in] holds tmp[b][co*K + k][t] = sum_ci Wtr[ci][co][k] * elu(x[b][ci][t]); K == 2*S.
+// tmp [B][Cout*K][tmp_ld >= T_in] holds tmp[b][co*K + k][t] = sum_ci Wtr[ci][co][k] * elu(x[b][ci][t]); K == 2*S.
 // ------------------------------------------------------------------------------------------------
 // out2: the ELU'd twin of `out` (same geometry) read by the next conv, or null (see ConvGemmArgs::out2)
 __global__ void k_convtr_combine(const float* __restrict__ tmp, const float* __restrict__ bias,
                                  float* __restrict__ partial, const uint8_t* __restrict__ exec, float* __restrict__ out,
-                                 int out_ld, int out_off, int B, int Cout, int K, int S, int T_in, float* __restrict__ out2) {
+                                 int out_ld, int out_off, int B, int Cout, int K, int S, int T_in, float* __restrict__ out2,
+                                 int tmp_ld) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Tout = T_in * S;
     if (idx >= (long)B * Cout * Tout) return;
@@ -818,15 +819,15 @@ __global__ void k_convtr_combine(const float* __restrict__ tmp, const float* __r
     int co = (int)(row % Cout);
     int b = (int)(row / Cout);
     int t = p / S, r = p - t * S;
-    const float* trow = tmp + row * (long)K * T_in;  // [K][T_in]
-    float v = trow[(long)r * T_in + t];
-    if (t > 0) v += trow[(long)(r + S) * T_in + (t - 1)];
+    const float* trow = tmp + row * (long)K * tmp_ld;  // [K][T_in], row stride tmp_ld
+    float v = trow[(long)r * tmp_ld + t];
+    if (t > 0) v += trow[(long)(r + S) * tmp_ld + (t - 1)];
     if (bias) v += bias[co];
     if (t == 0) {
         // y[..., :PT] += partial; then the thread that consumed partial[b][co][r] also refreshes it
         long pi = row * (long)(K - S) + r;
         v += partial[pi];
-        if (exec[b]) partial[pi] = trow[(long)(r + S) * T_in + (T_in - 1)];  // tail, bias excluded (conv.py:354-360)
+        if (exec[b]) partial[pi] = trow[(long)(r + S) * tmp_ld + (T_in - 1)];  // tail, bias excluded (conv.py:354-360)
     }
     out[row * (long)out_ld + out_off + p] = v;
     if (out2) out2[row * (long)out_ld + out_off + p] = mmi_elu(v);
