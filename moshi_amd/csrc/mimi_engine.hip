@@ -567,18 +567,32 @@ int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat
     const int K = m->n_codebooks;
     const int nchunk = m->nchunk;
     const size_t smem = ((size_t)MMI_RVQ_CHUNK * (D + 4) + (size_t)8 * D) * sizeof(float);
-    for (int k = 0; k < K; ++k) {
+    auto level = [&](int k, int slot) {
         const bool sem = k < c.q_n_q_semantic;
-        float* x = m->xq + (sem ? 0 : D);
-        const float* E = m->E_all + (size_t)k * bins * D;
-        const double* e2 = m->e2_all + (size_t)k * bins;
-        double* bd = m->best_d; int* bi = m->best_i; int* codes = m->codes_i32; const int nq = c.q_n_q;
+        RvqLevel L;
+        L.x = m->xq + (sem ? 0 : D);
+        L.E = m->E_all + (size_t)k * bins * D;
+        L.e2 = m->e2_all + (size_t)k * bins;
+        L.best_d = m->best_d + (size_t)slot * nchunk * m->max_batch;
+        L.best_i = m->best_i + (size_t)slot * nchunk * m->max_batch;
+        L.level = k;
+        return L;
+    };
+    int* codes = m->codes_i32; const int nq = c.q_n_q;
+    // the semantic quantiser's single level and the first acoustic level share their two launches (independent, see RvqLevel)
+    const bool pair = c.q_n_q_semantic == 1 && K >= 2 && !getenv("MMI_RVQ_NO_PAIR");
+    for (int k = 0; k < K; ++k) {
+        const RvqLevel a0 = level(k, 0);
+        const bool two = pair && k == 0;
+        const RvqLevel a1 = two ? level(1, 1) : a0;
+        const int nz = two ? 2 : 1;
         prog.add([=](hipStream_t s) {
-            MMI_LAUNCH(k_rvq_dist, dim3(nchunk, mmi_cdiv(B, 8)), 256, smem, s, (const float*)x, 2 * D, E, e2, bd, bi, B, D, bins);
-            MMI_LAUNCH(k_rvq_select, B, 256, 0, s, (const double*)bd, (const int*)bi, nchunk, x, 2 * D, E, codes, nq, k, B, D);
+            MMI_LAUNCH(k_rvq_dist, dim3(nchunk, mmi_cdiv(B, 8), nz), 256, smem, s, a0, a1, 2 * D, B, D, bins);
+            MMI_LAUNCH(k_rvq_select, dim3(B, nz), 256, 0, s, a0, a1, nchunk, 2 * D, codes, nq, B, D);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
+        if (two) ++k;
     }
     return MMI_OK;
 }
@@ -1058,8 +1072,8 @@ extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* w
     // ---- RVQ scratch
     m->nchunk = mmi_cdiv(c.q_bins, MMI_RVQ_CHUNK);
     if (hipSuccess != m->wts.alloc(&m->xq, (size_t)max_batch * 2 * c.q_dimension) ||
-        hipSuccess != m->wts.alloc(&m->best_d, (size_t)m->nchunk * max_batch) ||
-        hipSuccess != m->wts.alloc(&m->best_i, (size_t)m->nchunk * max_batch) ||
+        hipSuccess != m->wts.alloc(&m->best_d, (size_t)2 * m->nchunk * max_batch) ||
+        hipSuccess != m->wts.alloc(&m->best_i, (size_t)2 * m->nchunk * max_batch) ||
         hipSuccess != m->wts.alloc(&m->codes_i32, (size_t)max_batch * c.q_n_q) ||
         hipSuccess != m->wts.alloc(&m->q2, (size_t)max_batch * 2 * c.q_dimension) ||
         hipSuccess != m->wts.alloc(&m->lat_tmp, (size_t)max_batch * c.dimension) ||

@@ -1280,10 +1280,25 @@ __global__ __launch_bounds__(256) void k_mimi_attn_1pass(MimiAttnArgs a) {
 // grid (chunks of 32 codes, groups of 8 rows); 256 threads: thread (c, g) owns code c0+c and row rg0+g.  The chunk of the
 // codebook and the 8 rows are staged in LDS with 16-byte accesses (row stride D+4 floats keeps ds_read_b128 conflict
 // free); the dot product runs in four independent fp64 chains.  D % 4 == 0.
-__global__ __launch_bounds__(256) void k_rvq_dist(const float* __restrict__ x, int x_rstride,
-                                                  const float* __restrict__ E, const double* __restrict__ e2,
-                                                  double* __restrict__ best_d, int* __restrict__ best_i, int Bn, int D,
-                                                  int bins) {
+// one level's operands; a launch carries two of them (grid.z / grid.y picks): the semantic quantiser's only level and the acoustic
+// quantiser's first level work on different halves of the projected latent and do not depend on each other
+// (vq.py:269-287 SplitResidualVectorQuantizer.encode), so they share their launches
+struct RvqLevel {
+    float* x;              // residual rows [Bn][x_rstride], updated in place by k_rvq_select
+    const float* E;        // codebook [bins][D]
+    const double* e2;      // ||e||^2
+    double* best_d;        // [nchunk][Bn]
+    int* best_i;
+    int level;             // column of `codes` this level writes
+};
+
+__global__ __launch_bounds__(256) void k_rvq_dist(RvqLevel l0, RvqLevel l1, int x_rstride, int Bn, int D, int bins) {
+    const RvqLevel& L = blockIdx.z == 0 ? l0 : l1;
+    const float* __restrict__ x = L.x;
+    const float* __restrict__ E = L.E;
+    const double* __restrict__ e2 = L.e2;
+    double* __restrict__ best_d = L.best_d;
+    int* __restrict__ best_i = L.best_i;
     MMI_DYN_SHARED(float, sm);
     const int ldE = D + 4;
     float* Es = sm;                          // [CHUNK][D+4]
@@ -1333,10 +1348,14 @@ __global__ __launch_bounds__(256) void k_rvq_dist(const float* __restrict__ x, i
 }
 
 // pick the winning chunk per row, emit the code, subtract the centroid from the residual
-__global__ __launch_bounds__(256) void k_rvq_select(const double* __restrict__ best_d, const int* __restrict__ best_i,
-                                                    int nchunk, float* __restrict__ x, int x_rstride,
-                                                    const float* __restrict__ E, int* __restrict__ codes,
-                                                    int codes_rstride, int level, int Bn, int D) {
+__global__ __launch_bounds__(256) void k_rvq_select(RvqLevel l0, RvqLevel l1, int nchunk, int x_rstride, int* __restrict__ codes,
+                                                    int codes_rstride, int Bn, int D) {
+    const RvqLevel& L = blockIdx.y == 0 ? l0 : l1;
+    const double* __restrict__ best_d = L.best_d;
+    const int* __restrict__ best_i = L.best_i;
+    float* __restrict__ x = L.x;
+    const float* __restrict__ E = L.E;
+    const int level = L.level;
     const int r = blockIdx.x;
     MMI_SHARED int widx;
     if (threadIdx.x < 64) {   // first wave: strided scan of the chunk winners, then a wave argmin (lowest index on ties)
