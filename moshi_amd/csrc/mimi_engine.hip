@@ -553,7 +553,8 @@ int add_resblock(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a1, ConvGemmArgs a2
 }
 
 // residual vector quantiser: latent [B][dim] (column `lat_off` of rows of length lat_ld) -> codes_i32 [B][n_q]
-int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B) {
+// latent_packed: the producer of the latent also wrote it as the packed operand m->qin_bp (ConvGemmArgs::outp): no pack launch
+int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat_ld, int lat_off, int B, bool latent_packed = false) {
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins;
     Buf in; in.p = const_cast<float*>(latent); in.C = c.dimension; in.ld = lat_ld; in.H = lat_off;
@@ -561,6 +562,7 @@ int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat
     {
         ConvGemmArgs a = conv_args(m->q_in, in, lat_off, 1, out, 0, B, false);
         a.bp = m->qin_bp; a.partial = m->qin_part;
+        a.x_packed = latent_packed ? 1 : 0;
         int rc = add_conv(m, prog, a);
         if (rc) return rc;
     }
@@ -604,14 +606,17 @@ int add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int ou
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins, nq = c.q_n_q, nsem = c.q_n_q_semantic;
     float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all; const int* kdev = k_from_device ? m->dec_k_dev : nullptr;
+    const bool packed = B <= 128 && m->q_out.Q * 8 == 2 * D && !getenv("MMI_MIMI_PACK_LAUNCHES");
+    float* qp = packed ? m->qout_bp : nullptr; const int qQ = m->q_out.Q;
     prog.add([=](hipStream_t s) {
-        MMI_LAUNCH(k_rvq_gather, mmi_cdiv(B * D, 256), 256, 0, s, codes, nq, K, E, bins, D, nsem, q2, B, kdev);
+        MMI_LAUNCH(k_rvq_gather, mmi_cdiv(B * D, 256), 256, 0, s, codes, nq, K, E, bins, D, nsem, q2, B, kdev, qp, qQ);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
     Buf in; in.p = m->q2; in.C = 2 * D; in.ld = 1; in.H = 0;
     ConvGemmArgs a = conv_args(m->q_out, in, 0, 1, out, out_off, B, false);
     a.bp = m->qout_bp; a.partial = m->qout_part;
+    a.x_packed = packed ? 1 : 0;                 // the gather wrote the operand
     return add_conv(m, prog, a);
 }
 
@@ -722,7 +727,7 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
     return MMI_OK;
 }
 
-int upload_hist(mmi_mimi* m, std::vector<HistDesc>& h, int B, HistDesc** dev, int* n, int* rows) {
+int upload_hist(mmi_mimi* m, std::vector<HistDesc>& h, int B, HistDesc** dev, int* n, int* rows, HistTable* tab = nullptr) {
     int acc = 0;
     std::vector<HistDesc> keep;
     for (auto& d : h) {
@@ -733,6 +738,11 @@ int upload_hist(mmi_mimi* m, std::vector<HistDesc>& h, int B, HistDesc** dev, in
     }
     *n = (int)keep.size();
     *rows = acc;
+    if (tab) {                                   // by-value copy for k_commit_all (n = -1: too many descriptors, two-launch path)
+        memset(tab, 0, sizeof(*tab));
+        tab->n = keep.size() <= MMI_HIST_MAX ? (int)keep.size() : -1;
+        for (size_t i = 0; i < keep.size() && i < MMI_HIST_MAX; ++i) tab->d[i] = keep[i];
+    }
     MMI_HIP_CHECK(m->st.alloc(dev, keep.size() ? keep.size() : 1));
     if (!keep.empty())
         MMI_HIP_CHECK(hipMemcpy(*dev, keep.data(), keep.size() * sizeof(HistDesc), hipMemcpyHostToDevice));
@@ -820,21 +830,30 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     if (T % stride != 0 || T / stride != 1)
         return mmi_fail(MMI_ERR_UNSUPPORTED, "frame_size must map to exactly one latent column");
     if ((rc = alloc_buf(m, B, c.dimension, 0, 1, &m->latent, s0))) return rc;
+    const bool latent_packed = B <= 128 && m->q_in.Q * 8 == c.dimension && !getenv("MMI_MIMI_PACK_LAUNCHES");
     {
         ConvGemmArgs a = conv_args(m->downsample, dsin, 0, 1, m->latent, 0, B, false);
         a.first = m->first; a.exec = m->exec;
+        if (latent_packed) { a.outp = m->qin_bp; a.outQ = m->q_in.Q; }   // the latent, also as the RVQ input projection's operand
         prog.site("enc.downsample");
         if ((rc = add_conv(m, prog, a))) return rc;
     }
     prog.site("enc.rvq");
-    if ((rc = add_quantize_ops(m, prog, m->latent.p, 1, 0, B))) return rc;
+    if ((rc = add_quantize_ops(m, prog, m->latent.p, 1, 0, B, latent_packed))) return rc;
     prog.site("enc.commit");
     // commit
-    if ((rc = upload_hist(m, hist, B, &m->enc_hist, &m->enc_nhist, &m->enc_hist_rows))) return rc;
+    HistTable tab;
+    if ((rc = upload_hist(m, hist, B, &m->enc_hist, &m->enc_nhist, &m->enc_hist_rows, &tab))) return rc;
     {
         HistDesc* hd = m->enc_hist; int nh = m->enc_nhist, rows = m->enc_hist_rows;
         const uint8_t* ex = m->exec; uint8_t* fi = m->first; long* cnt = m->counters;
+        const bool one = tab.n >= 0 && !getenv("MMI_MIMI_TWO_COMMITS");
         prog.add([=](hipStream_t s) {
+            if (one) {
+                MMI_LAUNCH(k_commit_all, mmi_cdiv(rows + B, 256), 256, 0, s, tab, rows, ex, cnt, 1, T_tr, fi, B);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            }
             if (rows > 0) MMI_LAUNCH(k_commit_history, mmi_cdiv(rows, 256), 256, 0, s, (const HistDesc*)hd, nh, rows, ex);
             MMI_LAUNCH(k_commit_counters, mmi_cdiv(B, 64), 64, 0, s, cnt, 1, T_tr, fi, ex, B);
             MMI_CHECK_LAUNCH();
@@ -888,11 +907,20 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     int mult = 1 << c.n_ratios;
     Buf cur;
     const bool hoist = !getenv("MMI_NO_ELU_HOIST");       // see build_encoder
+    float* conv0_bp = nullptr;                            // dec.conv0's output in the packed operand order of dec.convtr0's GEMM
     {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
         if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
         cur.elu = hoist;
         prog.site("dec.conv0");
-        if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false)))) return rc;
+        ConvGemmArgs a0 = conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false);
+        // its (ELU'd) output is read by the first transposed-conv GEMM only: stored as that GEMM's packed operand as well
+        const ConvW& wtr0 = m->dec_convs[ci];
+        if (hoist && B * T <= 128 && wtr0.Q * 8 == mult * c.n_filters && !getenv("MMI_MIMI_PACK_LAUNCHES")) {
+            MMI_HIP_CHECK(m->st.alloc(&conv0_bp, (size_t)mmi_cdiv(B * T, 32) * wtr0.Q * 256));
+            MMI_HIP_CHECK(hipMemsetAsync(conv0_bp, 0, (size_t)mmi_cdiv(B * T, 32) * wtr0.Q * 256 * sizeof(float), s0));
+            a0.outp = conv0_bp; a0.outQ = wtr0.Q;
+        }
+        if ((rc = add_conv(m, prog, a0))) return rc;
     }
     for (int i = 0; i < c.n_ratios; ++i) {
         const int ratio = c.ratios[i];
@@ -908,6 +936,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         {
             ConvGemmArgs a = conv_args(wtr, cur, 0, T, tmp, 0, B, true);
             a.bias = nullptr;  // bias is added once, in the combine step
+            if (i == 0 && conv0_bp) { a.bp = conv0_bp; a.x_packed = 1; }
             if ((rc = add_conv(m, prog, a))) return rc;
         }
         {
@@ -948,11 +977,18 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     prog.site("dec.final");
     if ((rc = add_conv(m, prog, conv_args(m->dec_convs[ci++], cur, 0, T, m->dec_out, 0, B, true)))) return rc;
     prog.site("dec.commit");
-    if ((rc = upload_hist(m, hist, B, &m->dec_hist, &m->dec_nhist, &m->dec_hist_rows))) return rc;
+    HistTable tab;
+    if ((rc = upload_hist(m, hist, B, &m->dec_hist, &m->dec_nhist, &m->dec_hist_rows, &tab))) return rc;
     {
         HistDesc* hd = m->dec_hist; int nh = m->dec_nhist, rows = m->dec_hist_rows;
         const uint8_t* ex = m->exec; long* cnt = m->counters + B;
+        const bool one = tab.n >= 0 && !getenv("MMI_MIMI_TWO_COMMITS");
         prog.add([=](hipStream_t s) {
+            if (one) {
+                MMI_LAUNCH(k_commit_all, mmi_cdiv(rows + B, 256), 256, 0, s, tab, rows, ex, cnt, 1, T_tr, (uint8_t*)nullptr, B);
+                MMI_CHECK_LAUNCH();
+                return (int)MMI_OK;
+            }
             if (rows > 0) MMI_LAUNCH(k_commit_history, mmi_cdiv(rows, 256), 256, 0, s, (const HistDesc*)hd, nh, rows, ex);
             MMI_LAUNCH(k_commit_counters, mmi_cdiv(B, 64), 64, 0, s, cnt, 1, T_tr, (uint8_t*)nullptr, ex, B);
             MMI_CHECK_LAUNCH();

@@ -206,14 +206,18 @@ __device__ __forceinline__ void mmi_conv_store_n(const ConvGemmArgs& a, const in
             if (ok[i]) { a.out[at[i]] = v[i]; a.out2[at[i]] = mmi_elu(v[i]); }
     } else if (a.elu_out) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (ok[i]) a.out[at[i]] = mmi_elu(v[i]);
+        for (int i = 0; i < NV; ++i) {
+            v[i] = mmi_elu(v[i]);
+            if (ok[i]) a.out[at[i]] = v[i];
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (ok[i]) a.out[at[i]] = v[i];
     }
-    // the residual stream of the Mimi transformers is also kept as the packed operand of the next fused norm + linear
+    // also stored as the packed operand of the consuming linear (what `out` holds: the ELU'd value where that is what is stored):
+    // the residual stream of the Mimi transformers for the next fused norm + linear, the decoder's first conv for the first
+    // transposed-conv GEMM, the latent for the RVQ input projection - no k_pack_b_f32 launch in between
     if (a.outp && a.out_mode == MMI_GOUT_NATURAL) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -879,6 +883,35 @@ __global__ void k_commit_history(const HistDesc* __restrict__ descs, int ndesc, 
     for (int p = 0; p < h.H; ++p) r[p] = r[p + h.T];  // ascending: source p+T is always ahead of the write
 }
 
+// Both commits of a step in ONE launch, with the descriptor table passed by value (kernel arguments: scalar loads) instead of
+// searched through global memory by every thread: threads [0, total_rows) shift the histories, the next B advance the counters.
+#define MMI_HIST_MAX 16
+struct HistTable {
+    HistDesc d[MMI_HIST_MAX];
+    int n;
+};
+__global__ void k_commit_all(HistTable tab, int total_rows, const uint8_t* __restrict__ exec, long* __restrict__ counters,
+                             int n_counters, int inc, uint8_t* __restrict__ first, int B) {
+    int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (gid >= total_rows) {
+        gid -= total_rows;
+        if (gid >= B || !exec[gid]) return;
+        for (int i = 0; i < n_counters; ++i) counters[(long)i * B + gid] += inc;
+        if (first) first[gid] = 0;
+        return;
+    }
+    int d = 0;
+#pragma unroll
+    for (int i = 1; i < MMI_HIST_MAX; ++i)
+        if (i < tab.n && tab.d[i].row_begin <= gid) d = i;
+    const HistDesc h = tab.d[d];
+    int row = gid - h.row_begin;
+    int b = row / h.C;
+    if (!exec[b]) return;
+    float* r = h.p + (long)row * h.ld;
+    for (int p = 0; p < h.H; ++p) r[p] = r[p + h.T];  // ascending: source p+T is always ahead of the write
+}
+
 // offsets[i][b] += inc where exec; first[b] = 0 where exec
 __global__ void k_commit_counters(long* __restrict__ counters, int n_counters, int inc, uint8_t* __restrict__ first,
                                   const uint8_t* __restrict__ exec, int B) {
@@ -1387,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_rvq_select(RvqLevel l0, RvqLevel l1, in
 // serves `decode` calls with any K <= n_q (the split RVQ decodes however many codebooks it is given, vq.py:281-287)
 __global__ void k_rvq_gather(const int* __restrict__ codes, int codes_rstride, int n_codes,
                              const float* __restrict__ Eall, int bins, int D, int n_sem, float* __restrict__ q, int Bn,
-                             const int* __restrict__ n_codes_dev) {
+                             const int* __restrict__ n_codes_dev, float* __restrict__ qp, int qpQ) {
     int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (idx >= Bn * D) return;
     if (n_codes_dev) n_codes = *n_codes_dev;
@@ -1401,6 +1434,10 @@ __global__ void k_rvq_gather(const int* __restrict__ codes, int codes_rstride, i
     }
     q[(long)r * 2 * D + d] = first;
     q[(long)r * 2 * D + D + d] = rest;
+    if (qp) {   // also as the packed B operand of the output projection (column = row r): no k_pack_b_f32 launch in between
+        qp[mmi_bp_index(d, r, qpQ)] = first;
+        qp[mmi_bp_index(D + d, r, qpQ)] = rest;
+    }
 }
 
 // int64 <-> int32 code tensors at the ABI boundary: [B][K][F] i64 <-> per-frame [B][K] i32
