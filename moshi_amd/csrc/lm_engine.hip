@@ -427,11 +427,15 @@ size_t packed_elems(const mmi_lm* lm, int features) {
 }
 
 // x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
+// MMI_EPI_DEP_QKV0 (the depth transformer's in_proj at micro-step 0): where its epilogue writes k / v (frame cache, position 0)
+struct DepKv { uint16_t* kc; uint16_t* vc; int H, Dh, steps; };
+
 void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
               const uint16_t* resid, const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0,
-              bool dominant = false) {
+              bool dominant = false, const DepKv* kv = nullptr) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
+    if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
     a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
@@ -473,16 +477,17 @@ void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, ui
 // RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
-                   int out_features, bool out_packed, int epi) {
+                   int out_features, bool out_packed, int epi, const DepKv* kv = nullptr) {
     const int wq = g.wq;
     const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
-        add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr);
+        add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv);
         return;
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
+    if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
     a.out_ld = out_features;
@@ -722,6 +727,14 @@ int build_program(mmi_lm* lm) {
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
             P.site("dep.in_proj");
+            // micro-step 0 attends to one position: softmax over one score is 1 and the attention output is v itself, so in_proj's
+            // epilogue writes k / v into the frame's cache and v as out_proj's operand, and the attention launch is dropped
+            // (bit-identical: 1 * v / 1; MMI_DEP_ATTN0_LAUNCH=1 keeps the launch)
+            const bool skip_attn0 = k == 0 && Dhd % 8 == 0 && !getenv("MMI_DEP_ATTN0_LAUNCH");
+            if (skip_attn0) {
+                DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
+                add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv);
+            } else
             add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
@@ -729,6 +742,7 @@ int build_program(mmi_lm* lm) {
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
             P.site("dep.attn");
             const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8 && !getenv("MMI_DEP_ATTN_OLD");
+            if (!skip_attn0)
             P.add([=](hipStream_t s) {
                 if (attn8) MMI_LAUNCH((k_dep_attn8<4>), mmi_cdiv(B * Hd, 4), 256, 0, s, da);
                 else MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);

@@ -140,7 +140,7 @@ __device__ __forceinline__ u32x2 mmi_bf16x8_to_fp8(u32x4 x, float inv) {
 // fragments from L2.  The waves' partial tiles are summed through LDS in a fixed order (deterministic), and the
 // epilogue (bf16 rounding point of nn.Linear, residual add, SiLU gate, embedding add) writes 8 consecutive features
 // of one session as one 16-byte vector.
-enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5 };
+enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5, MMI_EPI_DEP_QKV0 = 6 };
 enum { MMI_OUT_ROWMAJOR = 0, MMI_OUT_PACKED = 1 };
 
 struct GemmArgs {
@@ -304,6 +304,21 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
             f32x4 lo = {s[0], s[1], s[2], s[3]}, hi = {s[4], s[5], s[6], s[7]};
             *reinterpret_cast<f32x4*>(pd) = lo;
             *reinterpret_cast<f32x4*>(pd + 4) = hi;
+            continue;
+        }
+        if (a.epi == MMI_EPI_DEP_QKV0) {
+            // in_proj of the depth transformer's FIRST micro-step: its attention sees one position, softmax over one score is
+            // exactly 1, so the attention output IS v (1 * v / 1) - the epilogue writes k and v into position 0 of the frame's
+            // cache (transformer.py:243-253) and v as out_proj's packed operand; q is not needed; no attention launch
+            const int HD = a.H * a.Dh;
+            const int sec = n0 / HD, hn = n0 - sec * HD, h = hn / a.Dh, d0 = hn - h * a.Dh;
+            if (sec == 0) continue;
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(s[2 * e], s[2 * e + 1]);      // nn.Linear output in bf16
+            uint16_t* cache = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap) * a.Dh + d0;
+            *reinterpret_cast<u32x4*>(cache) = ov;
+            if (sec == 2) *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)) = ov;
             continue;
         }
         if (a.epi == MMI_EPI_ROPE_KV) {
