@@ -63,6 +63,29 @@ def test_small_gemms_shared_in_row_octets(sim_lib, monkeypatch, mode):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=93, B=3, S=2)
 
 
+def test_depformer_attention_launch_at_micro_step_0_is_optional(sim_lib, monkeypatch):
+    """By default the depth transformer's first micro-step has no attention launch (softmax over one position: the output is v,
+    written by in_proj's epilogue together with the frame cache); MMI_DEP_ATTN0_LAUNCH=1 keeps the launch.  Both against the
+    oracle, with one and two batch tiles and at the 16-row tile; and both forms give the same greedy tokens."""
+    import numpy as np
+    import torch
+    from moshi_amd.lm import LMGen, LMModel
+    from moshi_amd.weights import random_lm_state_dict
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=5)
+
+    def tokens():
+        gen = LMGen(LMModel(sd, cfg, device="cpu", max_batch=3, lib=sim_lib), use_sampling=False, support_out_of_sync=True)
+        rng = np.random.default_rng(0)
+        with gen.streaming(3):
+            return np.stack([gen.step(torch.from_numpy(rng.integers(0, cfg.card, (3, 8, 1)))).numpy() for _ in range(4)])
+    fused = tokens()
+    monkeypatch.setenv("MMI_DEP_ATTN0_LAUNCH", "1")
+    assert np.array_equal(tokens(), fused)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=94, B=18, S=2)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=95, B=3, S=2)
+
+
 def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
     """Two n-tiles per workgroup (`MMI_GEMM_NTW=2`, the variant the 64-session experiments use), forced onto the tiny shapes,
     with one and two batch tiles."""

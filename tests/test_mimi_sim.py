@@ -68,6 +68,15 @@ def test_fused_residual_block_with_one_two_and_four_hidden_tiles(factory, monkey
     mimi_cases.oracle_vs_engine(big, "cpu", cfg, seed=32, B=5, F=3, K=5)
     assert not any("k_resblock" in k for k in res_kernels(made[-1])) and len(res_kernels(made[-1])) == 12
 
+def test_the_ab_switches_of_the_launch_mergers_still_run_the_separate_launches(factory, monkeypatch):
+    """The A/B switches of round 2's launch mergers select the older, separate-launch forms (one RVQ level per launch pair, pack
+    launches in front of the RVQ projections and the first transposed-conv GEMM, two commit launches, dense buffer rows): both forms
+    must give the oracle's codes and PCM."""
+    for var in ("MMI_RVQ_NO_PAIR", "MMI_MIMI_PACK_LAUNCHES", "MMI_MIMI_TWO_COMMITS", "MMI_MIMI_NO_ALIGN"):
+        monkeypatch.setenv(var, "1")
+    mimi_cases.oracle_vs_engine(factory, "cpu", tiny_mimi_config(), seed=41, B=3, F=4, K=5)
+
+
 @pytest.mark.parametrize("heads,two_pass", [(2, False), (4, False), (2, True)])
 def test_attention_head_dims_and_ring_wrap(factory, monkeypatch, heads, two_pass):
     """Head dims 64 / 32 (the tiny codec has 16) through the one-round-trip attention kernel and its two-pass fallback,
