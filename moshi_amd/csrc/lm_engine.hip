@@ -649,6 +649,7 @@ int build_program(mmi_lm* lm) {
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
+        a.mirror = getenv("MMI_ATTN_MIRROR") ? atoi(getenv("MMI_ATTN_MIRROR")) : 0;
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;

@@ -1107,6 +1107,7 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
+    int mirror;            // k_lm_attn_split: walk every second group of 8 sessions backwards (load balance across CUs)
 };
 
 #define MMI_ATTN_CHUNK 256
@@ -1124,7 +1125,18 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     constexpr int LPR = DH / EPL;      // lanes per row
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
     constexpr int CH = MMI_ATTN_CHUNK;
-    const int bh = blockIdx.x, b = bh / a.H;
+    // Which (session, head) a workgroup takes.  Workgroups are placed round-robin, so blocks i, i + 256, i + 512, ... share a CU
+    // and a CU's time is the sum of its sessions' ring depths; sessions admitted one after the other have depths that grow with
+    // the index (the benchmark's 8-frame stagger: 40..290 rows), and the plain order gives CU i the sessions i/32, i/32 + 8, ...
+    // - 17 % more rows on the heaviest CU than on the average one.  Every second group of 8 sessions is therefore walked
+    // backwards (b0, 15 - b0, 16 + b0, 31 - b0: equal sums for any linear profile, no worse for a random one).  A pure
+    // relabelling: results identical.
+    int bh = blockIdx.x;
+    if (a.mirror) {
+        const int bb = bh / a.H, g = bb >> 3;
+        if ((g & 1) && g * 8 + 7 < a.B) bh = (g * 8 + 7 - (bb & 7)) * a.H + (bh - bb * a.H);
+    }
+    const int b = bh / a.H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long off = a.offsets[b];
     const long end_new = off + 1;
