@@ -40,6 +40,9 @@ def parse():
                     help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears widened to bf16 in registers; fp8 = e4m3 linears on the fp8 MFMA")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "fp8"], help="KV ring of the temporal transformer: the reference's bf16, or e4m3 (half the attention stream)")
     ap.add_argument("--launch-lists", default="", help="directory to write the step's launch lists (site per kernel launch) into, for scripts/rocpd_sites.py")
+    ap.add_argument("--serial", action="store_true",
+                    help="duplex workload: the reference's serving loop on ONE stream (encode -> step -> decode back to back) instead of "
+                         "the three-stream pipeline of mmi_duplex_* (encode(t+1) and decode(t-1) under LMGen.step(t))")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
     return ap.parse_args()
 
@@ -243,6 +246,13 @@ def main():
     pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
     user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)
 
+    # the duplex step is software-pipelined by default (moshi_amd/duplex.py): frames are submitted back to back, each model keeps
+    # its own stream order (bit-identical results, tests/duplex_cases.py), and the codec runs in the shadow of the LM
+    dup = None
+    if workload == "duplex" and not args.serial:
+        from moshi_amd.duplex import DuplexStream
+        dup = DuplexStream(mimi, lm_gen)
+
     def step():
         nonlocal user_codes
         if workload == "mimi":
@@ -250,13 +260,20 @@ def main():
             return mimi.decode(codes)
         if workload == "lm":
             return lm_gen.step(user_codes)
+        if dup is not None:
+            return dup.step(pcm, want_tokens=False)[1]
         codes = mimi.encode(pcm)
         tokens = lm_gen.step(codes)
         if tokens is None:
             return None
-        return mimi.decode(tokens[:, 1:])      # the -2 "not yet valid" rows are clamped by the decoder's own gather kernel
+        return mimi.decode(tokens[:, 1:])      # read in place (strided); the -2 "not yet valid" rows are clamped by the decoder's gather
+
+    def join():
+        if dup is not None:
+            dup.join()
 
     def sync():
+        join()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -264,13 +281,14 @@ def main():
     staggered = 0
     if lm_gen is not None:
         from bench_lm import stagger
-        staggered = stagger(mimi if workload == "duplex" else None, lm_gen, step, B, args.stagger, dev)
+        staggered = stagger(mimi if workload == "duplex" else None, lm_gen, step, B, args.stagger, dev, before_mask=join)
     for _ in range(args.warmup):
         step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    join()
     torch.cuda.synchronize(dev)
     dt = job_time(time.perf_counter() - t0, dist, dev)
     if dist is not None:
@@ -291,25 +309,43 @@ def main():
             (d / f"launch_list_{k}.tsv").write_text("".join(f"{s_}\t{kn}\n" for s_, kn in v))
 
     # p50 / p95 latency of a single step (BASELINE.json's second figure): a separate, untimed-for-`value` pass with a
-    # device event before and after every step and no host synchronisation inside the loop
+    # device event before and after every step and no host synchronisation inside the loop.  Pipelined: every frame is joined
+    # before the next is submitted, so the figure is PCM-in -> PCM-out of ONE frame with nothing else in flight (what a
+    # session waits for), not the steady-state step interval `ms_per_step` reports.
     n_lat = max(8, min(args.steps, 40))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
+    join()
     for a_ev, b_ev in evs:
         a_ev.record()
         step()
+        join()
         b_ev.record()
     torch.cuda.synchronize(dev)
     lat = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
     p50, p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
+    p50_ranks, p95_ranks = [p50], [p95]
+    if dist is not None:                       # the metric is the job's latency: MAX over ranks, per-rank figures alongside
+        t = torch.tensor([p50, p95], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        p50_ranks, p95_ranks = [float(x[0]) for x in allr], [float(x[1]) for x in allr]
+        p50, p95 = max(p50_ranks), max(p95_ranks)
     out = {
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50_ranks, "p95_ms_per_rank": p95_ranks,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"none": "bf16", "q8": "bf16 x int8 weights", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
                                 "lm": "Moshi-7B LMGen.step (BASELINE configs[2])"}[workload],
                    "sessions_per_gpu": B, "parallelism": f"dp{world} (independent sessions, no collective)",
+                   "pipelined": dup is not None,
+                   "schedule": ("three HIP streams (encoder / LM / decoder) + events: encode(t+1) and decode(t-1) run under LMGen.step(t); "
+                                "ms_per_step = steady-state interval between frames of the 32-session batch, p50/p95 = one frame alone, "
+                                "PCM in -> PCM out; outputs bit-identical to the serial loop (tests/test_duplex_gpu.py)") if dup is not None
+                               else "one stream: encode -> step -> decode back to back (server.py:132-146)",
+                   "rvq": "exact fp64 argmin of ||x - e||^2 (equals the reference's fp32 cdist argmin except at fp32 near-ties: 16 of 131072 decisions, profiles/r02_logs/parity_rvq_indices_z.json)",
                    "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model" + {"none": "", "q8": ", LM linears row-wise int8", "fp8": ", LM linears row-wise e4m3"}[args.quant],
                    "sampling": "temp .8/.7 top-k 250/25 (LMGen defaults), on-device RNG",
                    "kv_cache": args.kv,

@@ -49,22 +49,25 @@ def make_lm(dev, B, args, streaming=True):
     return gen
 
 
-def stagger(mimi, lm_gen, step_fn, B, frames_apart, dev):
-    """sessions start staggered (row b has run frames_apart*b frames when timing starts)."""
+def stagger(mimi, lm_gen, step_fn, B, frames_apart, dev, before_mask=None):
+    """sessions start staggered (row b has run frames_apart*b frames when timing starts).
+    before_mask: called before every mask change (the pipelined step joins its streams there)."""
     if frames_apart <= 0 or B == 1:
         return 0
     n = frames_apart * (B - 1)
     rows = torch.arange(B, device=dev)
-    for f in range(n):
-        mask = rows >= (B - 1 - f // frames_apart)
+
+    def set_mask(mask):
+        if before_mask is not None:
+            before_mask()
         if mimi is not None:
             mimi.set_exec_mask(mask)
         lm_gen.set_exec_mask(mask)
+    for f in range(n):
+        if f % frames_apart == 0:
+            set_mask(rows >= (B - 1 - f // frames_apart))
         step_fn()
-    ones = torch.ones(B, dtype=torch.bool, device=dev)
-    if mimi is not None:
-        mimi.set_exec_mask(ones)
-    lm_gen.set_exec_mask(ones)
+    set_mask(torch.ones(B, dtype=torch.bool, device=dev))
     return n
 
 

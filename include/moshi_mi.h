@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MMI_ABI_VERSION 2
+#define MMI_ABI_VERSION 3
 
 typedef enum mmi_status {
     MMI_OK = 0,
@@ -110,6 +110,8 @@ int mmi_mimi_num_codebooks(const mmi_mimi* m);
  * zero the streaming state of `batch` rows; exec mask all ones. */
 int mmi_mimi_streaming_start(mmi_mimi* m, int32_t batch, mmi_stream stream);
 int mmi_mimi_streaming_stop(mmi_mimi* m);
+/* Rows of the current stream (StreamingModule._streaming_state.batch_size); 0 when not streaming. */
+int mmi_mimi_streaming_batch(const mmi_mimi* m);
 
 /* StreamingModule.set_exec_mask (streaming.py:183-211): mask = device uint8[batch]. */
 int mmi_mimi_set_exec_mask(mmi_mimi* m, const uint8_t* mask, mmi_stream stream);
@@ -143,6 +145,11 @@ int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* latent, int
  * codes i64 [batch,K,n_frames] (values in [0,bins)) -> pcm f32 [batch,1,n_frames*frame_size]. */
 int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pcm, int32_t batch, int32_t n_codebooks,
                          int32_t n_frames, mmi_stream stream);
+/* The same for a strided view: codes[b * batch_stride + k * n_frames + f].  What `mimi.decode(tokens[:, 1:])` is in the
+ * reference's serving loop (server.py:144-146: the audio columns of LMGen.step's [B, 1 + dep_q, 1] output) - the view is read
+ * in place, batch_stride = (1 + dep_q) * n_frames there. */
+int mmi_mimi_decode_step_strided(mmi_mimi* m, const int64_t* codes, int64_t batch_stride, float* pcm, int32_t batch,
+                                 int32_t n_codebooks, int32_t n_frames, mmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Moshi LM (Temporal + Depth transformer) and LMGen                                          */
@@ -225,6 +232,8 @@ typedef struct mmi_guidance {
 int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mmi_sampling* sampling, const mmi_guidance* guide_or_null,
                                   mmi_stream stream);
 int mmi_lm_model_rows(const mmi_lm* lm);
+/* Sessions of the current stream (rows of the caller's tensors); 0 when not streaming. */
+int mmi_lm_streaming_batch(const mmi_lm* lm);
 /* A handle binds to the HIP device that is current when it is created (weights, state, streams and graphs live there); every
  * entry point switches the calling thread to that device for the call and restores the caller's.  Pointers passed in must be
  * on that device.  mmi_*_device return the ordinal. */
@@ -257,6 +266,13 @@ int mmi_lm_reset(mmi_lm* lm, const uint8_t* mask_or_null, mmi_stream stream);   
 int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user, int64_t* out_tokens,
                 float* opt_text_logits, float* opt_audio_logits, const float* opt_noise, int32_t batch,
                 int32_t* valid, mmi_stream stream);
+
+/* Phase callback (no reference counterpart; used by the duplex pipeline below): a host function that every following
+ * mmi_lm_step calls, on the calling thread, between the temporal transformer + text head (chip-filling, HBM-bound GEMMs) and
+ * the depth transformer (dep_q x 33 small dependent launches that leave most CUs idle), with the step's stream: what it
+ * enqueues there marks the point from which other streams can run beside the step without costing it.  A non-zero return
+ * aborts the step.  NULL clears. */
+int mmi_lm_set_phase_callback(mmi_lm* lm, int (*fn)(void* user, mmi_stream stream), void* user);
 
 /* LMGen's per-step hooks (lm.py:568-570, 734-747): host callbacks between the stages of a step, each of which may READ and
  * MODIFY IN PLACE what the reference's hook receives (the TTS wrapper forces text tokens this way, models/tts.py):
@@ -310,6 +326,39 @@ int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t
 /* Architecture the handle was created with (what callers read as attributes: frame_size, num_codebooks, dep_q ...). */
 int mmi_mimi_get_cfg(const mmi_mimi* m, mmi_mimi_cfg* out);
 int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Duplex pipeline: the frame step  encode -> LMGen.step -> decode  software-pipelined        */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's serving loop runs the three calls of a frame back to back on one stream (server.py:132-146).  Their
+ * streaming states are disjoint: encode(t+1) depends on encode(t) only, decode(t) on LMGen.step(t) and decode(t-1).  A duplex
+ * pipeline owns three HIP streams (encoder, LM, decoder) and the events between them, so that - when frames are submitted
+ * back to back (offline inference, several session groups per GPU, a loaded server) - encode(t+1) and decode(t-1) run in the
+ * shadow of LMGen.step(t), whose depth-transformer phase leaves most CUs idle.  Results are bit-identical to the serial
+ * schedule (same kernels, same per-stream order).  Nothing synchronises the host.
+ *
+ *   mmi_duplex_submit   frame t: pcm_in f32 [batch, 1, frame_size] -> pcm_out f32 [batch, 1, frame_size] (written when the
+ *                       frame's decode ran; untouched while *valid == 0, i.e. where LMGen.step returns None) and, optionally,
+ *                       tokens_out i64 [batch, 1 + dep_q, 1] (LMGen.step's output, -2 rows included).  Work submitted on
+ *                       `caller` before the call is ordered before the frame (inputs, set_exec_mask / reset_streaming issued
+ *                       on the handles with that stream after a mmi_duplex_join).  At most two frames are in flight: the call
+ *                       blocks the host until frame t-2 has completed.  pcm_in must stay untouched until two further submits
+ *                       (or a join) and pcm_out / tokens_out unread until a mmi_duplex_join on the consuming stream.
+ *   mmi_duplex_join     makes `caller` wait (device side) for every frame submitted so far.
+ * Both handles must be streaming with the same batch before mmi_duplex_create and must not be driven through their own
+ * step entry points between a submit and the next join. */
+typedef struct mmi_duplex mmi_duplex;
+int mmi_duplex_create(mmi_mimi* mimi, mmi_lm* lm, mmi_duplex** out);
+void mmi_duplex_destroy(mmi_duplex* d);
+int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out_or_null, int32_t* valid,
+                      mmi_stream caller);
+int mmi_duplex_join(mmi_duplex* d, mmi_stream caller);
+/* Diagnostics: with the timeline on, every submit records timestamps around the frame's three phases on their streams;
+ * mmi_duplex_get_timeline synchronises the pipeline and returns, for the LAST submitted frame whose decode was enqueued, ms since
+ * the submit reached the caller's stream: {encode begin, encode end, LM begin, -, LM end, decode begin, decode end} (host f32[7]);
+ * entries of phases that did not run are -1. */
+int mmi_duplex_set_timeline(mmi_duplex* d, int32_t on);
+int mmi_duplex_get_timeline(mmi_duplex* d, float* ms7);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Session batcher: many live dialogue sessions on one GPU                                    */

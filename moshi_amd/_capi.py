@@ -96,6 +96,15 @@ SIGNATURES = {
     "mmi_mimi_quantize": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mmi_mimi_decode_latent": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mmi_mimi_decode_step": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mmi_mimi_decode_step_strided": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mmi_mimi_streaming_batch": (C.c_int, [_P]),
+    "mmi_lm_streaming_batch": (C.c_int, [_P]),
+    "mmi_duplex_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "mmi_duplex_destroy": (None, [_P]),
+    "mmi_duplex_submit": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    "mmi_duplex_join": (C.c_int, [_P, _P]),
+    "mmi_duplex_set_timeline": (C.c_int, [_P, C.c_int32]),
+    "mmi_duplex_get_timeline": (C.c_int, [_P, _P]),
     "mmi_lm_create": (C.c_int, [C.POINTER(LMCfg), C.POINTER(TensorDesc), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "mmi_lm_destroy": (None, [_P]),
     "mmi_lm_streaming_start": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), _P]),
@@ -116,6 +125,7 @@ SIGNATURES = {
     "mmi_lm_reset": (C.c_int, [_P, _P, _P]),
     "mmi_lm_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     "mmi_lm_force_next_tokens": (C.c_int, [_P, _P, _P]),
+    "mmi_lm_set_phase_callback": (C.c_int, [_P, _P, _P]),
     "mmi_lm_set_hooks": (C.c_int, [_P, C.POINTER(LMHooks)]),
     "mmi_lm_hook_io": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "mmi_mimi_get_cfg": (C.c_int, [_P, C.POINTER(MimiCfg)]),

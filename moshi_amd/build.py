@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 ROOT = PKG.parent
 LIB = PKG / "libmoshi_mi.so"
-SOURCES = ["api_common.hip", "mimi_engine.hip", "lm_engine.hip", "batcher.hip"]
+SOURCES = ["api_common.hip", "mimi_engine.hip", "lm_engine.hip", "batcher.hip", "duplex.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,309 @@
+// Duplex pipeline behind the C ABI (include/moshi_mi.h, "Duplex pipeline"): the frame step
+//     MimiModel.encode -> LMGen.step -> MimiModel.decode            (moshi/moshi/server.py:132-146)
+// with the three calls of consecutive frames overlapped on three HIP streams.  Like batcher.hip this file uses nothing of the
+// engines but the public entry points: the engines take a stream per call, so the pipeline is streams + hand-offs around them.
+//
+// Dependencies of frame t (E = encoder stream, L = LM stream, D = decoder stream):
+//     E: encode(t)      after encode(t-1) [stream order]
+//     L: LMGen.step(t)  after step(t-1)   [stream order]      and after encode(t)
+//     D: decode(t)      after decode(t-1) [stream order]      and after LMGen.step(t)
+// The user codes and the step's tokens are handed over through two-slot rings indexed by frame parity; a slot is reused by frame
+// t+2, which the host only enqueues once LMGen.step(t) has completed (flow control in mmi_duplex_submit).
+//
+// Gate (default on): the temporal transformer's GEMMs are chip-filling, HBM-bound launches with one workgroup per CU and a
+// static tile partition - a codec workgroup that takes a CU for 10 us makes such a launch 10 us late.  The depth-transformer
+// phase (1.6 of the LM's 5.7 ms at 32 sessions) is dep_q x 33 small dependent launches on 32-192 of the 256 CUs.  So the codec
+// work of the neighbouring frames - decode(t-1), encode(t+1): 1.5 ms of latency-bound launches - is held until step t reaches
+// that phase (mmi_lm_set_phase_callback) and runs in its shadow.
+//
+// Hand-offs between streams are counters in device memory, published by a one-thread kernel and polled by a one-wave kernel
+// (mmi_device.h mmi_flag_*), NOT hipStreamWaitEvent: on this stack a wait that stays pending makes the command processor poll
+// the producer queue's signal and slows every dependent launch of the producer by ~1.2 us (scripts/stream_probe.hip test 1e:
+// 1.60 -> 2.77 ms per 1000 launches; a resident polling wave: 1.71 ms) - the decoder stream waiting for a 487-launch LM step
+// cost that step 0.6 ms.  Events remain where the wait is already satisfied when the queue reaches it, and for the host.
+#include "mmi_common.h"
+
+namespace {
+
+__global__ void k_flag_publish(long* flag, long v) { mmi_flag_publish(flag, v); }
+__global__ void k_flag_wait(const long* flag, long v) {
+    if (threadIdx.x == 0) mmi_flag_wait(flag, v);
+}
+
+struct Pending { bool live = false, valid = false; float* pcm_out = nullptr; int64_t* tokens_out = nullptr; long frame = 0; };
+
+enum { F_ENC = 0, F_LM = 1, F_PHASE = 2, F_DEC = 3, F_IN = 4, F_COUNT = 5 };
+
+}  // namespace
+
+struct mmi_duplex {
+    mmi_mimi* mimi = nullptr;
+    mmi_lm* lm = nullptr;
+    int device = -1;
+    int B = 0, F = 0, K = 0, dep_q = 0, NTOK = 0;
+    hipStream_t sE = nullptr, sL = nullptr, sD = nullptr;
+    hipEvent_t ev_lm[2] = {nullptr, nullptr};      // host flow control: LMGen.step(t) done (never waited on by a stream)
+    hipEvent_t ev_dec[2] = {nullptr, nullptr};     // decode(t) done: waited on by L two frames later, when it has long completed
+    long* flags = nullptr;                         // [F_COUNT][16] device counters, one cache line each: frames completed per phase
+    int gate = 3;                                  // bit 0: encode(t+1), bit 1: decode(t-1) held until step t reaches its depth-transformer
+                                                   // phase (MMI_DUPLEX_GATE = 0..3; 0: as soon as they can)
+    bool use_events = false;                       // MMI_DUPLEX_EVENTS=1: hipStreamWaitEvent hand-offs instead of the flags (A/B)
+    hipEvent_t ev_x[F_COUNT][2];                   // the event form of the flags
+    long phase_frame = 0;                          // frame whose phase the callback publishes
+    bool host_gate = true;                         // the gate is kept by the HOST: submit(t) returns to enqueueing only once step t-1 has
+                                                   // reached its phase (ev_phase), so the gated work needs no device-side wait at all -
+                                                   // no polling wave sits on the codec queues through the LM's temporal phase
+                                                   // (MMI_DUPLEX_HOSTGATE=0: device-side, through the F_PHASE flag)
+    hipEvent_t ev_phase[2] = {nullptr, nullptr};
+    // diagnostic timeline (mmi_duplex_set_timeline): timestamps of the last frame's phases
+    bool timeline = false;
+    hipEvent_t tl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // in, enc0, enc1, lm0, -, lm1, dec0, dec1
+    Pending pend[2];                               // a frame's decode, enqueued by the NEXT submit (behind that step's phase) or by join
+    int64_t* codes[2] = {nullptr, nullptr};        // [B][K][1]         encoder -> LM
+    int64_t* tokens[2] = {nullptr, nullptr};       // [B][1 + dep_q][1] LM -> decoder
+    long frame = 0;
+};
+
+namespace {
+
+long* flag_of(mmi_duplex* d, int which) { return d->flags + 16 * which; }
+
+// producer side: frame `t` of phase `which` is complete once everything enqueued on s so far has run
+int publish(mmi_duplex* d, int which, long t, hipStream_t s) {
+    if (d->use_events) {
+        MMI_HIP_CHECK(hipEventRecord(d->ev_x[which][t & 1], s));
+        return MMI_OK;
+    }
+    MMI_LAUNCH(k_flag_publish, 1, 1, 0, s, flag_of(d, which), t + 1);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+// consumer side: s goes on once frame `t` of phase `which` is complete
+int await(mmi_duplex* d, int which, long t, hipStream_t s) {
+    if (d->use_events) {
+        MMI_HIP_CHECK(hipStreamWaitEvent(s, d->ev_x[which][t & 1], 0));
+        return MMI_OK;
+    }
+    MMI_LAUNCH(k_flag_wait, 1, 64, 0, s, (const long*)flag_of(d, which), t + 1);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+int phase_callback(void* user, mmi_stream stream) {
+    mmi_duplex* d = (mmi_duplex*)user;
+    if (d->host_gate) {
+        MMI_HIP_CHECK(hipEventRecord(d->ev_phase[d->phase_frame & 1], (hipStream_t)stream));
+        return MMI_OK;
+    }
+    return publish(d, F_PHASE, d->phase_frame, (hipStream_t)stream);
+}
+
+void release(mmi_duplex* d) {
+    if (d->flags) {      // a step that failed half-way may have left a polling wave without its producer: let every waiter through
+        std::vector<long> big((size_t)F_COUNT * 16, (long)1 << 62);
+        hipMemcpy(d->flags, big.data(), big.size() * sizeof(long), hipMemcpyHostToDevice);
+    }
+    for (hipStream_t s : {d->sE, d->sL, d->sD})
+        if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+    for (int i = 0; i < 2; ++i) {
+        if (d->ev_lm[i]) hipEventDestroy(d->ev_lm[i]);
+        if (d->ev_dec[i]) hipEventDestroy(d->ev_dec[i]);
+        if (d->ev_phase[i]) hipEventDestroy(d->ev_phase[i]);
+        for (int w = 0; w < F_COUNT; ++w)
+            if (d->ev_x[w][i]) hipEventDestroy(d->ev_x[w][i]);
+        if (d->codes[i]) hipFree(d->codes[i]);
+        if (d->tokens[i]) hipFree(d->tokens[i]);
+    }
+    if (d->flags) hipFree(d->flags);
+    for (hipEvent_t e : d->tl) if (e) hipEventDestroy(e);
+    delete d;
+}
+
+int create_impl(mmi_duplex* d) {
+    mmi_mimi_cfg mc;
+    mmi_lm_cfg lc;
+    int rc;
+    if ((rc = mmi_mimi_get_cfg(d->mimi, &mc)) || (rc = mmi_lm_get_cfg(d->lm, &lc))) return rc;
+    d->B = mmi_mimi_streaming_batch(d->mimi);
+    if (d->B <= 0 || mmi_lm_streaming_batch(d->lm) <= 0)
+        return mmi_fail(MMI_ERR_STATE, "mmi_duplex_create: both models must be streaming");                // lm.py:673-676
+    if (d->B != mmi_lm_streaming_batch(d->lm)) return mmi_fail(MMI_ERR_SHAPE, "the codec and the LM stream different batch sizes");
+    d->F = mc.frame_size * mc.channels;
+    d->K = mmi_mimi_num_codebooks(d->mimi);
+    d->dep_q = lc.dep_q;
+    d->NTOK = 1 + lc.dep_q;
+    if (d->K < lc.n_q - lc.dep_q)
+        return mmi_fail(MMI_ERR_SHAPE, "the codec produces fewer codebooks than the LM expects from the user stream");   // lm.py:683-686
+    if (lc.dep_q < 1 || lc.dep_q > mc.q_n_q) return mmi_fail(MMI_ERR_SHAPE, "the LM must generate between 1 and n_q codebooks for the codec");
+    if (mc.q_bins != lc.card) return mmi_fail(MMI_ERR_SHAPE, "codec cardinality != LM card");
+    // Stream priorities.  Streams of one priority share a pool of GPU_MAX_HW_QUEUES (4) hardware queues with everything else the
+    // process created at that priority, and two streams that land on one queue do not overlap (profiles/r03_logs: the encoder
+    // and the LM shared queue 4 without priorities).  The codec streams get the high-priority pool: distinct queues, and their
+    // short latency-bound launches win arbitration against the bulk LM stream.  (A/B: MMI_DUPLEX_PRIO = "0" none, "lm", "mimi")
+    int lo = 0, hi = 0;
+    const char* e = getenv("MMI_DUPLEX_PRIO");
+    const std::string mode = e && e[0] ? e : "mimi";
+    const bool have = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
+    if (have && mode == "tri" && hi + 2 <= lo) {      // encoder high, LM normal, decoder low: three pools, three queues
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, hi + 1));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, hi));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, lo));
+    } else if (have && mode != "0") {
+        const int pl = mode == "lm" ? hi : lo, pm = mode == "lm" ? lo : hi;
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, pl));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, pm));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, pm));
+    } else {
+        MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sL, hipStreamNonBlocking));
+        MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sE, hipStreamNonBlocking));
+        MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sD, hipStreamNonBlocking));
+    }
+    if (const char* g = getenv("MMI_DUPLEX_GATE")) d->gate = atoi(g) & 3;
+    if (const char* g = getenv("MMI_DUPLEX_EVENTS")) d->use_events = g[0] == '1';
+    if (const char* g = getenv("MMI_DUPLEX_HOSTGATE")) d->host_gate = g[0] != '0';
+    if (!d->gate) d->host_gate = false;
+    MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)F_COUNT * 16 * sizeof(long)));
+    MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)F_COUNT * 16 * sizeof(long)));
+    for (int i = 0; i < 2; ++i) {
+        MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_lm[i], hipEventDisableTiming));
+        MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
+        MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_phase[i], hipEventDisableTiming));
+        for (int w = 0; w < F_COUNT; ++w) MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_x[w][i], hipEventDisableTiming));
+        MMI_HIP_CHECK(hipMalloc((void**)&d->codes[i], (size_t)d->B * d->K * sizeof(int64_t)));
+        MMI_HIP_CHECK(hipMalloc((void**)&d->tokens[i], (size_t)d->B * d->NTOK * sizeof(int64_t)));
+    }
+    return MMI_OK;
+}
+
+// decode(t) of the audio columns of step t's output, read in place; rows still inside the LM's delay hold -2, which the
+// decoder's gather clamps into the codebook exactly where the reference would index unchecked (vq.py:144-146).
+// gate_frame >= 0: not before LMGen.step(gate_frame) has reached its depth-transformer phase.
+int enqueue_decode(mmi_duplex* d, int p, long gate_frame) {
+    Pending& q = d->pend[p];
+    if (!q.live) return MMI_OK;
+    int rc;
+    // gate_frame -2: the host has seen the step complete (no device-side wait); -1: behind the step itself; >= 0: behind the
+    // phase of step gate_frame (which implies step gate_frame - 1)
+    if (gate_frame > -2 && (rc = await(d, gate_frame >= 0 ? F_PHASE : F_LM, gate_frame >= 0 ? gate_frame : q.frame, d->sD))) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[6], d->sD));
+    if (q.tokens_out)
+        MMI_HIP_CHECK(hipMemcpyAsync(q.tokens_out, d->tokens[p], (size_t)d->B * d->NTOK * sizeof(int64_t), hipMemcpyDeviceToDevice, d->sD));
+    if (q.valid && (rc = mmi_mimi_decode_step_strided(d->mimi, d->tokens[p] + 1, d->NTOK, q.pcm_out, d->B, d->dep_q, 1, d->sD))) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[7], d->sD));
+    if ((rc = publish(d, F_DEC, q.frame, d->sD))) return rc;
+    MMI_HIP_CHECK(hipEventRecord(d->ev_dec[p], d->sD));
+    q.live = false;
+    return MMI_OK;
+}
+
+}  // namespace
+
+extern "C" int mmi_duplex_create(mmi_mimi* mimi, mmi_lm* lm, mmi_duplex** out) {
+    MmiDeviceGuard dev_guard_(lm ? mmi_lm_device(lm) : -1);
+    if (!mimi || !lm || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (mmi_lm_device(lm) != mmi_mimi_device(mimi)) return mmi_fail(MMI_ERR_INVALID, "the codec and the LM live on different devices");
+    mmi_duplex* d = new mmi_duplex();
+    memset(d->ev_x, 0, sizeof(d->ev_x));
+    d->mimi = mimi;
+    d->lm = lm;
+    d->device = mmi_lm_device(lm);
+    int rc = create_impl(d);
+    if (rc) {
+        release(d);
+        return rc;
+    }
+    *out = d;
+    return MMI_OK;
+}
+
+extern "C" void mmi_duplex_destroy(mmi_duplex* d) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (d) release(d);
+}
+
+extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out, int32_t* valid,
+                                 mmi_stream caller) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d || !pcm_in || !pcm_out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    const long t = d->frame;
+    const int p = (int)(t & 1);
+    int rc;
+    // flow control: the host runs at most two LM steps ahead of the device.  It blocks here until LMGen.step(t-2) - the previous
+    // writer of ring slot p - has completed, which also bounds the lifetime the caller owes its pcm_in buffers.
+    if (t >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
+    // host-kept gate: the frame is enqueued once LMGen.step(t-1) has reached its depth-transformer phase
+    if (d->host_gate && t >= 1) MMI_HIP_CHECK(hipEventSynchronize(d->ev_phase[p ^ 1]));
+    // everything the caller enqueued so far (the frame's input; mask / reset calls made after a join) comes first: the encoder
+    // waits for it, and the LM and the decoder of this frame wait for the encoder
+    if ((rc = publish(d, F_IN, t, (hipStream_t)caller))) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[0], (hipStream_t)caller));
+    if ((rc = await(d, F_IN, t, d->sE))) return rc;
+    // ---- E: encode(t) into codes slot p.  Gated: not before the LM step in flight (t-1) has reached its depth-transformer phase
+    if (!d->host_gate && (d->gate & 1) && t >= 1 && (rc = await(d, F_PHASE, t - 1, d->sE))) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[1], d->sE));
+    if ((rc = mmi_mimi_encode_step(d->mimi, pcm_in, d->codes[p], d->B, 1, d->sE))) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[2], d->sE));
+    if ((rc = publish(d, F_ENC, t, d->sE))) return rc;
+    // ---- L: LMGen.step(t) into tokens slot p, whose last reader decode(t-2) was enqueued by an earlier submit (long done)
+    // host-kept gate: decode(t-2) - step t-2 is complete, step t-1 in its depth-transformer phase - goes out now, ahead of the
+    // step that will overwrite its tokens slot
+    if (d->host_gate && (rc = enqueue_decode(d, p, -2))) return rc;
+    if ((rc = await(d, F_ENC, t, d->sL))) return rc;
+    if (t >= 2) MMI_HIP_CHECK(hipStreamWaitEvent(d->sL, d->ev_dec[p], 0));
+    int ok = 0;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[3], d->sL));
+    d->phase_frame = t;
+    if (d->gate && (rc = mmi_lm_set_phase_callback(d->lm, phase_callback, d))) return rc;
+    rc = mmi_lm_step(d->lm, d->codes[p], d->K, d->tokens[p], nullptr, nullptr, nullptr, d->B, &ok, d->sL);
+    if (d->gate) mmi_lm_set_phase_callback(d->lm, nullptr, nullptr);
+    if (rc) return rc;
+    if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[5], d->sL));
+    if ((rc = publish(d, F_LM, t, d->sL))) return rc;
+    MMI_HIP_CHECK(hipEventRecord(d->ev_lm[p], d->sL));
+    d->pend[p] = Pending{true, ok != 0, pcm_out, tokens_out, t};
+    // ---- D: gated, decode(t-1) runs beside the depth-transformer phase of step t; ungated, decode(t) follows step t directly
+    if (d->host_gate) {
+        // nothing: this frame's decode is enqueued by submit(t+2), or by join
+    } else if (d->gate & 2) {
+        if ((rc = enqueue_decode(d, p ^ 1, t))) return rc;
+    } else if ((rc = enqueue_decode(d, p, -1))) return rc;
+    if (valid) *valid = ok;
+    d->frame += 1;
+    return MMI_OK;
+}
+
+extern "C" int mmi_duplex_join(mmi_duplex* d, mmi_stream caller) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (d->frame == 0) return MMI_OK;
+    const long t = d->frame - 1;                  // the last frame: everything earlier precedes it on each stream
+    const int p = (int)(t & 1);
+    int rc;
+    if ((rc = enqueue_decode(d, p ^ 1, -1)) || (rc = enqueue_decode(d, p, -1))) return rc;     // a decode still held back for its gate: now
+    hipStream_t s = (hipStream_t)caller;
+    if ((rc = await(d, F_DEC, t, s))) return rc;  // decode(t) implies step(t) implies encode(t)
+    return MMI_OK;
+}
+
+extern "C" int mmi_duplex_set_timeline(mmi_duplex* d, int32_t on) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (on && !d->tl[0])
+        for (hipEvent_t& e : d->tl) MMI_HIP_CHECK(hipEventCreate(&e));
+    d->timeline = on != 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_duplex_get_timeline(mmi_duplex* d, float* ms) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d || !ms) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!d->timeline || d->frame == 0) return mmi_fail(MMI_ERR_STATE, "no frame was submitted with the timeline on");
+    for (hipStream_t s : {d->sE, d->sL, d->sD}) MMI_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 1; i < 8; ++i) {
+        ms[i - 1] = -1.f;
+        if (i == 4) continue;
+        if (hipEventElapsedTime(&ms[i - 1], d->tl[0], d->tl[i]) != hipSuccess) ms[i - 1] = -1.f;
+    }
+    (void)hipGetLastError();
+    return MMI_OK;
+}

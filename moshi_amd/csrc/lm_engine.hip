@@ -101,6 +101,9 @@ struct mmi_lm {
     mmi_lm_hooks hooks{nullptr, nullptr, nullptr, nullptr};
     bool in_hook = false;
     size_t op_text_sample = 0, op_after_text_sample = 0, op_commit = 0;
+    size_t op_depformer = 0;        // first op after the temporal transformer + text head: where mmi_lm_set_phase_event's event is recorded
+    int (*phase_fn)(void*, mmi_stream) = nullptr;   // mmi_lm_set_phase_callback
+    void* phase_user = nullptr;
     SampleArgs text_sample_args;    // to rebuild the depth transformer's first input when a hook changed the text token
     long offset_cpu = 0;
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
@@ -714,6 +717,7 @@ int build_program(mmi_lm* lm) {
     // depformer_in[k](transformer_out) for every micro-step in one launch; each sampler then adds its token's embedding row
     // and writes the next micro-step's input (lm.py:465-470) - 8 dependent launches less on the sequential chain
     const bool grouped = lm->dep_in_grouped;
+    lm->op_depformer = P.ops.size();
     P.site("dep.in_all");
     if (grouped) add_gemm(lm, lm->dep_in_all, lm->tout, lm->dpre, c.dep_q * dd, false, MMI_EPI_STORE, nullptr);
     P.site("text_sample");
@@ -834,7 +838,12 @@ int run_step_with_hooks(mmi_lm* lm, hipStream_t s) {
         lm->in_hook = false;
         return r ? mmi_fail(MMI_ERR_INVALID, "a step hook reported an error") : MMI_OK;
     };
-    int rc = P.run_range(s, 0, lm->op_text_sample);
+    int rc;
+    if (lm->phase_fn && lm->op_depformer <= lm->op_text_sample) {       // mmi_lm_set_phase_callback: the same point as in the un-hooked step
+        if ((rc = P.run_range(s, 0, lm->op_depformer))) return rc;
+        if (lm->phase_fn(lm->phase_user, (mmi_stream)s)) return mmi_fail(MMI_ERR_INVALID, "the phase callback reported an error");
+        rc = P.run_range(s, lm->op_depformer, lm->op_text_sample);
+    } else rc = P.run_range(s, 0, lm->op_text_sample);
     if (rc || (rc = call(lm->hooks.on_text_logits))) return rc;
     if ((rc = P.run_range(s, lm->op_text_sample, lm->op_after_text_sample))) return rc;
     if (lm->hooks.on_text_token) {
@@ -1186,7 +1195,12 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     int rc;
     const bool hooked = lm->hooks.on_text_logits || lm->hooks.on_text_token || lm->hooks.on_audio_tokens;
     if (hooked) rc = run_step_with_hooks(lm, s);
-    else rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
+    else if (lm->phase_fn) {
+        auto fn = lm->phase_fn; void* user = lm->phase_user;
+        rc = lm->prog.run_split(s, lm->use_graph && !lm->profiling, lm->cap_stream, lm->op_depformer, [fn, user](hipStream_t st) {
+            return fn(user, (mmi_stream)st) ? mmi_fail(MMI_ERR_INVALID, "the phase callback reported an error") : (int)MMI_OK;
+        });
+    } else rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
     if (rc) return rc;
     MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(B * (c.dep_q + 1), 256), 256, 0, s, (const int*)lm->out_i32, (long*)out_tokens, B * (c.dep_q + 1));
     if (opt_text_logits)
@@ -1205,6 +1219,13 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     }
     lm->offset_cpu += 1;
     if (valid) *valid = lm->offset_cpu > lm->max_delay ? 1 : 0;   // lm.py:774-776
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_set_phase_callback(mmi_lm* lm, int (*fn)(void*, mmi_stream), void* user) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    lm->phase_fn = fn;
+    lm->phase_user = user;
     return MMI_OK;
 }
 
@@ -1288,6 +1309,7 @@ extern "C" int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream) {
 }
 
 extern "C" int mmi_lm_model_rows(const mmi_lm* lm) { return lm ? lm->batch : 0; }
+extern "C" int mmi_lm_streaming_batch(const mmi_lm* lm) { return lm && lm->streaming ? lm->gen_batch : 0; }
 extern "C" int mmi_lm_device(const mmi_lm* lm) { return lm ? lm->device : -1; }
 
 int64_t mmi_copy_launch_log(const std::vector<std::string>& log, char* buf, int64_t cap);   // api_common.hip

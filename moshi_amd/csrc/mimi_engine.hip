@@ -55,7 +55,9 @@ struct mmi_mimi {
     float* xq = nullptr;                       // [maxB][2*Dq] residuals (first | rest)
     double* best_d = nullptr;
     int* best_i = nullptr;
-    int* codes_i32 = nullptr;                  // [maxB][n_q]
+    int* codes_i32 = nullptr;                  // [maxB][n_q]  encoder side: what the RVQ selected
+    int* dec_codes_i32 = nullptr;              // [maxB][n_q]  decoder side: the codes being decoded (its own buffer: an encode of the
+                                               //              next frame may run on another stream while a decode is in flight, duplex.hip)
     float* q2 = nullptr;                       // [maxB][2*Dq]
     float* lat_tmp = nullptr;                  // [maxB][dimension]
     float *qin_bp = nullptr, *qin_part = nullptr, *qout_bp = nullptr, *qout_part = nullptr;   // projection scratch (max_batch)
@@ -605,7 +607,7 @@ int add_quantize_ops(mmi_mimi* m, MmiProgram& prog, const float* latent, int lat
 int add_dequant_ops(mmi_mimi* m, MmiProgram& prog, int K, const Buf& out, int out_off, int B, bool k_from_device = false) {
     const mmi_mimi_cfg& c = m->cfg;
     const int D = c.q_dimension, bins = c.q_bins, nq = c.q_n_q, nsem = c.q_n_q_semantic;
-    float* q2 = m->q2; const int* codes = m->codes_i32; const float* E = m->E_all; const int* kdev = k_from_device ? m->dec_k_dev : nullptr;
+    float* q2 = m->q2; const int* codes = m->dec_codes_i32; const float* E = m->E_all; const int* kdev = k_from_device ? m->dec_k_dev : nullptr;
     const bool packed = B <= 128 && m->q_out.Q * 8 == 2 * D && !getenv("MMI_MIMI_PACK_LAUNCHES");
     float* qp = packed ? m->qout_bp : nullptr; const int qQ = m->q_out.Q;
     prog.add([=](hipStream_t s) {
@@ -1111,6 +1113,7 @@ extern "C" int mmi_mimi_create(const mmi_mimi_cfg* cfg, const mmi_tensor_desc* w
         hipSuccess != m->wts.alloc(&m->best_d, (size_t)2 * m->nchunk * max_batch) ||
         hipSuccess != m->wts.alloc(&m->best_i, (size_t)2 * m->nchunk * max_batch) ||
         hipSuccess != m->wts.alloc(&m->codes_i32, (size_t)max_batch * c.q_n_q) ||
+        hipSuccess != m->wts.alloc(&m->dec_codes_i32, (size_t)max_batch * c.q_n_q) ||
         hipSuccess != m->wts.alloc(&m->q2, (size_t)max_batch * 2 * c.q_dimension) ||
         hipSuccess != m->wts.alloc(&m->lat_tmp, (size_t)max_batch * c.dimension) ||
         hipSuccess != m->wts.alloc(&m->qin_bp, (size_t)mmi_cdiv(max_batch, 32) * m->q_in.Q * 256) ||
@@ -1204,6 +1207,8 @@ extern "C" int mmi_mimi_streaming_stop(mmi_mimi* m) {
     return MMI_OK;
 }
 
+extern "C" int mmi_mimi_streaming_batch(const mmi_mimi* m) { return m && m->streaming ? m->batch : 0; }
+
 extern "C" int64_t mmi_mimi_state_bytes(const mmi_mimi* m) { return m && m->streaming ? (int64_t)m->st.bytes : 0; }
 
 extern "C" int mmi_mimi_state_save(mmi_mimi* m, void* dst, int64_t bytes, mmi_stream stream) {
@@ -1221,6 +1226,7 @@ extern "C" int mmi_mimi_state_load(mmi_mimi* m, const void* src, int64_t bytes, 
     if (!m->streaming) return mmi_fail(MMI_ERR_STATE, "not streaming");
     if (bytes != (int64_t)m->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch)");
     MMI_HIP_CHECK(m->st.load(src, (hipStream_t)stream));
+    m->dec_k_cur = -1;        // the snapshot carries its own device-side K: the next decode re-uploads the caller's
     return MMI_OK;
 }
 
@@ -1316,7 +1322,8 @@ extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* 
     const mmi_mimi_cfg& c = m->cfg;
     Buf out; out.p = latent; out.C = c.dimension; out.ld = n_frames; out.H = 0;
     for (int f = 0; f < n_frames; ++f) {
-        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
+        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, (long)n_codebooks * n_frames, m->dec_codes_i32,
+                   c.q_n_q, batch, n_codebooks, n_frames, f);
         MmiProgram prog;
         int rc = add_dequant_ops(m, prog, n_codebooks, out, f, batch);
         if (rc) return rc;
@@ -1328,12 +1335,18 @@ extern "C" int mmi_mimi_decode_latent(mmi_mimi* m, const int64_t* codes, float* 
 
 extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pcm, int32_t batch, int32_t n_codebooks,
                                     int32_t n_frames, mmi_stream stream) {
+    return mmi_mimi_decode_step_strided(m, codes, (int64_t)n_codebooks * n_frames, pcm, batch, n_codebooks, n_frames, stream);
+}
+
+extern "C" int mmi_mimi_decode_step_strided(mmi_mimi* m, const int64_t* codes, int64_t batch_stride, float* pcm, int32_t batch,
+                                            int32_t n_codebooks, int32_t n_frames, mmi_stream stream) {
     MmiDeviceGuard dev_guard_(m ? m->device : -1);
     int rc = frame_count_ok(m, batch, n_frames);
     if (rc) return rc;
     if (!codes || !pcm) return mmi_fail(MMI_ERR_INVALID, "null argument");
     // any 1 <= K <= n_q: "the split RVQ decodes however many codebooks it is given" (compression.py:406-429, vq.py:281-287)
     if (n_codebooks < 1 || n_codebooks > m->cfg.q_n_q) return mmi_fail(MMI_ERR_SHAPE, "codes must carry between 1 and n_q codebooks");
+    if (batch_stride < (int64_t)n_codebooks * n_frames) return mmi_fail(MMI_ERR_SHAPE, "batch stride smaller than one row of codes");
     hipStream_t s = (hipStream_t)stream;
     const mmi_mimi_cfg& c = m->cfg;
     const int F = c.frame_size;
@@ -1344,7 +1357,8 @@ extern "C" int mmi_mimi_decode_step(mmi_mimi* m, const int64_t* codes, float* pc
         m->dec_k_cur = n_codebooks;
     }
     for (int f = 0; f < n_frames; ++f) {
-        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, m->codes_i32, c.q_n_q, batch, n_codebooks, n_frames, f);
+        MMI_LAUNCH(k_codes_in, mmi_cdiv(batch * n_codebooks, 256), 256, 0, s, (const long*)codes, (long)batch_stride, m->dec_codes_i32, c.q_n_q,
+                   batch, n_codebooks, n_frames, f);
         MMI_CHECK_LAUNCH();
         if ((rc = m->dec_prog.run(s, m->use_graph, m->cap_stream))) return rc;
         MMI_LAUNCH(k_copy2d_f32, (int)mmi_cdiv64((int64_t)batch * c.channels * F, 256), 256, 0, s, (const float*)m->dec_out.p, (long)m->dec_out.ld,

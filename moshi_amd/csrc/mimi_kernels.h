@@ -1448,10 +1448,12 @@ __global__ void k_codes_out(const int* __restrict__ src, int src_rstride, long* 
     int b = idx / K, k = idx % K;
     dst[((long)b * K + k) * F + f] = (long)src[(long)b * src_rstride + k];
 }
-__global__ void k_codes_in(const long* __restrict__ src, int* __restrict__ dst, int dst_rstride, int B, int K, int F,
-                           int f) {
+// src: i64 [B][K][F] with `src_bstride` elements between batch rows (K * F when dense; larger for a column slice of a wider
+// tensor such as LMGen's [B][1 + dep_q][1] step output read from its second column on)
+__global__ void k_codes_in(const long* __restrict__ src, long src_bstride, int* __restrict__ dst, int dst_rstride, int B, int K,
+                           int F, int f) {
     int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (idx >= B * K) return;
     int b = idx / K, k = idx % K;
-    dst[(long)b * dst_rstride + k] = (int)src[((long)b * K + k) * F + f];
+    dst[(long)b * dst_rstride + k] = (int)src[(long)b * src_bstride + (long)k * F + f];
 }

@@ -108,3 +108,20 @@ __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_
 
 __device__ __forceinline__ float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }  // IEEE, matches torch.rsqrt closely
 __device__ __forceinline__ unsigned mmi_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+
+// Cross-stream hand-off flags (duplex.hip): a monotonic counter in device memory, published with release semantics by a
+// one-thread kernel at the end of a producer stream's work and polled by a one-wave kernel at the head of the consumer's.
+// Why not hipStreamWaitEvent: a wait that stays PENDING makes the command processor poll the producer queue's signal, which
+// slows every dependent launch of the producer (1.60 -> 2.77 ms for a chain of 1000 tiny kernels on this stack; a resident
+// polling wave costs 1.71 ms - scripts/stream_probe.hip test 1e, profiles/r03_logs/stream_probe.txt).
+__device__ __forceinline__ void mmi_flag_publish(long* flag, long v) {
+    __threadfence();
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The poll is a RELAXED agent-scope load (it bypasses the non-coherent cache levels by itself); the acquire fence - on gfx950 an
+// invalidation of the polling XCD's L2, which would evict the working set of every kernel running there once per iteration -
+// comes once, after the flag was seen.
+__device__ __forceinline__ void mmi_flag_wait(const long* flag, long v) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) __builtin_amdgcn_s_sleep(96);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}

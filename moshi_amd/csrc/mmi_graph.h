@@ -23,6 +23,11 @@ struct MmiProgram {
     bool logged = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // the same list captured as two graphs, ops [0, cut) and [cut, end), for callers that put something between the halves
+    // (run_split: an event record that another stream waits on)
+    hipGraph_t graph_a = nullptr, graph_b = nullptr;
+    hipGraphExec_t exec_a = nullptr, exec_b = nullptr;
+    size_t cut_ = 0;
 
     void site(const std::string& label) { site_ = label; }
     void add(std::function<int(hipStream_t)> f) { ops.push_back(std::move(f)); sites.push_back(site_); }
@@ -60,9 +65,51 @@ struct MmiProgram {
         return MMI_OK;
     }
 
+    int capture_range(hipStream_t capture_stream, size_t i0, size_t i1, hipGraph_t* g, hipGraphExec_t* e) {
+        MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
+        int rc = run_range(capture_stream, i0, i1);
+        hipError_t err = hipStreamEndCapture(capture_stream, g);
+        if (rc) return rc;
+        if (err != hipSuccess) return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(err));
+        MMI_HIP_CHECK(hipGraphInstantiate(e, *g, nullptr, nullptr, 0));
+        return MMI_OK;
+    }
+
+    // ops [0, cut) - between(s) - ops [cut, end): as two graph launches (or eagerly), `between` enqueued on s in the middle
+    int run_split(hipStream_t s, bool use_graph, hipStream_t capture_stream, size_t cut, const std::function<int(hipStream_t)>& between) {
+        int rc;
+        if (!use_graph || !logged) {            // the first run of a program is the eager one that records the launch list
+            const bool rec = !logged;
+            if (rec) mmi_record_begin(&launch_log);
+            rc = MMI_OK;
+            for (size_t i = 0; i < ops.size() && !rc; ++i) {
+                if (i == cut && (rc = between(s))) break;
+                if (rec) mmi_record_site(sites[i].c_str());
+                rc = ops[i](s);
+            }
+            if (rec) { mmi_record_end(); logged = true; }
+            return rc;
+        }
+        if (!exec_a || cut_ != cut) {
+            if (exec_a) { hipGraphExecDestroy(exec_a); hipGraphDestroy(graph_a); exec_a = nullptr; }
+            if (exec_b) { hipGraphExecDestroy(exec_b); hipGraphDestroy(graph_b); exec_b = nullptr; }
+            if ((rc = capture_range(capture_stream, 0, cut, &graph_a, &exec_a))) return rc;
+            if ((rc = capture_range(capture_stream, cut, ops.size(), &graph_b, &exec_b))) return rc;
+            cut_ = cut;
+        }
+        MMI_HIP_CHECK(hipGraphLaunch(exec_a, s));
+        if ((rc = between(s))) return rc;
+        MMI_HIP_CHECK(hipGraphLaunch(exec_b, s));
+        return MMI_OK;
+    }
+
     void clear() {
         if (exec) hipGraphExecDestroy(exec);
         if (graph) hipGraphDestroy(graph);
+        if (exec_a) { hipGraphExecDestroy(exec_a); hipGraphDestroy(graph_a); }
+        if (exec_b) { hipGraphExecDestroy(exec_b); hipGraphDestroy(graph_b); }
+        exec_a = exec_b = nullptr;
+        graph_a = graph_b = nullptr;
         exec = nullptr;
         graph = nullptr;
         ops.clear();

@@ -1,0 +1,85 @@
+"""Software-pipelined frame step: `mimi.encode -> lm_gen.step -> mimi.decode` of consecutive frames overlapped on the GPU.
+
+The reference's serving loop (moshi/moshi/server.py:132-146) runs
+
+    codes = mimi.encode(chunk); tokens = lm_gen.step(codes); pcm = mimi.decode(tokens[:, 1:])
+
+back to back on one stream.  `DuplexStream.step(chunk)` is the same three calls through `mmi_duplex_submit`
+(include/moshi_mi.h): each model keeps its own stream order, so the results are bit-identical, but encode(t+1) and
+decode(t-1) execute while LMGen.step(t) runs.  Outputs of frame t are valid on torch's current stream after `join()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from .lm import LMGen
+from .mimi import MimiModel
+
+
+class DuplexStream:
+    """Both models must already be streaming with the same batch (`streaming_forever(B)` / inside `streaming(B)`).
+
+    depth: output buffers kept alive (frames whose results may still be unread when `step` returns)."""
+
+    def __init__(self, mimi: MimiModel, lm_gen: LMGen, depth: int = 4):
+        assert depth >= 3, "two frames may be in flight when `step` returns"
+        assert mimi._lib is lm_gen._lib, "both models must come from the same engine library"
+        self._lib = mimi._lib
+        self.mimi, self.lm_gen = mimi, lm_gen
+        self.device = mimi.device
+        h = C.c_void_p()
+        with _capi.device_scope(self.device):
+            self._lib.check(self._lib.mmi_duplex_create(mimi._handle, lm_gen.lm_model._handle, C.byref(h)))
+        self._handle = h
+        B = mimi._batch
+        ntok = 1 + lm_gen.lm_model.dep_q
+        self._pcm = [torch.zeros(B, mimi.channels, mimi.frame_size, device=self.device, dtype=torch.float32) for _ in range(depth)]
+        self._tok = [torch.full((B, ntok, 1), -2, device=self.device, dtype=torch.int64) for _ in range(depth)]
+        self._in = [None] * depth            # a frame's input must outlive its encode: two further submits (include/moshi_mi.h)
+        self._n = 0
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.mmi_duplex_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, chunk: torch.Tensor, want_tokens: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """Submit one 80 ms frame [B, C, frame_size].  Returns (tokens [B, 1 + dep_q, 1] or None, pcm [B, C, frame_size] or None)
+        - None exactly where `lm_gen.step` returns None (lm.py:774-776).  The tensors are slots of a ring `depth` frames deep:
+        read them after `join()` and before `depth` further steps."""
+        x = self.mimi._check_audio(chunk)
+        assert x.shape[-1] == self.mimi.frame_size, "one frame per step"
+        slot = self._n % len(self._pcm)
+        self._n += 1
+        pcm, tok = self._pcm[slot], self._tok[slot]
+        valid = C.c_int32(0)
+        self._in[slot] = x
+        self._lib.check(self._lib.mmi_duplex_submit(self._handle, x.data_ptr(), pcm.data_ptr(), tok.data_ptr() if want_tokens else None,
+                                                    C.byref(valid), _capi.stream_ptr(self.device)))
+        if not valid.value:
+            return None, None
+        return (tok if want_tokens else None), pcm
+
+    def join(self) -> None:
+        """torch's current stream waits (on the device) for every submitted frame."""
+        self._lib.check(self._lib.mmi_duplex_join(self._handle, _capi.stream_ptr(self.device)))
+
+    def timeline(self, on: Optional[bool] = None):
+        """Diagnostics (mmi_duplex_set_timeline / get_timeline): `timeline(True)` switches the per-phase timestamps on;
+        `timeline()` synchronises and returns the last frame's {phase: (begin_ms, end_ms)} since its submit."""
+        if on is not None:
+            self._lib.check(self._lib.mmi_duplex_set_timeline(self._handle, 1 if on else 0))
+            return None
+        ms = (C.c_float * 7)()
+        self._lib.check(self._lib.mmi_duplex_get_timeline(self._handle, C.cast(ms, C.c_void_p)))
+        return {"encode": (ms[0], ms[1]), "lm": (ms[2], ms[4]), "decode": (ms[5], ms[6])}

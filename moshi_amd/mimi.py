@@ -264,15 +264,19 @@ class MimiModel:
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """[B, K, T'] int64 codes -> [B, C, T' * frame_size] float."""
         assert codes.dim() == 3
-        codes = codes.to(device=self.device, dtype=torch.int64).contiguous()
+        codes = codes.to(device=self.device, dtype=torch.int64)
         B, K, n = codes.shape
+        # a column slice of a wider tensor - `tokens[:, 1:]` of LMGen.step's output (server.py:144-146) - is read in place
+        strided = codes.stride(2) == 1 and codes.stride(1) == n and codes.stride(0) >= K * n
+        if not strided:
+            codes = codes.contiguous()
         temporary = not self.is_streaming
         if temporary:
             self.streaming_forever(B)
         try:
             out = torch.empty(B, self.channels, n * self.frame_size, device=self.device, dtype=torch.float32)
-            self._lib.check(self._lib.mmi_mimi_decode_step(self._handle, codes.data_ptr(), out.data_ptr(), B, K, n,
-                                                           self._stream()))
+            self._lib.check(self._lib.mmi_mimi_decode_step_strided(self._handle, codes.data_ptr(), codes.stride(0), out.data_ptr(),
+                                                                   B, K, n, self._stream()))
         finally:
             if temporary:
                 self._stop_streaming()

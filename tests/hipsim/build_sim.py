@@ -13,7 +13,7 @@ HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 CSRC = ROOT / "moshi_amd" / "csrc"
 LIB = HERE / "libmoshi_sim.so"
-SOURCES = ["api_common.hip", "mimi_engine.hip", "lm_engine.hip", "batcher.hip"]
+SOURCES = ["api_common.hip", "mimi_engine.hip", "lm_engine.hip", "batcher.hip", "duplex.hip"]
 
 
 def _cxx() -> str:

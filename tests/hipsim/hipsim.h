@@ -62,12 +62,19 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hip
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t* s);
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipEventCreate(hipEvent_t* e);
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+// the simulator executes every call synchronously in host order, so a wait on a recorded event is already satisfied
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

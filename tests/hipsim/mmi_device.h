@@ -257,3 +257,13 @@ inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
 inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline unsigned mmi_atomic_add(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// hand-off flags (duplex.hip).  The simulator runs every launch synchronously in host order, so a wait whose producer has not
+// been launched yet can never be satisfied: abort loudly instead of spinning forever.
+inline void mmi_flag_publish(long* flag, long v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
+inline void mmi_flag_wait(const long* flag, long v) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < v) {
+        fprintf(stderr, "hipsim: mmi_flag_wait on a flag whose producer was not enqueued first (have %ld, want %ld)\n", *flag, v);
+        abort();
+    }
+}

@@ -32,7 +32,7 @@ def test_product_library_builds_loads_and_exports_all_symbols():
     lib = _capi.load()
     for name in declared_symbols():
         assert hasattr(lib.cdll, name), name
-    assert lib.mmi_version() == 2
+    assert lib.mmi_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

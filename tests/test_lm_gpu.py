@@ -182,6 +182,23 @@ def test_full_depth_32_layers_at_the_benchmark_batch_match_oracle(gpu_lib):
     lm_cases.full_depth_vs_oracle(DEV, None, B=32, S=3)
 
 
+def test_benchmark_model_matches_the_reference_at_full_depth(gpu_lib):
+    """The model `bench.py` times (32 temporal layers, context 3000) against the REFERENCE's own LMGen run on the CPU
+    (tests/golden/lm_full.npz, make_golden_lm_full.py): ring outputs identical, logits within FULL_WIDEN x the tolerance;
+    measured distances in gpurun_out/parity_golden_full_cuda.json."""
+    lm_cases.check_golden_full(DEV, None)
+
+
+def test_c5_shape_int8_linears_at_64_sessions_match_oracle(gpu_lib):
+    """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), row-wise int8 linears."""
+    lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, quantize=True)
+
+
+def test_c5_shape_fp8_linears_at_64_sessions_within_the_conditioning_of_the_fp8_network(gpu_lib):
+    """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), e4m3 linears on the fp8 MFMA."""
+    print(lm_cases.fp8_engine_within_format_conditioning(DEV, None, LMConfig(num_layers=2, context=64), seed=464, B=64, S=2))
+
+
 @pytest.mark.parametrize("B", [40, 64])
 def test_two_batch_tiles_at_full_width_match_oracle(gpu_lib, B):
     """33..64 sessions at the 7B layer shapes on the DEFAULT GEMM path (k_gemm_xp with two batch tiles per weight fragment:

@@ -1,5 +1,7 @@
 """The numpy oracle is pinned against golden vectors produced by running the reference itself
 (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -162,3 +164,35 @@ def test_lm_oracle_matches_reference_for_an_asr_style_model():
         out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
         return out, tl
     lm_cases.check_stt_golden(lambda: o.streaming(B), step, lambda: o.extra_head_probs())
+
+
+def _host_ram_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.skipif(_host_ram_gib() < 36 or os.environ.get("MMI_SKIP_FULL_GOLDEN") == "1",
+                    reason="the 32-layer benchmark model needs ~20 GB of host memory for the checker (15.4 GB of bf16 weights)")
+def test_lm_oracle_matches_reference_at_the_benchmark_depth():
+    """oracle/lm_oracle.py against the reference's LMGen ON THE BENCHMARK MODEL (32 temporal layers, dim 4096, context 3000,
+    B = 2 with the rows one step apart): tests/golden/lm_full.npz (make_golden_lm_full.py).  ~3 minutes: 15.4 GB of seeded
+    bf16 weights are re-drawn, the checker widens each temporal linear to fp32 only while it multiplies with it."""
+    from dataclasses import replace
+    from oracle.lm_oracle import LMOracle
+    from moshi_amd.weights import random_lm_state_dict
+    from tests import lm_cases
+    g, cfg = lm_cases.load_full()
+    sd = lm_cases.lazy_temporal_linears(random_lm_state_dict(cfg, seed=int(g["seed"][0])))
+    o = LMOracle(sd, replace(cfg, context=64))            # no wrap inside 4 steps; the 3000-slot ring would be 3 GB of fp32
+    B = g["codes"].shape[1]
+    o.streaming(B)
+
+    def step(codes, forced):
+        out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
+        return out, tl, al
+    lm_cases.check_wide_steps(step, g, cfg, name="golden_full_oracle", widen=lm_cases.FULL_WIDEN, set_mask=o.set_exec_mask)
