@@ -25,6 +25,12 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def trace(msg):
+    if os.environ.get("MMI_BENCH_TRACE"):
+        sys.stderr.write(f"[bench {time.perf_counter():.3f}] {msg}\n")
+        sys.stderr.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +108,17 @@ def job_time(dt_local, dist, dev):
     t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def job_latency(p50, p95, dist, dev, world):
+    """BASELINE.json's second figure is the JOB's step latency: MAX over ranks, with the per-rank figures alongside."""
+    if dist is None:
+        return p50, p95, [p50], [p95]
+    t = torch.tensor([p50, p95], device=dev, dtype=torch.float64)
+    allr = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allr, t)
+    p50s, p95s = [float(x[0]) for x in allr], [float(x[1]) for x in allr]
+    return max(p50s), max(p95s), p50s, p95s
 
 
 def job_value(world, sessions_per_gpu, steps, dt):
@@ -202,11 +219,13 @@ def launchcheck_main(args, backend):
     if dist is not None:
         dist.barrier()
     dt = job_time(0.5 + 0.25 * rank, dist, dev)
+    p50, p95, p50s, p95s = job_latency(5.0 + rank, 6.0 + rank, dist, dev, world)      # rank r pretends to be r ms slower
     if dist is not None:
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "launchcheck", "value": job_value(world, args.batch, args.steps, dt), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50s, "p95_ms_per_rank": p95s,
                           "backend": backend}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -224,6 +243,7 @@ def main():
     from moshi_amd import MimiConfig, MimiModel
     from moshi_amd.weights import random_mimi_state_dict
 
+    t_load = time.perf_counter()
     workload = args.workload
     have_lm = (ROOT / "moshi_amd" / "lm.py").exists()
     if workload == "auto":
@@ -242,6 +262,8 @@ def main():
         from bench_lm import make_lm  # noqa
         lm_gen = make_lm(dev, B, args)
 
+    torch.cuda.synchronize(dev)
+    load_s = job_time(time.perf_counter() - t_load, dist, dev)      # rank 0 draws, RCCL broadcasts in 1 GiB buckets, every rank packs
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
     user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)
@@ -282,9 +304,11 @@ def main():
     if lm_gen is not None:
         from bench_lm import stagger
         staggered = stagger(mimi if workload == "duplex" else None, lm_gen, step, B, args.stagger, dev, before_mask=join)
+    trace("staggered")
     for _ in range(args.warmup):
         step()
     sync()
+    trace("warm")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -297,6 +321,7 @@ def main():
 
     ms = 1e3 * dt / args.steps
     value = job_value(world, B, args.steps, dt)
+    trace("timed region done")
     if args.launch_lists and rank == 0:
         d = Path(args.launch_lists)
         d.mkdir(parents=True, exist_ok=True)
@@ -309,32 +334,40 @@ def main():
             (d / f"launch_list_{k}.tsv").write_text("".join(f"{s_}\t{kn}\n" for s_, kn in v))
 
     # p50 / p95 latency of a single step (BASELINE.json's second figure): a separate, untimed-for-`value` pass with a
-    # device event before and after every step and no host synchronisation inside the loop.  Pipelined: every frame is joined
+    # device event before and after every step and no host synchronisation inside the loop.  Pipelined: every frame completes
     # before the next is submitted, so the figure is PCM-in -> PCM-out of ONE frame with nothing else in flight (what a
     # session waits for), not the steady-state step interval `ms_per_step` reports.
     n_lat = max(8, min(args.steps, 40))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
     join()
-    for a_ev, b_ev in evs:
-        a_ev.record()
-        step()
-        join()
-        b_ev.record()
     torch.cuda.synchronize(dev)
-    lat = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
+    if dup is not None:
+        # one frame alone through the pipeline: device timestamps from the submit reaching the caller's stream (PCM in) to the end
+        # of the frame's decode (PCM out) - mmi_duplex_get_timeline - with the host waiting for the frame (mmi_duplex_flush)
+        dup.timeline(True)
+        lat = []
+        for _ in range(n_lat):
+            out = step()
+            dup.flush()
+            if out is not None:
+                lat.append(dup.timeline()["decode"][1])
+        dup.timeline(False)
+        lat.sort()
+    else:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
+        for a_ev, b_ev in evs:
+            a_ev.record()
+            step()
+            b_ev.record()
+        torch.cuda.synchronize(dev)
+        lat = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
     p50, p95 = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.95 * len(lat)))]
-    p50_ranks, p95_ranks = [p50], [p95]
-    if dist is not None:                       # the metric is the job's latency: MAX over ranks, per-rank figures alongside
-        t = torch.tensor([p50, p95], device=dev, dtype=torch.float64)
-        allr = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allr, t)
-        p50_ranks, p95_ranks = [float(x[0]) for x in allr], [float(x[1]) for x in allr]
-        p50, p95 = max(p50_ranks), max(p95_ranks)
+    trace("latency pass done")
+    p50, p95, p50_ranks, p95_ranks = job_latency(p50, p95, dist, dev, world)
     out = {
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50_ranks, "p95_ms_per_rank": p95_ranks,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "load_s": load_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"none": "bf16", "q8": "bf16 x int8 weights", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",

@@ -180,7 +180,17 @@ def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5):
     lm_s = times[lo] + (full_layers - lo) * per_layer
     mimi_s = 1.0 / mimi_base["value"]
     cores, ram = _host_info()
-    return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": cores, "host_ram_gib": ram, "kind": "port",
+    # the reference ITSELF cannot travel to the GPU box (no copy of its sources is kept here): its own CPU path, timed on the
+    # build container by scripts/reference_cpu_baseline.py (recipe of scripts/moshi_benchmark.py:76-100), is quoted beside the port
+    ref = None
+    rp = Path(__file__).resolve().parent / "profiles" / "r03_logs" / "reference_cpu_baseline.json"
+    if rp.exists():
+        rd = json.loads(rp.read_text())
+        ref = {"value": rd["duplex_b1_frames_per_s"], "unit": "frames/s", "cores": rd["host"]["cores"], "cpu": rd["host"]["cpu"],
+               "measured_on": rd["host"].get("where", "build container"), "mimi_b1_ms": rd["mimi_b1"], "mimi_b8_ms": rd["mimi_b8"],
+               "lm_7b_bf16_b1_step_ms": rd["lm_7b_bf16_b1"]["step_p50_ms"],
+               "note": "kyutai-labs/moshi PyTorch CPU path, B=1, NOT measured in this run (committed: profiles/r03_logs/reference_cpu_baseline.json)"}
+    return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": cores, "host_ram_gib": ram, "kind": "port", "reference_on_build_host": ref,
             "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle (fp32 numpy) median of "
                        f"{timed} steps at {lo} and {hi} temporal layers + full depformer and text head ({times[lo]:.3f} s, "
                        f"{times[hi]:.3f} s per step; temporal stack alone {text_times[lo]*1e3:.0f} / {text_times[hi]*1e3:.0f} ms = "

@@ -353,6 +353,9 @@ void mmi_duplex_destroy(mmi_duplex* d);
 int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out_or_null, int32_t* valid,
                       mmi_stream caller);
 int mmi_duplex_join(mmi_duplex* d, mmi_stream caller);
+/* The host-side form: blocks the calling thread until every submitted frame has completed (its outputs are then readable from any
+ * stream).  Unlike mmi_duplex_join it leaves no waiter on the device while the frames run. */
+int mmi_duplex_flush(mmi_duplex* d);
 /* Diagnostics: with the timeline on, every submit records timestamps around the frame's three phases on their streams;
  * mmi_duplex_get_timeline synchronises the pipeline and returns, for the LAST submitted frame whose decode was enqueued, ms since
  * the submit reached the caller's stream: {encode begin, encode end, LM begin, -, LM end, decode begin, decode end} (host f32[7]);

@@ -41,6 +41,18 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
+    """Several ranks of one node may call this at once (one process per GPU): the compile runs under a file lock, and a rank
+    that waited for it finds the library up to date."""
+    import fcntl
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> Path:
     if not force and not needs_build():
         return LIB
     objs = []

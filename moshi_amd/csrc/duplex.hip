@@ -140,6 +140,16 @@ int create_impl(mmi_duplex* d) {
     // process created at that priority, and two streams that land on one queue do not overlap (profiles/r03_logs: the encoder
     // and the LM shared queue 4 without priorities).  The codec streams get the high-priority pool: distinct queues, and their
     // short latency-bound launches win arbitration against the bulk LM stream.  (A/B: MMI_DUPLEX_PRIO = "0" none, "lm", "mimi")
+    MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)(F_COUNT + 1) * 16 * sizeof(long)));
+    MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)(F_COUNT + 1) * 16 * sizeof(long)));
+    if (const char* pad = getenv("MMI_DUPLEX_PAD")) {      // experiment: shift which hardware queues / pipes the three streams land on
+        for (int i = 0; i < atoi(pad) && i < 16; ++i) {
+            hipStream_t x;
+            MMI_HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+            MMI_LAUNCH(k_flag_publish, 1, 1, 0, x, d->flags + 16 * F_COUNT, (long)i);
+            MMI_HIP_CHECK(hipStreamSynchronize(x));
+        }
+    }
     int lo = 0, hi = 0;
     const char* e = getenv("MMI_DUPLEX_PRIO");
     const std::string mode = e && e[0] ? e : "mimi";
@@ -162,8 +172,6 @@ int create_impl(mmi_duplex* d) {
     if (const char* g = getenv("MMI_DUPLEX_EVENTS")) d->use_events = g[0] == '1';
     if (const char* g = getenv("MMI_DUPLEX_HOSTGATE")) d->host_gate = g[0] != '0';
     if (!d->gate) d->host_gate = false;
-    MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)F_COUNT * 16 * sizeof(long)));
-    MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)F_COUNT * 16 * sizeof(long)));
     for (int i = 0; i < 2; ++i) {
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_lm[i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
@@ -282,6 +290,23 @@ extern "C" int mmi_duplex_join(mmi_duplex* d, mmi_stream caller) {
     if ((rc = enqueue_decode(d, p ^ 1, -1)) || (rc = enqueue_decode(d, p, -1))) return rc;     // a decode still held back for its gate: now
     hipStream_t s = (hipStream_t)caller;
     if ((rc = await(d, F_DEC, t, s))) return rc;  // decode(t) implies step(t) implies encode(t)
+    return MMI_OK;
+}
+
+extern "C" int mmi_duplex_flush(mmi_duplex* d) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (d->frame == 0) return MMI_OK;
+    const int p = (int)((d->frame - 1) & 1);
+    int rc;
+    for (int slot : {p ^ 1, p}) {               // older frame first; the host sees the step complete, so the decode needs no device-side wait
+        if (!d->pend[slot].live) continue;
+        MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[slot]));
+        if ((rc = enqueue_decode(d, slot, -2))) return rc;
+    }
+    MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
+    MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[p]));
+    if (d->frame >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[p ^ 1]));
     return MMI_OK;
 }
 

@@ -1194,7 +1194,13 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     MMI_CHECK_LAUNCH();
     int rc;
     const bool hooked = lm->hooks.on_text_logits || lm->hooks.on_text_token || lm->hooks.on_audio_tokens;
-    if (hooked) rc = run_step_with_hooks(lm, s);
+    if (hooked) {
+        rc = run_step_with_hooks(lm, s);
+        if (rc) {           // a hook aborted the step half-way: it is NOT committed (ring, offsets unchanged), and the forcing armed for
+            hipMemsetAsync(lm->use_forced, 0, sizeof(int), s);   // this step does not leak into the next one
+            lm->forced_armed = false;
+        }
+    }
     else if (lm->phase_fn) {
         auto fn = lm->phase_fn; void* user = lm->phase_user;
         rc = lm->prog.run_split(s, lm->use_graph && !lm->profiling, lm->cap_stream, lm->op_depformer, [fn, user](hipStream_t st) {

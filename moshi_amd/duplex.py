@@ -74,6 +74,10 @@ class DuplexStream:
         """torch's current stream waits (on the device) for every submitted frame."""
         self._lib.check(self._lib.mmi_duplex_join(self._handle, _capi.stream_ptr(self.device)))
 
+    def flush(self) -> None:
+        """The host waits until every submitted frame has completed (mmi_duplex_flush)."""
+        self._lib.check(self._lib.mmi_duplex_flush(self._handle))
+
     def timeline(self, on: Optional[bool] = None):
         """Diagnostics (mmi_duplex_set_timeline / get_timeline): `timeline(True)` switches the per-phase timestamps on;
         `timeline()` synchronises and returns the last frame's {phase: (begin_ms, end_ms)} since its submit."""

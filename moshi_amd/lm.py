@@ -123,6 +123,11 @@ class LMModel:
         elif quantize:                                                    # the reference's `quantize=True` (lm.py:242-243)
             state_dict = quantize_lm_state_dict(state_dict)
         self.quantized = any(v.dtype in (torch.int8, torch.float8_e4m3fn) for v in state_dict.values())
+        if self.quantized and getattr(config, "cross_attention", False):
+            # the engine runs one weight format per model (activation buffers are laid out for it) and keeps cross-attention
+            # linears bf16: fail here, with the reason, instead of inside mmi_lm_create
+            raise NotImplementedError("quantised linears (int8 / fp8) are not supported for models with cross-attention layers; "
+                                      "load the bf16 checkpoint (quantize=False)")
 
         def place(k, v):     # quantised weights and their fp32 scales keep their dtype (utils/quantize.py:29-34); the rest is bf16
             if v.dtype in (torch.int8, torch.float8_e4m3fn):

@@ -180,6 +180,8 @@ def export_quantized(src: str | Path, dst: str | Path, fmt: str = "int8", lm_kwa
                                      f"(default dep_q = {cfg.dep_q}): pass the model's lm_kwargs")
                 break
     state = normalize_lm_state_dict(state, cfg)
+    if cfg.cross_attention or any(".cross_attention." in k for k in state):
+        raise NotImplementedError("quantised export of a model with cross-attention layers is not supported (the engine runs them bf16 only)")
     if fmt == "int8":
         out = quantize_lm_state_dict(state)
     elif fmt == "fp8":

@@ -189,9 +189,15 @@ class BatchedServer:
                 for sess in sessions:
                     if sess.closed:
                         continue
+                    channel = sess.channel
                     while True:
-                        fr = self.batcher.pop(sess.channel)
-                        if fr is None:
+                        # a handler may close (disconnect) or re-open (RESTART) the channel between the check above and the
+                        # pop: a vanished channel is that session's business, not a failure of the model loop
+                        try:
+                            fr = self.batcher.pop(channel)
+                        except ValueError:
+                            break
+                        if fr is None or sess.closed or sess.channel != channel:
                             break
                         sess.loop.call_soon_threadsafe(sess.queue.put_nowait, fr)
         except BaseException as e:                    # noqa: BLE001 - surfaced to the handlers and the tests
@@ -213,6 +219,10 @@ class BatchedServer:
         finds every slot taken gets an Error message (MT=5) and is closed - the Rust server's behaviour; the reference's Python
         server would make it wait on the lock."""
         import aiohttp
+        if self.errors:                               # the model loop is gone: a new connection would get a slot and no frames
+            await ws.send_bytes(encode_error(f"model loop failed: {self.errors[0]!r}"))
+            await ws.close()
+            return
         try:
             channel = self.batcher.open()
         except BufferError as e:
@@ -268,9 +278,16 @@ class BatchedServer:
                     with self._lock:
                         self._sessions.pop(channel, None)
                     self.batcher.close(channel)
-                    channel = self.batcher.open()
+                    try:
+                        channel = self.batcher.open()
+                    except BufferError as e:          # another connection took the slot in between
+                        await ws.send_bytes(encode_error(f"no free slot: {e}"))
+                        await ws.close()
+                        break
                     sess.channel = channel
                     sess.pending = np.zeros(0, np.float32)
+                    while not sess.queue.empty():     # frames of the old dialogue that were not sent yet
+                        sess.queue.get_nowait()
                     with self._lock:
                         self._sessions[channel] = sess
                 elif kind == MT_PING:

@@ -16,7 +16,10 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 # Logits tolerance (bf16 model, fp32 accumulation; only summation order / attention-backend rounding differ):
 #   max |d| <= LOGIT_MAX_REL * max|ref|   and   mean |d| <= LOGIT_MEAN_REL * max|ref|   per (row, sampling site).
 # Measured: the numpy oracle sits at max 3.1 % / mean 0.9 % (median 1.2 % / 0.4 %) from the reference PyTorch CPU path
-# on the golden vectors - pure bf16 rounding-order noise through 2 + 8x2 transformer layers.
+# on the golden vectors - pure bf16 rounding-order noise through 2 + 8x2 transformer layers.  The ENGINE against the same
+# goldens on MI355X (profiles/r03_logs/parity_golden_{tiny,wide}_cuda.json): tiny worst max 3.12 % / mean 0.90 %, 7B widths x 1
+# layer worst max 2.38 % / mean 0.50 %.  Gate = worst measured x 1.5, rounded: max 3.12 % x 1.5 = 4.7 % -> 5 %; the mean gate
+# (1.2 %) is already tighter than 0.90 % x 1.5 and stays.
 LOGIT_MAX_REL, LOGIT_MEAN_REL = 0.05, 0.012
 
 
@@ -137,9 +140,10 @@ def check_golden_wide(device, lib):
 # The reference ITSELF at the benchmark depth (tests/golden/make_golden_lm_full.py): Moshi-7B as loaders._lm_kwargs builds it,
 # 32 temporal layers, bf16 on the CPU, B = 2 with the rows one step apart, 4 greedy steps.  Two correct bf16 implementations
 # drift apart layer by layer under random-init weights (see FULL_DEPTH_FACTOR below), so the logits gate is FULL_WIDEN x the
-# shallow-model tolerance; the measured distances are written to gpurun_out/parity_golden_full_*.json and the gate is their
-# worst case x 1.5 (profiles/r03_logs/).
-FULL_WIDEN = 3.0
+# shallow-model tolerance.  Measured against the reference at 32 layers (profiles/r03_logs/parity_golden_full_cuda.json,
+# parity_golden_full_oracle_cpu.txt): engine worst max 5.77 % / mean 1.13 % (text head 2.30 % / 0.44 %), numpy oracle worst max
+# 6.10 % / mean 1.15 %.  Gate = the larger x 1.5 = 9.2 % of max|logit| -> FULL_WIDEN = 9.2 / 5.
+FULL_WIDEN = 1.85
 
 
 def load_full():

@@ -87,6 +87,9 @@ def test_bench_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2
     assert abs(out["value"] - 2 * 32 * 10 / 0.75) < 1e-6      # both ranks' sessions over the slower rank's time
+    # the latency figure is the job's: MAX over ranks (rank 1 pretends to be 1 ms slower), the per-rank figures alongside
+    assert out["p50_ms_per_step"] == 6.0 and out["p95_ms_per_step"] == 7.0
+    assert out["p50_ms_per_rank"] == [5.0, 6.0] and out["p95_ms_per_rank"] == [6.0, 7.0]
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -135,3 +135,48 @@ def test_concurrent_clients_each_get_their_own_stream(sim_lib):
             assert np.array_equal(pcm[f], expect[i][f][0]), f"client {i} frame {f}: audio differs from the batcher's own output"
         want_text = [str(int(tok[0])) for _, tok in expect[i] if int(tok[0]) not in (0, 3)]
         assert text == want_text
+
+
+def test_a_vanished_channel_does_not_stop_the_model_loop():
+    """A handler may close (disconnect) or re-open (RESTART) a channel between the loop's `closed` check and its pop - the
+    batcher then reports an unknown channel.  That must end nothing but this session's drain: the loop keeps stepping and
+    the other sessions keep receiving (server.py model loop)."""
+    import threading
+    import time
+
+    class FakeBatcher:
+        frame_size = 4
+
+        def __init__(self):
+            self.steps = 0
+            self.queues = {2: [("pcm", np.zeros(9, np.int64))] * 3}
+
+        def step(self):
+            self.steps += 1
+            return 1 if self.steps < 50 else 0
+
+        def pop(self, channel):
+            if channel == 1:
+                raise ValueError("unknown channel (mmi status -1)")
+            q = self.queues.get(channel, [])
+            return q.pop(0) if q else None
+
+    class Loop:
+        def __init__(self):
+            self.calls = []
+
+        def call_soon_threadsafe(self, fn, arg):
+            self.calls.append(arg)
+
+    server = srv.BatchedServer(FakeBatcher(), model_version=3, idle_sleep=0.001)
+    gone, alive = Loop(), Loop()
+    server._sessions[1] = srv._Session(1, None, gone)
+    server._sessions[2] = srv._Session(2, type("Q", (), {"put_nowait": None})(), alive)
+    server.start()
+    deadline = time.time() + 5
+    while server.batcher.steps < 50 and time.time() < deadline:
+        time.sleep(0.01)
+    server.stop()
+    assert not server.errors, server.errors
+    assert server.batcher.steps >= 50
+    assert len(alive.calls) == 3 and not gone.calls
