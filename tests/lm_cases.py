@@ -153,20 +153,22 @@ def load_full():
     return g, LMConfig()
 
 
-def check_golden_full(device, lib):
-    """The engine on the benchmark model (32 layers, context 3000) against the reference's own output, teacher-forced."""
+def check_golden_full(device, lib, max_batch=None, name=None):
+    """The engine on the benchmark model (32 layers, context 3000) against the reference's own output, teacher-forced.
+    max_batch: build the handle for that many sessions (> 16: the 32-row MFMA tile and k_gemm_xlds - the benchmark's kernels -
+    instead of the 16-row tile a 2-session handle gets)."""
     g, cfg = load_full()
     sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))     # CPU draw, as in the generator (the CUDA RNG stream differs)
     if torch.device(device).type == "cuda":
         sd = {k: v.to(device) for k, v in sd.items()}
     B = g["codes"].shape[1]
-    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    gen = make_engine(cfg, sd, device, lib, max_batch or B, use_sampling=False, support_out_of_sync=True)
     del sd
     with gen.streaming(B):
         def step(codes, forced):
             out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
             return out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
-        return check_wide_steps(step, g, cfg, name=f"golden_full_{torch.device(device).type}", widen=FULL_WIDEN,
+        return check_wide_steps(step, g, cfg, name=name or f"golden_full_{torch.device(device).type}", widen=FULL_WIDEN,
                                 set_mask=lambda m: gen.set_exec_mask(torch.from_numpy(m).to(device)))
 
 
@@ -265,7 +267,9 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
                     a_e, a_o = int(al[b, k].argmax()), int(oat[b, k])
                     assert a_e == a_o or near_tie(oal[b, k], a_e, a_o)
         if stats is not None:
+            import collections
             stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
+            stats["launch_sites"] = dict(collections.Counter(site for site, _ in gen.launch_list()))
 
 
 class ErrorLog:

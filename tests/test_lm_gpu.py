@@ -189,6 +189,12 @@ def test_benchmark_model_matches_the_reference_at_full_depth(gpu_lib):
     lm_cases.check_golden_full(DEV, None)
 
 
+def test_benchmark_kernels_match_the_reference_at_full_depth(gpu_lib):
+    """The same golden run on a handle built for 32 sessions: the 32-row tile, k_gemm_xlds, the split-K temporal GEMMs - the
+    kernels `bench.py` times - against the reference's own logits (a 2-session handle takes the 16-row tile)."""
+    lm_cases.check_golden_full(DEV, None, max_batch=32, name="golden_full_cuda_tile32")
+
+
 def test_c5_shape_int8_linears_at_64_sessions_match_oracle(gpu_lib):
     """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), row-wise int8 linears."""
     lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, quantize=True)
