@@ -12,6 +12,7 @@ namespace {
 struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
     int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
+    int gate_oct = 0;         // ... per row octet instead (MMI_EPI_GATE_OCT)
     float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; fp8: weight_scale * input_scale; KSTEPS then counts k-step PAIRS
     int wq = 0;               // 0 bf16, 1 int8, 2 fp8
     float xinv = 1.f;         // fp8: 1 / input_scale
@@ -159,8 +160,13 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
     const int TN = lm->T;
+    // gate_hidden < 0: a gated linear_in packed with the per-octet interleave (bf16 weights at the 32-row tile only)
+    const bool oct = gate_hidden < 0;
+    if (oct) gate_hidden = -gate_hidden;
+    if (oct && (q8 || lm->T != 32)) return mmi_fail(MMI_ERR_UNSUPPORTED, "octet-interleaved gate needs bf16 weights at the 32-row tile: " + name);
     g->K = K;
     g->gate = gate_hidden > 0 ? 1 : 0;
+    g->gate_oct = oct ? 1 : 0;
     g->N = gate_hidden > 0 ? gate_hidden : N;
     if (g->N % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "out_features must be a multiple of 8: " + name);
     const int rows_per_tile = gate_hidden > 0 ? TN / 2 : TN;
@@ -174,7 +180,7 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         g->wp = reinterpret_cast<u32x4*>(p);
         g->bytes = n * sizeof(uint16_t);
         MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
-                   TN, g->NT, g->KSTEPS, gate_hidden, col_scale);
+                   TN, g->NT, g->KSTEPS, oct ? -gate_hidden : gate_hidden, col_scale);
     } else {
         if (col_scale) return mmi_fail(MMI_ERR_UNSUPPORTED, "a folded norm needs bf16 linears: " + name);
         // int8: `<linear>.weight_scb` = row absmax (utils/quantize.py:20-22).  fp8: `<linear>.weight_scale` = dequantisation
@@ -261,7 +267,7 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
 int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T);
 // the fused-norm GEMMs: share when that brings the launch from under 128 workgroups to at most ~256
 int plan_osplit_norm(const GemmW& g, const GemmPlan& p, int epi, int T) {
-    if (epi == MMI_EPI_GATE || g.wq != 0 || (T != 32 && T != 16)) return 1;
+    if (epi == MMI_EPI_GATE || epi == MMI_EPI_GATE_OCT || g.wq != 0 || (T != 32 && T != 16)) return 1;
     if (const char* e = getenv("MMI_GEMM_OSPLIT")) { if (e[0]) return plan_osplit(g, p, epi, T); }
     int os = 1;
     while (os < T / 8 && (long)g.NT * os < 128) os *= 2;
@@ -272,7 +278,7 @@ int plan_osplit_norm(const GemmW& g, const GemmPlan& p, int epi, int T) {
 // bound by what a single CU can pull (~25 GB/s) - the depth transformer's N = 1024 linears: 32 tiles of 64-180 KB.
 // MMI_GEMM_OSPLIT: "0" = off, "2" / "4" = force (test hook / A-B), default = as many parts as bring the launch to >= 128 workgroups.
 int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T) {
-    if (epi == MMI_EPI_GATE || g.wq != 0 || p.ntw != 1 || (T != 32 && T != 16)) return 1;
+    if (epi == MMI_EPI_GATE || epi == MMI_EPI_GATE_OCT || g.wq != 0 || p.ntw != 1 || (T != 32 && T != 16)) return 1;
     const int octs = T / 8;
     int os = 1;
     const char* e = getenv("MMI_GEMM_OSPLIT");
@@ -344,7 +350,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     // no prefetched addend, no split-K: the residual form only in place on a packed buffer (each workgroup reads the 8-feature
     // groups it then writes)
     const bool resid_ok = a.epi == MMI_EPI_RESID && a.out_mode == MMI_OUT_PACKED && a.resid == a.out;
-    if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE && !resid_ok) return p;
+    if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_GATE_OCT && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE && !resid_ok) return p;
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
     if (tg && atoi(tg) > 0) cus = atoi(tg);
@@ -354,14 +360,15 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     else if (tg && g.KSTEPS % 8 == 0) p.kc = 8;
     else if (tg && g.KSTEPS % 4 == 0) p.kc = 4;
     else return p;
+    const int ntmax = (a.epi == MMI_EPI_GATE_OCT && mode == '2' && g.wq == 0) ? 4 : 3;      // tiles a workgroup may touch (launch_xlds_n)
     p.grid = g.NT < cus ? g.NT : cus;
     // shared out in row octets, a GEMM with fewer n-tiles than CUs still covers the chip (out_proj: 128 tiles = 512 octets)
     if (a.epi != MMI_EPI_GATE && !a.whole_tiles && a.epi == MMI_EPI_RESID) p.grid = 4L * g.NT < cus ? 4 * g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
-    if (a.epi != MMI_EPI_GATE && !a.whole_tiles) {   // the kernel shares the tiles out in row octets: no workgroup may touch more than 3 tiles
+    if (a.epi != MMI_EPI_GATE && !a.whole_tiles) {   // the kernel shares the tiles out in row octets: no workgroup may touch more than ntmax tiles
         for (long b = 0; b < p.grid; ++b) {
             const long u0 = b * 4L * g.NT / p.grid, u1 = (b + 1) * 4L * g.NT / p.grid;
-            if (u1 > u0 && ((u1 + 3) >> 2) - (u0 >> 2) > 3) return p;
+            if (u1 > u0 && ((u1 + 3) >> 2) - (u0 >> 2) > ntmax) return p;
         }
     }
     p.stagger = mode == '2' && g.wq == 0;                     // per-tile epilogues under the last chunk's stream (bf16)
@@ -372,16 +379,24 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     return p;
 }
 
-template <int MT, int KC, bool STAGGER, int WQ, bool NORM>
-int launch_xlds_n(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+template <int MT, int KC, bool STAGGER, int WQ, bool NORM, int NTMAX>
+int launch_xlds_t(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3, STAGGER, WQ, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, NTMAX, STAGGER, WQ, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_set = true;
     }
-    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3, STAGGER, WQ, NORM>), p.grid, 512, p.smem, s, a);
+    MMI_LAUNCH((k_gemm_xlds<MT, KC, NTMAX, STAGGER, WQ, NORM>), p.grid, 512, p.smem, s, a);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
+}
+template <int MT, int KC, bool STAGGER, int WQ, bool NORM>
+int launch_xlds_n(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
+    // the octet-interleaved gated linear_in: 11 octets per workgroup touch up to 4 tiles
+    if constexpr (WQ == 0 && STAGGER) {
+        if (a.epi == MMI_EPI_GATE_OCT) return launch_xlds_t<MT, KC, STAGGER, WQ, NORM, 4>(s, p, a);
+    }
+    return launch_xlds_t<MT, KC, STAGGER, WQ, NORM, 3>(s, p, a);
 }
 template <int MT, int KC, bool STAGGER, int WQ>
 int launch_xlds_v(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
@@ -410,6 +425,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
+    if (g.gate_oct && a.epi == MMI_EPI_GATE) a.epi = MMI_EPI_GATE_OCT;     // the weights say how their tiles interleave gate and value rows
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     a.osplit = plan_osplit(g, p, a.epi, lm->T);
@@ -1004,7 +1020,13 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
         if ((rc = load_linear(lm, W, p + ".self_attn.in_projs.0.weight", 3 * d, d, 0, &L.in_proj, nullptr, nullptr,
                               lm->fold1 && l > 0 ? L.n1 : nullptr))) return fail(rc);
         if ((rc = load_linear(lm, W, p + ".self_attn.out_projs.0.weight", d, d, 0, &L.out_proj))) return fail(rc);
-        if ((rc = load_linear(lm, W, p + ".gating.linear_in.weight", 2 * c.ffn_hidden, d, c.ffn_hidden, &L.ffn_in, nullptr, nullptr,
+        // MMI_GATE_OCT=1: the temporal linear_in interleaves gate / value rows per row octet so that k_gemm_xlds shares its 704
+        // tiles out in octets (11 per workgroup instead of 2 or 3 whole tiles).  OFF by default: measured SLOWER on MI355X - 40.2
+        // against 39.0 us per launch at 32 sessions, 49.5 against 44.6 us at 64 (profiles/r03_logs/gate_oct_ab.txt): a workgroup
+        // then touches up to 4 tiles, i.e. issues 4 weight loads per k-step of which 2.75 carry new bytes, and the stream is
+        // bound by the loads in flight, not by the 8 % imbalance.
+        const bool oct = lm->q8 == 0 && lm->T == 32 && c.ffn_hidden % 4 == 0 && getenv("MMI_GATE_OCT") && getenv("MMI_GATE_OCT")[0] == '1';
+        if ((rc = load_linear(lm, W, p + ".gating.linear_in.weight", 2 * c.ffn_hidden, d, oct ? -c.ffn_hidden : c.ffn_hidden, &L.ffn_in, nullptr, nullptr,
                               lm->fold2 ? L.n2 : nullptr))) return fail(rc);
         if ((rc = load_linear(lm, W, p + ".gating.linear_out.weight", d, c.ffn_hidden, 0, &L.ffn_out))) return fail(rc);
         if (c.cross_attention) {
@@ -1481,8 +1503,11 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (kernel_name)
         *kernel_name = lm->q8 == 1   ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
                        : lm->q8 == 2 ? "k_gemm_xp<32, 1, 1, 8, 2, 2> (temporal FFN linear_in, fp8 weights on the fp8 MFMA + SiLU gate)"
-                       : lm->dominant_xlds ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
-                                                             : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)")
+                       : lm->dominant_xlds ? (!lm->layers.empty() && lm->layers[0].ffn_in.gate_oct
+                                                  ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 4, true, 0> (temporal FFN linear_in + SiLU gate, tiles shared in row octets)"
+                                                                    : "k_gemm_xlds<1, 64, 4, true, 0> (temporal FFN linear_in + SiLU gate, tiles shared in row octets)")
+                                                  : (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
+                                                                    : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)"))
                                      : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;

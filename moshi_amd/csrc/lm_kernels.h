@@ -55,7 +55,12 @@ __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restri
     int k = ks * kstep + 8 * kq + e;
     long row;
     bool valid;
-    if (gate_hidden > 0) {
+    if (gate_hidden < 0) {             // per-octet interleave (MMI_EPI_GATE_OCT): row i of the tile -> octet i >> 3, r = i & 7
+        const int H = -gate_hidden;
+        const int f = nt * (TN / 2) + 4 * (i >> 3) + (i & 3);
+        valid = f < H;
+        row = ((i & 7) < 4 ? 0 : H) + f;
+    } else if (gate_hidden > 0) {
         int half = TN / 2;
         int r = nt * half + (i < half ? i : i - half);
         valid = r < gate_hidden;
@@ -91,7 +96,12 @@ __global__ void k_pack_w_i8(const int8_t* __restrict__ W, int8_t* __restrict__ P
     int k = (2 * kp + (e >> 3)) * kstep + 8 * kq + (e & 7);
     long row;
     bool valid;
-    if (gate_hidden > 0) {
+    if (gate_hidden < 0) {             // per-octet interleave (MMI_EPI_GATE_OCT): row i of the tile -> octet i >> 3, r = i & 7
+        const int H = -gate_hidden;
+        const int f = nt * (TN / 2) + 4 * (i >> 3) + (i & 3);
+        valid = f < H;
+        row = ((i & 7) < 4 ? 0 : H) + f;
+    } else if (gate_hidden > 0) {
         int half = TN / 2;
         int r = nt * half + (i < half ? i : i - half);
         valid = r < gate_hidden;
@@ -145,7 +155,11 @@ __device__ __forceinline__ u32x2 mmi_bf16x8_to_fp8(u32x4 x, float inv) {
 // fragments from L2.  The waves' partial tiles are summed through LDS in a fixed order (deterministic), and the
 // epilogue (bf16 rounding point of nn.Linear, residual add, SiLU gate, embedding add) writes 8 consecutive features
 // of one session as one 16-byte vector.
-enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5, MMI_EPI_DEP_QKV0 = 6 };
+enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5, MMI_EPI_DEP_QKV0 = 6,
+       // gated linear_in whose tiles interleave gate and value rows PER ROW OCTET (k_pack_w_bf16 gate_hidden < 0): octet o of tile nt
+       // = gate rows of features 16 nt + 4 o .. + 3, then their value rows - every octet is self-contained, so k_gemm_xlds can
+       // share the tiles out in octets (704 tiles over 256 workgroups = 11 octets each instead of 2 or 3 whole tiles)
+       MMI_EPI_GATE_OCT = 7 };
 enum { MMI_OUT_ROWMAJOR = 0, MMI_OUT_PACKED = 1 };
 
 struct GemmArgs {
@@ -270,8 +284,9 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 
     // ---- epilogue: one task = 8 consecutive output features of one session
     const bool gate = a.epi == MMI_EPI_GATE;
-    const int rows_out = gate ? TN / 2 : TN;         // output features per tile
-    const int G = rows_out / 8;                      // feature groups per tile
+    const bool gate_oct = a.epi == MMI_EPI_GATE_OCT; // 4 output features per task: one row octet = 4 gate rows + their 4 value rows
+    const int rows_out = (gate || gate_oct) ? TN / 2 : TN;         // output features per tile
+    const int G = gate_oct ? TN / 8 : rows_out / 8;  // feature groups per tile
     const int ntasks = NTW * MT * G * TN;
     for (int q = (int)threadIdx.x; q < ntasks; q += WAVES * 64) {
         const int bl = q % TN;
@@ -281,7 +296,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         const int m = rest % MT, t = rest / MT;
         const int nt = nt0 + t;
         const int b = m * TN + bl;
-        const int n0 = nt * rows_out + 8 * gi;
+        const int n0 = nt * rows_out + (gate_oct ? 4 : 8) * gi;
         if (nt >= a.NT || b >= a.B || n0 >= a.N || gi < g_lo || gi >= g_hi) continue;
         const float* rb = red + (t * MT + m) * 64 * LS;
         // features 8*gi .. 8*gi+7 of the tile live in two lanes' accumulator quads (MFMA C layout, lm_kernels.h header):
@@ -328,6 +343,24 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s2[e] *= g0[e]; s2[4 + e] *= g1[e]; }
             }
+        }
+        if (gate_oct) {
+            // s[0..3] = the octet's gate rows (lane bl), s[4..7] = its value rows (lane bl + 32): 4 output features, 8 bytes
+            u32x2 ov;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float y[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float g = mmi_round_bf16(s[2 * e + h]);
+                    const float u = mmi_round_bf16(s[4 + 2 * e + h]);
+                    y[h] = mmi_round_bf16(g / (1.0f + expf(-g))) * u;       // F.silu on a bf16 tensor, times the value
+                }
+                ov[e] = mmi_pack_bf16x2(y[0], y[1]);
+            }
+            uint16_t* dst4 = a.out_mode == MMI_OUT_PACKED ? a.out + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.out + (long)b * a.out_ld + n0;
+            *reinterpret_cast<u32x2*>(dst4) = ov;
+            continue;
         }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
@@ -802,7 +835,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     // 384 in_proj tiles over 256 workgroups are 6 octets = 1.5 tiles each instead of 1 or 2 whole tiles, i.e. every CU streams
     // the same number of bytes.  A workgroup that owns only part of a tile loads only those octets' lanes (the other lanes
     // repeat a valid lane's address: rows of the MFMA are independent, their results are simply not written).
-    const bool by_octet = a.epi != MMI_EPI_GATE && !a.whole_tiles;
+    const bool by_octet = a.epi != MMI_EPI_GATE && !a.whole_tiles;      // MMI_EPI_GATE_OCT: octets are self-contained
     const long units = by_octet ? 4L * a.NT : (long)a.NT;
     const long u0 = (long)bid * units / G, u1 = (long)(bid + 1) * units / G;          // [u0, u1) octets or tiles
     const int t0 = by_octet ? (int)(u0 >> 2) : (int)u0;

@@ -133,6 +133,16 @@ def test_rmsnorm_folded_across_gemm_pairs(sim_lib, monkeypatch, B, ksplit):
     assert st["launch_sites"]["L.in_proj"] == 3 and st["launch_sites"]["L.ffn_in"] == 3
 
 
+@pytest.mark.parametrize("B", [18, 34])
+def test_gated_linear_in_shared_out_in_row_octets(sim_lib, monkeypatch, B):
+    """MMI_GATE_OCT=1 (opt-in, measured slower on hardware): gate and value rows interleaved per row octet, the gated GEMM's
+    tiles shared out in octets on k_gemm_xlds (up to 4 tiles per workgroup), 4-feature epilogue tasks."""
+    monkeypatch.setenv("MMI_GATE_OCT", "1")
+    monkeypatch.setenv("MMI_GEMM_LDS", "2")
+    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "7")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=190 + B, B=B, S=2)
+
+
 def test_norm_launches_are_the_default(sim_lib, monkeypatch):
     """Without MMI_NORM_FOLD=1 the weights stay plain and the k_resid_rmsnorm launches stay (the reference's rounding points)."""
     monkeypatch.setenv("MMI_GEMM_LDS", "2")
