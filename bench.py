@@ -329,9 +329,9 @@ def main():
         if workload in ("duplex", "mimi"):
             lists["mimi_encode"], lists["mimi_decode"] = mimi.launch_list("encode"), mimi.launch_list("decode")
         if lm_gen is not None:
-            lists["lm"] = lm_gen.launch_list()
+            lists["lm"] = lm_gen.launch_list(with_bytes=True)
         for k, v in lists.items():
-            (d / f"launch_list_{k}.tsv").write_text("".join(f"{s_}\t{kn}\n" for s_, kn in v))
+            (d / f"launch_list_{k}.tsv").write_text("".join("\t".join(str(x) for x in row) + "\n" for row in v))
 
     # p50 / p95 latency of a single step (BASELINE.json's second figure): a separate, untimed-for-`value` pass with a
     # device event before and after every step and no host synchronisation inside the loop.  Pipelined: every frame completes
@@ -395,7 +395,9 @@ def main():
                                "kernel": "whole Mimi step (all kernels)", "algorithmic_bytes": nbytes}
         elif lm_gen is not None:
             from bench_lm import lm_step_algorithmic_bytes, roofline_lm
-            out["roofline"] = roofline_lm(lm_gen, step, args, sync)
+            # ring depth of every session in the middle of the profiled steps (they follow the timed region and the latency pass)
+            done = args.warmup + args.steps + max(8, min(args.steps, 40)) + max(4, min(args.steps, 20)) // 2
+            out["roofline"] = roofline_lm(lm_gen, step, args, sync, kv_rows=[(args.stagger * b if B > 1 else staggered) + done for b in range(B)])
             # the WHOLE step against the HBM roofline: LM weights once + every session's KV at its depth at
             # the middle of the timed region (+ Mimi's weights / rings / KV when the step includes the codec)
             mid = args.warmup + args.steps // 2

@@ -87,7 +87,7 @@ def lm_step_algorithmic_bytes(cfg, L_per_row, quant="none", kv="bf16"):
     return wbytes + kvb
 
 
-def roofline_lm(lm_gen, step_fn, args, sync):
+def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
     """Dominant kernel = the temporal FFN linear_in GEMM (184.5 MB of weights per launch, 32 launches per step).
     Timed live with hipEvents on the launch stream over `steps` un-graphed steps (include/moshi_mi.h profile tap)."""
     lib, h = lm_gen._lib, lm_gen.lm_model._handle
@@ -95,6 +95,10 @@ def roofline_lm(lm_gen, step_fn, args, sync):
     lib.check(lib.mmi_lm_profile_begin(h))
     for _ in range(max(4, min(args.steps, 20))):
         step_fn()
+    sync()
+    from moshi_amd import _capi
+    n_prof = max(4, min(args.steps, 20))
+    site_txt = _capi.read_text(lambda buf, cap: lib.mmi_lm_profile_sites(h, buf, cap))
     mean_ms, n, nbytes, name = C.c_double(), C.c_int64(), C.c_int64(), C.c_char_p()
     lib.check(lib.mmi_lm_profile_end(h, C.byref(mean_ms), C.byref(n), C.byref(nbytes), C.byref(name)))
     ach = nbytes.value / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
@@ -102,6 +106,25 @@ def roofline_lm(lm_gen, step_fn, args, sync):
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "traffic": None, "kernel": kname, "avg_launch_ms": mean_ms.value,
            "launches_timed": n.value, "algorithmic_bytes_per_launch": nbytes.value}
+    # every site of the LM step, live: hipEvent pairs around each op of the same un-graphed steps (dispatch gaps included, so a
+    # few us above the rocprofv3 kernel durations of profiles/*_sites.csv).  GB/s = packed weight bytes of the GEMM / time;
+    # the attention's bytes are the valid K and V rows of the sessions at their depth in the middle of these steps.
+    cfg_ = lm_gen.lm_model.config
+    sites = {}
+    for line in site_txt.splitlines():
+        f = line.split("\t")
+        if len(f) < 4 or int(f[1]) == 0:
+            continue
+        site, ops, tot_ms, wbytes = f[0], int(f[1]), float(f[2]), int(f[3])
+        us = 1e3 * tot_ms / ops
+        rec = {"ops_per_step": ops / n_prof, "us_per_op": us, "us_per_step": 1e3 * tot_ms / n_prof}
+        if site == "L.attn" and kv_rows is not None:
+            s_kv = 1 if getattr(args, "kv", "bf16") == "fp8" else 2
+            wbytes = int(sum(2 * cfg_.dim * s_kv * (min(L, cfg_.context) + 1) for L in kv_rows))
+        if wbytes > 0:
+            rec.update({"bytes_per_op": wbytes, "GBps": wbytes / us / 1e3, "frac": wbytes / us / 1e3 / HBM_PEAK_GBS})
+        sites[site] = rec
+    out["sites"] = sites
     # secondary figure (north_star: "achieved MFMA/HBM fraction"): the same launch's matrix-core rate.  The GEMM is
     # 2 * N * K * B flops with N = 2 * ffn_hidden rows, K = dim, B sessions; dense peaks from MI355X_MICROARCH.md.
     cfg = lm_gen.lm_model.config

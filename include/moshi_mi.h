@@ -301,7 +301,7 @@ int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, mmi_stre
  * replay the reference's token history exactly. */
 int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream);
 
-/* The launch list of one frame step, recorded while the step ran for the first time: one line "site<TAB>kernel" per kernel
+/* The launch list of one frame step, recorded while the step ran for the first time: one line "site<TAB>kernel[<TAB>weight bytes]" per kernel
  * launch in launch order (sites: "L.in_proj", "L.ffn_in", "dep.out_proj", "text_linear", ...).  scripts/rocpd_sites.py joins
  * it with a rocprofv3 kernel trace by position inside the step, which is how per-site durations of kernels that share one
  * name are recomputed under profiles/.  Returns the bytes needed including the final NUL (call with buf = NULL to size);
@@ -318,6 +318,10 @@ int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream);
 /* Dominant-kernel timing tap for bench.py's roofline object: when enabled, steps run un-graphed and
  * every launch of the widest weight-streaming GEMM is bracketed by hipEvents on `stream`. */
 int mmi_lm_profile_begin(mmi_lm* lm);
+/* Per-site timings of the steps run since mmi_lm_profile_begin: one line "site<TAB>ops<TAB>total ms<TAB>weight bytes per op"
+ * per site of the launch list (hipEvent pairs around every op of the un-graphed steps; dispatch gaps included).  Call before
+ * mmi_lm_profile_end; synchronises the stream.  Returns the bytes needed including the final NUL (buf = NULL to size). */
+int64_t mmi_lm_profile_sites(mmi_lm* lm, char* buf, int64_t cap);
 /* Returns the mean duration (ms) and launch count since mmi_lm_profile_begin, plus the algorithmic
  * bytes one such launch streams (packed weight bytes + activations in/out). Synchronises the stream. */
 int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,

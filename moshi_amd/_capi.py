@@ -143,6 +143,7 @@ SIGNATURES = {
     "mmi_mimi_launch_list": (C.c_int64, [_P, C.c_int32, _P, C.c_int64]),
     "mmi_lm_seek": (C.c_int, [_P, _P, _P]),
     "mmi_lm_profile_begin": (C.c_int, [_P]),
+    "mmi_lm_profile_sites": (C.c_int64, [_P, _P, C.c_int64]),
     "mmi_lm_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_char_p)]),
 }
@@ -230,17 +231,24 @@ def stream_ptr(device: torch.device) -> Optional[int]:
     return None
 
 
-def launch_list(call):
-    """Decode a `mmi_*_launch_list` buffer: [(site, kernel)] in launch order; [] before the first step."""
+def read_text(call) -> str:
+    """A `(buf, cap) -> bytes needed` text getter of the ABI, sized and read."""
     need = int(call(None, 0))
     if need <= 1:
-        return []
+        return ""
     buf = C.create_string_buffer(need)
     call(C.cast(buf, C.c_void_p), need)
+    return buf.value.decode()
+
+
+def launch_list(call, with_bytes: bool = False):
+    """Decode a `mmi_*_launch_list` buffer: [(site, kernel)] in launch order ([(site, kernel, weight bytes)] with_bytes);
+    [] before the first step."""
     out = []
-    for line in buf.value.decode().splitlines():
-        site, _, kern = line.partition("\t")
-        out.append((site, kern))
+    for line in read_text(call).splitlines():
+        f = line.split("\t")
+        site, kern, nb = f[0], f[1] if len(f) > 1 else "", int(f[2]) if len(f) > 2 else 0
+        out.append((site, kern, nb) if with_bytes else (site, kern))
     return out
 
 

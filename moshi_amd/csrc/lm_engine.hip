@@ -121,6 +121,9 @@ struct mmi_lm {
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
     // profiling tap
+    struct SiteEv { size_t op; hipEvent_t a, b; };
+    std::vector<SiteEv> site_ev;     // one pair per eagerly run op while profiling (mmi_lm_profile_sites)
+    size_t site_ev_used = 0;
     bool profiling = false;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
@@ -444,6 +447,7 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
         MMI_HIP_CHECK(hipEventRecord(ev->a, s));
     }
     int rc;
+    mmi_record_bytes((long)g.bytes);
     if (a.ss && !xl.on) return mmi_fail(MMI_ERR_UNSUPPORTED, "a GEMM with a folded RMSNorm did not take k_gemm_xlds");
     if (a.finish_ctr && (p.ksplit > 4 || xl.on)) return mmi_fail(MMI_ERR_UNSUPPORTED, "split-K finish: unsupported plan");
     if (is_dominant) lm->dominant_xlds = xl.on;
@@ -490,7 +494,7 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
     a.out_ld = out_features;
     a.out_ksteps = packed_ksteps(lm, out_features);
     GemmW gw = g;
-    lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); });
+    lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); }, (long)g.bytes);
 }
 
 // K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
@@ -513,7 +517,7 @@ int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, 
         a.out = x; a.resid = x; a.out_mode = MMI_OUT_PACKED; a.out_ld = features; a.out_ksteps = packed_ksteps(lm, features);
     }
     GemmW gw = g;
-    lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); });
+    lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); }, (long)g.bytes);
     return finish ? 0 : p.ksplit;
 }
 
@@ -560,7 +564,9 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
         a.osplit = (e && atoi(e) != 0) || getenv("MMI_GEMM_OSPLIT") ? plan_osplit_norm(g, pp, epi, lm->T) : 1;
     }
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
+    const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
+        mmi_record_bytes(gbytes);
         if (wq == 1) {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
@@ -576,7 +582,7 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
         }
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
-    });
+    }, gbytes);
 }
 
 // next_k >= 0: the sampled token opens depth-transformer micro-step next_k, whose input row the sampler writes itself
@@ -731,7 +737,7 @@ int build_program(mmi_lm* lm) {
             ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context; ga.kv8 = kv8 ? 1 : 0;
             ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
-            P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); });
+            P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); }, (long)gw.bytes);
         }
         P.site("L.attn");
         P.add([=](hipStream_t s) {
@@ -1116,6 +1122,7 @@ extern "C" void mmi_lm_destroy(mmi_lm* lm) {
     mmi_lm_streaming_stop(lm);
     lm->wts.release();
     for (auto& e : lm->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : lm->site_ev) { if (e.a) hipEventDestroy(e.a); if (e.b) hipEventDestroy(e.b); }
     if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
     delete lm;
 }
@@ -1476,7 +1483,57 @@ extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     lm->profiling = true;
     lm->ev_used = 0;
+    lm->site_ev_used = 0;
+    lm->prog.tap = [lm](size_t i, bool begin, hipStream_t s) {       // an event pair around every op of the un-graphed steps
+        if (begin) {
+            if (lm->site_ev_used == lm->site_ev.size()) {
+                mmi_lm::SiteEv e{0, nullptr, nullptr};
+                if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+                lm->site_ev.push_back(e);
+            }
+            lm->site_ev[lm->site_ev_used].op = i;
+            hipEventRecord(lm->site_ev[lm->site_ev_used].a, s);
+        } else if (lm->site_ev_used < lm->site_ev.size() && lm->site_ev[lm->site_ev_used].op == i) {
+            hipEventRecord(lm->site_ev[lm->site_ev_used].b, s);
+            lm->site_ev_used += 1;
+        }
+    };
     return MMI_OK;
+}
+
+// Per-site timings of the steps run since mmi_lm_profile_begin: one line "site<TAB>ops<TAB>total ms<TAB>weight bytes per op" per
+// site of the launch list (hipEvent pairs around every op of the un-graphed steps: dispatch gaps included).  Call before
+// mmi_lm_profile_end; synchronises the stream.  Returns the bytes needed including the final NUL.
+extern "C" int64_t mmi_lm_profile_sites(mmi_lm* lm, char* buf, int64_t cap) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !lm->profiling) return 0;
+    if (lm->prof_stream) hipStreamSynchronize(lm->prof_stream);
+    else hipDeviceSynchronize();
+    std::vector<std::string> order;
+    std::vector<double> tot;
+    std::vector<long> cnt, bytes;
+    for (size_t k = 0; k < lm->site_ev_used; ++k) {
+        const auto& e = lm->site_ev[k];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+        const std::string& site = lm->prog.sites[e.op];
+        size_t j = 0;
+        while (j < order.size() && order[j] != site) ++j;
+        if (j == order.size()) { order.push_back(site); tot.push_back(0.0); cnt.push_back(0); bytes.push_back(0); }
+        tot[j] += ms; cnt[j] += 1;
+        if (lm->prog.op_bytes[e.op] > bytes[j]) bytes[j] = lm->prog.op_bytes[e.op];
+    }
+    (void)hipGetLastError();
+    std::string all;
+    for (size_t j = 0; j < order.size(); ++j)
+        all += order[j] + "\t" + std::to_string(cnt[j]) + "\t" + std::to_string(tot[j]) + "\t" + std::to_string(bytes[j]) + "\n";
+    const int64_t need = (int64_t)all.size() + 1;
+    if (buf && cap > 0) {
+        const int64_t n = need <= cap ? need - 1 : cap - 1;
+        memcpy(buf, all.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return need;
 }
 
 extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launches, int64_t* bytes_per_launch,
@@ -1485,6 +1542,7 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->profiling) return mmi_fail(MMI_ERR_STATE, "profiling was not started");
     lm->profiling = false;
+    lm->prog.tap = nullptr;
     if (lm->prof_stream || lm->ev_used) MMI_HIP_CHECK(hipStreamSynchronize(lm->prof_stream));
     double tot = 0.0;
     for (size_t i = 0; i < lm->ev_used; ++i) {

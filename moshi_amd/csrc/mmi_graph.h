@@ -13,11 +13,14 @@
 // the per-site durations of kernels that share one name (k_gemm_xp serves six GEMM shapes) are recomputed.
 void mmi_record_begin(std::vector<std::string>* log);
 void mmi_record_site(const char* site);
+void mmi_record_bytes(long bytes);      // the NEXT launch streams this many weight bytes: third column of its line
 void mmi_record_end();
 
 struct MmiProgram {
     std::vector<std::function<int(hipStream_t)>> ops;
     std::vector<std::string> sites;             // one label per op
+    std::vector<long> op_bytes;                 // weight bytes the op streams (GEMMs), 0 otherwise
+    std::function<void(size_t, bool, hipStream_t)> tap;   // profiling: called before (true) and after (false) every eagerly run op
     std::vector<std::string> launch_log;        // "site\tkernel" per launch, in launch order (filled by the first run)
     std::string site_ = "-";                    // label given to the ops added from now on
     bool logged = false;
@@ -30,7 +33,7 @@ struct MmiProgram {
     size_t cut_ = 0;
 
     void site(const std::string& label) { site_ = label; }
-    void add(std::function<int(hipStream_t)> f) { ops.push_back(std::move(f)); sites.push_back(site_); }
+    void add(std::function<int(hipStream_t)> f, long bytes = 0) { ops.push_back(std::move(f)); sites.push_back(site_); op_bytes.push_back(bytes); }
 
     int run_eager(hipStream_t s) {
         const bool rec = !logged;
@@ -38,7 +41,9 @@ struct MmiProgram {
         int rc = MMI_OK;
         for (size_t i = 0; i < ops.size() && !rc; ++i) {
             if (rec) mmi_record_site(sites[i].c_str());
+            if (tap) tap(i, true, s);
             rc = ops[i](s);
+            if (tap) tap(i, false, s);
         }
         if (rec) { mmi_record_end(); logged = true; }
         return rc;
@@ -85,7 +90,9 @@ struct MmiProgram {
             for (size_t i = 0; i < ops.size() && !rc; ++i) {
                 if (i == cut && (rc = between(s))) break;
                 if (rec) mmi_record_site(sites[i].c_str());
+                if (tap) tap(i, true, s);
                 rc = ops[i](s);
+                if (tap) tap(i, false, s);
             }
             if (rec) { mmi_record_end(); logged = true; }
             return rc;
@@ -114,6 +121,8 @@ struct MmiProgram {
         graph = nullptr;
         ops.clear();
         sites.clear();
+        op_bytes.clear();
+        tap = nullptr;
         launch_log.clear();
         logged = false;
         site_ = "-";

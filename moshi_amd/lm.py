@@ -413,9 +413,10 @@ class LMGen:
         arr = (C.c_int64 * len(offs))(*offs)
         self._lib.check(self._lib.mmi_lm_seek(self.lm_model._handle, C.cast(arr, C.c_void_p), self._stream()))
 
-    def launch_list(self):
-        """[(site, kernel)] per kernel launch of one step, in launch order (recorded during the first step)."""
-        return _capi.launch_list(lambda buf, cap: self._lib.mmi_lm_launch_list(self.lm_model._handle, buf, cap))
+    def launch_list(self, with_bytes: bool = False):
+        """[(site, kernel)] per kernel launch of one step, in launch order (recorded during the first step); with_bytes: a
+        third field, the weight bytes a GEMM launch streams."""
+        return _capi.launch_list(lambda buf, cap: self._lib.mmi_lm_launch_list(self.lm_model._handle, buf, cap), with_bytes)
 
     # ---- step ------------------------------------------------------------------------------------
     def _step(self, input_tokens: torch.Tensor, want_taps: bool, noise: Optional[torch.Tensor],

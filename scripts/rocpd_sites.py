@@ -7,8 +7,10 @@ step issued which kernel (`mmi_lm_launch_list` / `mmi_mimi_launch_list`, one "si
 
     python scripts/rocpd_sites.py <results.db> <launch_list_dir> [--header "comment"] > profiles/<name>_sites.csv
 
-Columns: program, site, launches per step, mean us per step, mean us per launch, algorithmic MB per launch (weight-streaming
-sites of the 7B bf16 model; blank otherwise), GB/s, fraction of the 8 TB/s HBM peak.
+Columns: program, site, launches per step, mean us per step, mean us per launch, algorithmic MB per launch (the packed weight
+bytes the engine recorded for the launch - third column of the launch list, right for bf16, int8 and fp8 weights alike; the
+7B bf16 table below only serves lists written before the engine recorded them), GB/s, fraction of the 8 TB/s HBM peak.
+The pipelined step runs its three programs on three streams: each program is matched on the stream that replays it.
 """
 import sqlite3
 import sys
@@ -38,11 +40,13 @@ def short(name):
 
 
 def load_list(path):
+    """[(site, kernel, weight bytes or 0)]: `bench.py --launch-lists` writes the engine's launch list, whose GEMM lines carry the
+    packed weight bytes of the launch (whatever the weight format: bf16, int8, fp8)."""
     out = []
     for line in Path(path).read_text().splitlines():
         if line.strip():
-            site, _, kern = line.partition("\t")
-            out.append((site, kern))
+            f = line.split("\t")
+            out.append((f[0], f[1] if len(f) > 1 else "", int(f[2]) if len(f) > 2 else 0))
     return out
 
 
@@ -52,21 +56,35 @@ def main():
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
-    rows = c.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-    names = [short(r[0]) for r in rows]
-    dur = [(r[2] - r[1]) / 1e3 for r in rows]
+    # the pipelined step runs the encoder, the LM and the decoder on three streams: a program's launches are consecutive on ITS
+    # stream, not in the global order
+    scol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
+    rows = c.execute(f"select {name_col}, start, end, {scol} from kernels order by start").fetchall()
+    by_stream = {}
+    for r in rows:
+        by_stream.setdefault(r[3], []).append(r)
     if header:
         print("# " + header)
     print("program,site,launches_per_step,us_per_step,us_per_launch,algorithmic_MB_per_launch,GBps,frac_of_8TBps")
-    nbytes = site_bytes_7b()
+    nbytes = site_bytes_7b()           # fallback for launch lists written before the engine recorded bytes
+    seen_bytes = set()
     for prog in ("lm", "mimi_encode", "mimi_decode"):
         f = ldir / f"launch_list_{prog}.tsv"
         if not f.exists():
             continue
         ll = load_list(f)
-        want = [k for _, k in ll]
+        want = [k for _, k, _ in ll]
         n = len(want)
-        starts = [i for i in range(len(names) - n + 1) if names[i] == want[0] and names[i:i + n] == want]
+        names, dur, starts = [], [], []
+        for srows in by_stream.values():           # the stream that replays this program
+            nm = [short(r[0]) for r in srows]
+            st = [i for i in range(len(nm) - n + 1) if nm[i] == want[0] and nm[i:i + n] == want]
+            if len(st) > len(starts):
+                names, dur, starts = nm, [(r[2] - r[1]) / 1e3 for r in srows], st
+        for site, _, nb in ll:                      # bytes of a site = its heaviest launch (the engine's own figure)
+            if nb:
+                nbytes[site] = max(nb, nbytes.get(site, 0)) if site in seen_bytes else nb
+                seen_bytes.add(site)
         # keep the graph-replayed steps of the timed region: the last half of the matches
         starts = starts[len(starts) // 2:]
         if not starts:
@@ -74,13 +92,13 @@ def main():
             continue
         per_site, cnt, order = {}, {}, []
         for st in starts:
-            for j, (site, _) in enumerate(ll):
+            for j, (site, _, _) in enumerate(ll):
                 if site not in per_site:
                     per_site[site] = 0.0
                     cnt[site] = 0
                     order.append(site)
                 per_site[site] += dur[st + j]
-        for site, _ in ll:
+        for site, _, _ in ll:
             cnt[site] += 1
         total = 0.0
         for site in order:

@@ -29,3 +29,26 @@ def test_sites_join_by_position(tmp_path):
     assert rows["L.in_proj"][2] == "2" and abs(float(rows["L.in_proj"][3]) - 40.0) < 1e-6 and abs(float(rows["L.in_proj"][4]) - 20.0) < 1e-6
     assert abs(float(rows["L.ffn_in"][4]) - 40.0) < 1e-6
     assert abs(float(rows["L.ffn_in"][6]) - 2 * 2 * 11264 * 4096 / 40e-6 / 1e9) < 1.0      # GB/s of the 7B shape
+
+
+def test_sites_take_bytes_from_the_launch_list_and_match_per_stream(tmp_path):
+    """Quantised weights: the GB/s column uses the bytes the engine recorded (third column), not the bf16 table; and a program
+    is found on its own stream although another stream's kernels interleave in time (the pipelined duplex step)."""
+    ll = [("prepare", "k_lm_prepare", 0), ("L.ffn_in", "k_gemm_xp", 1000000), ("commit", "k_lm_commit", 0)]
+    (tmp_path / "launch_list_lm.tsv").write_text("".join(f"{s}\t{k}" + (f"\t{b}" if b else "") + "\n" for s, k, b in ll))
+    db = tmp_path / "t.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer, stream_id integer)")
+    t = 0
+    for step in range(4):
+        for site, k, _ in ll:
+            d = {"prepare": 5000, "L.ffn_in": 10000, "commit": 7000}[site]
+            c.execute("insert into kernels values (?,?,?,?)", (k + "(Args)", t, t + d, 3))
+            c.execute("insert into kernels values (?,?,?,?)", ("k_conv_wide(ConvGemmArgs)", t + 100, t + 900, 4))   # another stream, overlapping
+            t += d + 500
+    c.commit(); c.close()
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "rocpd_sites.py"), str(db), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = {ln.split(",")[1]: ln.split(",") for ln in r.stdout.splitlines() if ln.startswith("lm,")}
+    assert abs(float(rows["L.ffn_in"][4]) - 10.0) < 1e-6 and abs(float(rows["L.ffn_in"][5]) - 1.0) < 1e-6
+    assert abs(float(rows["L.ffn_in"][6]) - 100.0) < 1e-3
