@@ -103,6 +103,7 @@ struct mmi_lm {
     int* forced = nullptr;                          // [B][1+dep_q]
     int* use_forced = nullptr;
     bool forced_armed = false;
+    bool noise_on = false;                          // host mirror of *use_noise
     unsigned long long* rng = nullptr;
     // per-step host hooks (mmi_lm_set_hooks): the step is cut at these ops of the launch list
     mmi_lm_hooks hooks{nullptr, nullptr, nullptr, nullptr};
@@ -121,8 +122,9 @@ struct mmi_lm {
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
     // profiling tap
-    struct SiteEv { size_t op; hipEvent_t a, b; };
-    std::vector<SiteEv> site_ev;     // one pair per eagerly run op while profiling (mmi_lm_profile_sites)
+    struct SiteEv { size_t op; hipEvent_t ev; };
+    std::vector<SiteEv> site_ev;     // one event in front of every eagerly run op while profiling, one behind the step's last
+                                     // (op = SIZE_MAX): an op's time is the distance to the next event (mmi_lm_profile_sites)
     size_t site_ev_used = 0;
     bool profiling = false;
     std::vector<EvPair> ev_pool;
@@ -1122,7 +1124,7 @@ extern "C" void mmi_lm_destroy(mmi_lm* lm) {
     mmi_lm_streaming_stop(lm);
     lm->wts.release();
     for (auto& e : lm->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    for (auto& e : lm->site_ev) { if (e.a) hipEventDestroy(e.a); if (e.b) hipEventDestroy(e.b); }
+    for (auto& e : lm->site_ev) { if (e.ev) hipEventDestroy(e.ev); }
     if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
     delete lm;
 }
@@ -1238,6 +1240,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     MMI_HIP_CHECK(hipMemsetAsync(lm->dkc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dvc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
+    lm->noise_on = false;
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->finish_ctr, 0, (size_t)mmi_cdiv(d, 8) * sizeof(unsigned), s));
     lm->forced_armed = false;
@@ -1311,8 +1314,10 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     if (opt_noise) {
         MMI_HIP_CHECK(hipMemcpyAsync(lm->noise, opt_noise, (size_t)B * (1 + c.dep_q) * lm->kmax * sizeof(float), hipMemcpyDeviceToDevice, s));
         MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 1, 1, s));
-    } else {
+        lm->noise_on = true;
+    } else if (lm->noise_on) {          // the device flag only changes when the caller starts / stops supplying noise: no fill per step
         MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
+        lm->noise_on = false;
     }
     MMI_CHECK_LAUNCH();
     int rc;
@@ -1424,6 +1429,7 @@ extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int
     MMI_HIP_CHECK(lm->st.load(src, (hipStream_t)stream));
     lm->offset_cpu = (long)host_word;
     lm->forced_armed = false;
+    lm->noise_on = true;               // the snapshot carries its own use_noise word: the next step rewrites it
     return MMI_OK;
 }
 
@@ -1484,25 +1490,23 @@ extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {
     lm->profiling = true;
     lm->ev_used = 0;
     lm->site_ev_used = 0;
-    lm->prog.tap = [lm](size_t i, bool begin, hipStream_t s) {       // an event pair around every op of the un-graphed steps
-        if (begin) {
-            if (lm->site_ev_used == lm->site_ev.size()) {
-                mmi_lm::SiteEv e{0, nullptr, nullptr};
-                if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-                lm->site_ev.push_back(e);
-            }
-            lm->site_ev[lm->site_ev_used].op = i;
-            hipEventRecord(lm->site_ev[lm->site_ev_used].a, s);
-        } else if (lm->site_ev_used < lm->site_ev.size() && lm->site_ev[lm->site_ev_used].op == i) {
-            hipEventRecord(lm->site_ev[lm->site_ev_used].b, s);
-            lm->site_ev_used += 1;
+    lm->prog.tap = [lm](size_t i, bool begin, hipStream_t s) {       // one event per op boundary of the un-graphed steps
+        if (!begin && i + 1 != lm->prog.ops.size()) return;
+        if (lm->site_ev_used == lm->site_ev.size()) {
+            mmi_lm::SiteEv e{0, nullptr};
+            if (hipEventCreate(&e.ev) != hipSuccess) return;
+            lm->site_ev.push_back(e);
         }
+        lm->site_ev[lm->site_ev_used].op = begin ? i : (size_t)-1;
+        hipEventRecord(lm->site_ev[lm->site_ev_used].ev, s);
+        lm->site_ev_used += 1;
     };
     return MMI_OK;
 }
 
 // Per-site timings of the steps run since mmi_lm_profile_begin: one line "site<TAB>ops<TAB>total ms<TAB>weight bytes per op" per
-// site of the launch list (hipEvent pairs around every op of the un-graphed steps: dispatch gaps included).  Call before
+// site of the launch list (one hipEvent per op boundary of the un-graphed steps: an op's time runs to the next op's event, so the
+// eager dispatch gap and the event's own marker - a few us - are included).  Call before
 // mmi_lm_profile_end; synchronises the stream.  Returns the bytes needed including the final NUL.
 extern "C" int64_t mmi_lm_profile_sites(mmi_lm* lm, char* buf, int64_t cap) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
@@ -1512,10 +1516,11 @@ extern "C" int64_t mmi_lm_profile_sites(mmi_lm* lm, char* buf, int64_t cap) {
     std::vector<std::string> order;
     std::vector<double> tot;
     std::vector<long> cnt, bytes;
-    for (size_t k = 0; k < lm->site_ev_used; ++k) {
+    for (size_t k = 0; k + 1 < lm->site_ev_used; ++k) {
         const auto& e = lm->site_ev[k];
+        if (e.op == (size_t)-1) continue;            // the end of a step: the distance to the next step's first event is host time
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, e.ev, lm->site_ev[k + 1].ev) != hipSuccess) continue;
         const std::string& site = lm->prog.sites[e.op];
         size_t j = 0;
         while (j < order.size() && order[j] != site) ++j;
