@@ -7,8 +7,11 @@
 //     E: encode(t)      after encode(t-1) [stream order]
 //     L: LMGen.step(t)  after step(t-1)   [stream order]      and after encode(t)
 //     D: decode(t)      after decode(t-1) [stream order]      and after LMGen.step(t)
-// The user codes and the step's tokens are handed over through two-slot rings indexed by frame parity; a slot is reused by frame
-// t+2, which the host only enqueues once LMGen.step(t) has completed (flow control in mmi_duplex_submit).
+// The user codes are handed over through a two-slot ring indexed by frame parity: a slot is reused by frame t+2, which the host
+// only enqueues once LMGen.step(t) has completed (flow control in mmi_duplex_submit).  The step's tokens go through a THREE-slot
+// ring: decode(t-2) runs beside the depth-transformer phase of step t-1 and, slowed by the company, ends about when that step
+// does - with two slots step t (the next writer of decode(t-2)'s slot) waited for it, 0.35 ms per frame with nothing on the LM's
+// queue (the pipeline's timeline: steps 5.71 ms long, 6.06 ms apart).  With three slots step t follows decode(t-3).
 //
 // Gate (default on): the temporal transformer's GEMMs are chip-filling, HBM-bound launches with one workgroup per CU and a
 // static tile partition - a codec workgroup that takes a CU for 10 us makes such a launch 10 us late.  The depth-transformer
@@ -43,7 +46,8 @@ struct mmi_duplex {
     int B = 0, F = 0, K = 0, dep_q = 0, NTOK = 0;
     hipStream_t sE = nullptr, sL = nullptr, sD = nullptr;
     hipEvent_t ev_lm[2] = {nullptr, nullptr};      // host flow control: LMGen.step(t) done (never waited on by a stream)
-    hipEvent_t ev_dec[2] = {nullptr, nullptr};     // decode(t) done: waited on by L two frames later, when it has long completed
+    hipEvent_t ev_dec[3] = {nullptr, nullptr, nullptr};   // decode(t) done: waited on by L `slots` frames later, when it has long completed
+    int slots = 3;                                 // token ring (MMI_DUPLEX_TOKEN_SLOTS=2: round 3's first form, A/B)
     long* flags = nullptr;                         // [F_COUNT][16] device counters, one cache line each: frames completed per phase
     int gate = 3;                                  // bit 0: encode(t+1), bit 1: decode(t-1) held until step t reaches its depth-transformer
                                                    // phase (MMI_DUPLEX_GATE = 0..3; 0: as soon as they can)
@@ -58,9 +62,9 @@ struct mmi_duplex {
     // diagnostic timeline (mmi_duplex_set_timeline): timestamps of the last frame's phases
     bool timeline = false;
     hipEvent_t tl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // in, enc0, enc1, lm0, -, lm1, dec0, dec1
-    Pending pend[2];                               // a frame's decode, enqueued by the NEXT submit (behind that step's phase) or by join
+    Pending pend[3];                               // a frame's decode, enqueued two submits later (behind step t+1's phase) or by join / flush
     int64_t* codes[2] = {nullptr, nullptr};        // [B][K][1]         encoder -> LM
-    int64_t* tokens[2] = {nullptr, nullptr};       // [B][1 + dep_q][1] LM -> decoder
+    int64_t* tokens[3] = {nullptr, nullptr, nullptr};   // [B][1 + dep_q][1] LM -> decoder
     long frame = 0;
 };
 
@@ -99,6 +103,7 @@ int phase_callback(void* user, mmi_stream stream) {
 }
 
 void release(mmi_duplex* d) {
+    if (d->sD == d->sE) d->sD = nullptr;            // MMI_DUPLEX_ONE_CODEC_STREAM
     if (d->flags) {      // a step that failed half-way may have left a polling wave without its producer: let every waiter through
         std::vector<long> big((size_t)F_COUNT * 16, (long)1 << 62);
         hipMemcpy(d->flags, big.data(), big.size() * sizeof(long), hipMemcpyHostToDevice);
@@ -107,11 +112,13 @@ void release(mmi_duplex* d) {
         if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
     for (int i = 0; i < 2; ++i) {
         if (d->ev_lm[i]) hipEventDestroy(d->ev_lm[i]);
-        if (d->ev_dec[i]) hipEventDestroy(d->ev_dec[i]);
         if (d->ev_phase[i]) hipEventDestroy(d->ev_phase[i]);
         for (int w = 0; w < F_COUNT; ++w)
             if (d->ev_x[w][i]) hipEventDestroy(d->ev_x[w][i]);
         if (d->codes[i]) hipFree(d->codes[i]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (d->ev_dec[i]) hipEventDestroy(d->ev_dec[i]);
         if (d->tokens[i]) hipFree(d->tokens[i]);
     }
     if (d->flags) hipFree(d->flags);
@@ -168,16 +175,22 @@ int create_impl(mmi_duplex* d) {
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sE, hipStreamNonBlocking));
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sD, hipStreamNonBlocking));
     }
+    if (const char* g = getenv("MMI_DUPLEX_ONE_CODEC_STREAM")) {     // A/B: encoder and decoder share one stream (two chains beside the LM instead of three)
+        if (g[0] == '1') { hipStreamDestroy(d->sD); d->sD = d->sE; }
+    }
     if (const char* g = getenv("MMI_DUPLEX_GATE")) d->gate = atoi(g) & 3;
     if (const char* g = getenv("MMI_DUPLEX_EVENTS")) d->use_events = g[0] == '1';
     if (const char* g = getenv("MMI_DUPLEX_HOSTGATE")) d->host_gate = g[0] != '0';
+    if (const char* g = getenv("MMI_DUPLEX_TOKEN_SLOTS")) d->slots = g[0] == '2' ? 2 : 3;
     if (!d->gate) d->host_gate = false;
     for (int i = 0; i < 2; ++i) {
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_lm[i], hipEventDisableTiming));
-        MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_phase[i], hipEventDisableTiming));
         for (int w = 0; w < F_COUNT; ++w) MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_x[w][i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipMalloc((void**)&d->codes[i], (size_t)d->B * d->K * sizeof(int64_t)));
+    }
+    for (int i = 0; i < 3; ++i) {
+        MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipMalloc((void**)&d->tokens[i], (size_t)d->B * d->NTOK * sizeof(int64_t)));
     }
     return MMI_OK;
@@ -234,10 +247,12 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     MmiDeviceGuard dev_guard_(d ? d->device : -1);
     if (!d || !pcm_in || !pcm_out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     const long t = d->frame;
-    const int p = (int)(t & 1);
+    const int p = (int)(t & 1);                            // codes slot, flow-control events
+    const int q = (int)(t % d->slots);                     // tokens slot, pending decode, ev_dec
+    const int q_m1 = (int)((t + d->slots - 1) % d->slots), q_m2 = (int)((t + d->slots - 2) % d->slots);    // slots of frames t-1, t-2
     int rc;
     // flow control: the host runs at most two LM steps ahead of the device.  It blocks here until LMGen.step(t-2) - the previous
-    // writer of ring slot p - has completed, which also bounds the lifetime the caller owes its pcm_in buffers.
+    // writer of codes slot p - has completed, which also bounds the lifetime the caller owes its pcm_in buffers.
     if (t >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
     // host-kept gate: the frame is enqueued once LMGen.step(t-1) has reached its depth-transformer phase
     if (d->host_gate && t >= 1) MMI_HIP_CHECK(hipEventSynchronize(d->ev_phase[p ^ 1]));
@@ -252,29 +267,28 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     if ((rc = mmi_mimi_encode_step(d->mimi, pcm_in, d->codes[p], d->B, 1, d->sE))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[2], d->sE));
     if ((rc = publish(d, F_ENC, t, d->sE))) return rc;
-    // ---- L: LMGen.step(t) into tokens slot p, whose last reader decode(t-2) was enqueued by an earlier submit (long done)
-    // host-kept gate: decode(t-2) - step t-2 is complete, step t-1 in its depth-transformer phase - goes out now, ahead of the
-    // step that will overwrite its tokens slot
-    if (d->host_gate && (rc = enqueue_decode(d, p, -2))) return rc;
+    // ---- L: LMGen.step(t) into tokens slot q, whose last reader decode(t - slots) was enqueued by an earlier submit
+    // host-kept gate: decode(t-2) - step t-2 is complete, step t-1 in its depth-transformer phase - goes out now
+    if (d->host_gate && (rc = enqueue_decode(d, q_m2, -2))) return rc;
     if ((rc = await(d, F_ENC, t, d->sL))) return rc;
-    if (t >= 2) MMI_HIP_CHECK(hipStreamWaitEvent(d->sL, d->ev_dec[p], 0));
+    if (t >= d->slots) MMI_HIP_CHECK(hipStreamWaitEvent(d->sL, d->ev_dec[q], 0));
     int ok = 0;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[3], d->sL));
     d->phase_frame = t;
     if (d->gate && (rc = mmi_lm_set_phase_callback(d->lm, phase_callback, d))) return rc;
-    rc = mmi_lm_step(d->lm, d->codes[p], d->K, d->tokens[p], nullptr, nullptr, nullptr, d->B, &ok, d->sL);
+    rc = mmi_lm_step(d->lm, d->codes[p], d->K, d->tokens[q], nullptr, nullptr, nullptr, d->B, &ok, d->sL);
     if (d->gate) mmi_lm_set_phase_callback(d->lm, nullptr, nullptr);
     if (rc) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[5], d->sL));
     if ((rc = publish(d, F_LM, t, d->sL))) return rc;
     MMI_HIP_CHECK(hipEventRecord(d->ev_lm[p], d->sL));
-    d->pend[p] = Pending{true, ok != 0, pcm_out, tokens_out, t};
+    d->pend[q] = Pending{true, ok != 0, pcm_out, tokens_out, t};
     // ---- D: gated, decode(t-1) runs beside the depth-transformer phase of step t; ungated, decode(t) follows step t directly
     if (d->host_gate) {
         // nothing: this frame's decode is enqueued by submit(t+2), or by join
     } else if (d->gate & 2) {
-        if ((rc = enqueue_decode(d, p ^ 1, t))) return rc;
-    } else if ((rc = enqueue_decode(d, p, -1))) return rc;
+        if ((rc = enqueue_decode(d, q_m1, t))) return rc;
+    } else if ((rc = enqueue_decode(d, q, -1))) return rc;
     if (valid) *valid = ok;
     d->frame += 1;
     return MMI_OK;
@@ -285,9 +299,9 @@ extern "C" int mmi_duplex_join(mmi_duplex* d, mmi_stream caller) {
     if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (d->frame == 0) return MMI_OK;
     const long t = d->frame - 1;                  // the last frame: everything earlier precedes it on each stream
-    const int p = (int)(t & 1);
+    const int q = (int)(t % d->slots), q_m1 = (int)((t + d->slots - 1) % d->slots);
     int rc;
-    if ((rc = enqueue_decode(d, p ^ 1, -1)) || (rc = enqueue_decode(d, p, -1))) return rc;     // a decode still held back for its gate: now
+    if ((rc = enqueue_decode(d, q_m1, -1)) || (rc = enqueue_decode(d, q, -1))) return rc;     // a decode still held back for its gate: now
     hipStream_t s = (hipStream_t)caller;
     if ((rc = await(d, F_DEC, t, s))) return rc;  // decode(t) implies step(t) implies encode(t)
     return MMI_OK;
@@ -297,16 +311,17 @@ extern "C" int mmi_duplex_flush(mmi_duplex* d) {
     MmiDeviceGuard dev_guard_(d ? d->device : -1);
     if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (d->frame == 0) return MMI_OK;
-    const int p = (int)((d->frame - 1) & 1);
+    const long t = d->frame - 1;
     int rc;
-    for (int slot : {p ^ 1, p}) {               // older frame first; the host sees the step complete, so the decode needs no device-side wait
-        if (!d->pend[slot].live) continue;
-        MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[slot]));
+    for (long f : {t - 1, t}) {                 // older frame first; the host sees the step complete, so the decode needs no device-side wait
+        if (f < 0) continue;
+        const int slot = (int)(f % d->slots);
+        if (!d->pend[slot].live || d->pend[slot].frame != f) continue;
+        MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[f & 1]));
         if ((rc = enqueue_decode(d, slot, -2))) return rc;
     }
-    MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
-    MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[p]));
-    if (d->frame >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[p ^ 1]));
+    MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[t & 1]));
+    MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[t % d->slots]));     // the decoder's stream order: every earlier decode precedes it
     return MMI_OK;
 }
 

@@ -9,6 +9,28 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: ~200 simulator / oracle / host-logic tests, 10+ minutes in one process) spreads over a few
+    worker processes when pytest-xdist is there; the GPU suite never does (one GPU, timing-sensitive cases).  MMI_TEST_WORKERS=0
+    (or an explicit -n) switches this off."""
+    # a worker process runs this hook too (with numprocesses reset to None): it must never spawn workers of its own
+    if os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("MMI_XDIST_PARENT") or hasattr(config, "workerinput"):
+        return None
+    want = os.environ.get("MMI_TEST_WORKERS", "")
+    if want == "0" or "not gpu" not in (config.getoption("markexpr", "") or ""):
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None):
+        return None
+    n = int(want) if want.isdigit() else min(6, os.cpu_count() or 1)
+    if n > 1:
+        os.environ["MMI_XDIST_PARENT"] = str(os.getpid())        # inherited by every worker: second guard against re-entry
+        config.option.numprocesses = n
+        config.option.dist = "load"
+        config.option.tx = ["popen"] * n
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")

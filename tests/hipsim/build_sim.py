@@ -32,6 +32,17 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    """Several test workers may call this at once: the compile runs under a file lock."""
+    import fcntl
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> Path:
     if not force and not needs_build():
         return LIB
     objs, jobs = [], []
