@@ -366,6 +366,11 @@ int mmi_duplex_flush(mmi_duplex* d);
  * entries of phases that did not run are -1. */
 int mmi_duplex_set_timeline(mmi_duplex* d, int32_t on);
 int mmi_duplex_get_timeline(mmi_duplex* d, float* ms7);
+/* Diagnostics, finer: with the timeline on the pipeline also stamps the device's constant-rate clock at its hand-off points
+ * (one-thread kernels on the three streams).  Returns ms40[4][10] - frames t & 3 of the last four submits; per frame: input
+ * published, encode begin / end, the LM's wait for the encoder begin / end, LM begin, depth-transformer phase, LM end, decode
+ * begin / end - in ms since the oldest stamp held (-1: not stamped), and the number of the last submitted frame. */
+int mmi_duplex_get_stamps(mmi_duplex* d, double* ms40, int64_t* last_frame);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Session batcher: many live dialogue sessions on one GPU                                    */

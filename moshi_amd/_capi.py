@@ -106,6 +106,7 @@ SIGNATURES = {
     "mmi_duplex_flush": (C.c_int, [_P]),
     "mmi_duplex_set_timeline": (C.c_int, [_P, C.c_int32]),
     "mmi_duplex_get_timeline": (C.c_int, [_P, _P]),
+    "mmi_duplex_get_stamps": (C.c_int, [_P, _P, _P]),
     "mmi_lm_create": (C.c_int, [C.POINTER(LMCfg), C.POINTER(TensorDesc), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "mmi_lm_destroy": (None, [_P]),
     "mmi_lm_streaming_start": (C.c_int, [_P, C.c_int32, C.POINTER(Sampling), _P]),

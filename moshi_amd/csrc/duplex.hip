@@ -33,6 +33,17 @@ __global__ void k_flag_wait(const long* flag, long v) {
     if (threadIdx.x == 0) mmi_flag_wait(flag, v);
 }
 
+// diagnostic stamps (mmi_duplex_get_stamps): device clock at the pipeline's hand-off points, four frames deep
+enum { S_IN = 0, S_ENC0, S_ENC1, S_WAIT0, S_WAIT1, S_LM0, S_PHASE, S_LM1, S_DEC0, S_DEC1, S_COUNT };
+__global__ void k_stamp(long* p) { *p = mmi_wall_clock(); }
+__global__ void k_flag_wait_stamped(const long* flag, long v, long* p) {
+    if (threadIdx.x == 0) {
+        p[0] = mmi_wall_clock();
+        mmi_flag_wait(flag, v);
+        p[1] = mmi_wall_clock();
+    }
+}
+
 struct Pending { bool live = false, valid = false; float* pcm_out = nullptr; int64_t* tokens_out = nullptr; long frame = 0; };
 
 enum { F_ENC = 0, F_LM = 1, F_PHASE = 2, F_DEC = 3, F_IN = 4, F_COUNT = 5 };
@@ -61,6 +72,7 @@ struct mmi_duplex {
     hipEvent_t ev_phase[2] = {nullptr, nullptr};
     // diagnostic timeline (mmi_duplex_set_timeline): timestamps of the last frame's phases
     bool timeline = false;
+    long* stamps = nullptr;                        // [4][S_COUNT] device clock stamps of frames t & 3 (timeline on)
     hipEvent_t tl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // in, enc0, enc1, lm0, -, lm1, dec0, dec1
     Pending pend[3];                               // a frame's decode, enqueued two submits later (behind step t+1's phase) or by join / flush
     int64_t* codes[2] = {nullptr, nullptr};        // [B][K][1]         encoder -> LM
@@ -93,8 +105,17 @@ int await(mmi_duplex* d, int which, long t, hipStream_t s) {
     return MMI_OK;
 }
 
+long* stamp_of(mmi_duplex* d, long t, int which) { return d->stamps + (t & 3) * S_COUNT + which; }
+int stamp(mmi_duplex* d, long t, int which, hipStream_t s) {
+    if (!d->timeline || !d->stamps) return MMI_OK;
+    MMI_LAUNCH(k_stamp, 1, 1, 0, s, stamp_of(d, t, which));
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
 int phase_callback(void* user, mmi_stream stream) {
     mmi_duplex* d = (mmi_duplex*)user;
+    stamp(d, d->phase_frame, S_PHASE, (hipStream_t)stream);
     if (d->host_gate) {
         MMI_HIP_CHECK(hipEventRecord(d->ev_phase[d->phase_frame & 1], (hipStream_t)stream));
         return MMI_OK;
@@ -122,6 +143,7 @@ void release(mmi_duplex* d) {
         if (d->tokens[i]) hipFree(d->tokens[i]);
     }
     if (d->flags) hipFree(d->flags);
+    if (d->stamps) hipFree(d->stamps);
     for (hipEvent_t e : d->tl) if (e) hipEventDestroy(e);
     delete d;
 }
@@ -207,10 +229,12 @@ int enqueue_decode(mmi_duplex* d, int p, long gate_frame) {
     // phase of step gate_frame (which implies step gate_frame - 1)
     if (gate_frame > -2 && (rc = await(d, gate_frame >= 0 ? F_PHASE : F_LM, gate_frame >= 0 ? gate_frame : q.frame, d->sD))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[6], d->sD));
+    stamp(d, q.frame, S_DEC0, d->sD);
     if (q.tokens_out)
         MMI_HIP_CHECK(hipMemcpyAsync(q.tokens_out, d->tokens[p], (size_t)d->B * d->NTOK * sizeof(int64_t), hipMemcpyDeviceToDevice, d->sD));
     if (q.valid && (rc = mmi_mimi_decode_step_strided(d->mimi, d->tokens[p] + 1, d->NTOK, q.pcm_out, d->B, d->dep_q, 1, d->sD))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[7], d->sD));
+    stamp(d, q.frame, S_DEC1, d->sD);
     if ((rc = publish(d, F_DEC, q.frame, d->sD))) return rc;
     MMI_HIP_CHECK(hipEventRecord(d->ev_dec[p], d->sD));
     q.live = false;
@@ -260,26 +284,34 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     // waits for it, and the LM and the decoder of this frame wait for the encoder
     if ((rc = publish(d, F_IN, t, (hipStream_t)caller))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[0], (hipStream_t)caller));
+    stamp(d, t, S_IN, (hipStream_t)caller);
     if ((rc = await(d, F_IN, t, d->sE))) return rc;
     // ---- E: encode(t) into codes slot p.  Gated: not before the LM step in flight (t-1) has reached its depth-transformer phase
     if (!d->host_gate && (d->gate & 1) && t >= 1 && (rc = await(d, F_PHASE, t - 1, d->sE))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[1], d->sE));
+    stamp(d, t, S_ENC0, d->sE);
     if ((rc = mmi_mimi_encode_step(d->mimi, pcm_in, d->codes[p], d->B, 1, d->sE))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[2], d->sE));
+    stamp(d, t, S_ENC1, d->sE);
     if ((rc = publish(d, F_ENC, t, d->sE))) return rc;
     // ---- L: LMGen.step(t) into tokens slot q, whose last reader decode(t - slots) was enqueued by an earlier submit
     // host-kept gate: decode(t-2) - step t-2 is complete, step t-1 in its depth-transformer phase - goes out now
     if (d->host_gate && (rc = enqueue_decode(d, q_m2, -2))) return rc;
-    if ((rc = await(d, F_ENC, t, d->sL))) return rc;
+    if (d->timeline && d->stamps && !d->use_events) {      // the LM's wait for the encoder, with the clock at its begin and end
+        MMI_LAUNCH(k_flag_wait_stamped, 1, 64, 0, d->sL, (const long*)flag_of(d, F_ENC), t + 1, stamp_of(d, t, S_WAIT0));
+        MMI_CHECK_LAUNCH();
+    } else if ((rc = await(d, F_ENC, t, d->sL))) return rc;
     if (t >= d->slots) MMI_HIP_CHECK(hipStreamWaitEvent(d->sL, d->ev_dec[q], 0));
     int ok = 0;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[3], d->sL));
+    stamp(d, t, S_LM0, d->sL);
     d->phase_frame = t;
     if (d->gate && (rc = mmi_lm_set_phase_callback(d->lm, phase_callback, d))) return rc;
     rc = mmi_lm_step(d->lm, d->codes[p], d->K, d->tokens[q], nullptr, nullptr, nullptr, d->B, &ok, d->sL);
     if (d->gate) mmi_lm_set_phase_callback(d->lm, nullptr, nullptr);
     if (rc) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[5], d->sL));
+    stamp(d, t, S_LM1, d->sL);
     if ((rc = publish(d, F_LM, t, d->sL))) return rc;
     MMI_HIP_CHECK(hipEventRecord(d->ev_lm[p], d->sL));
     d->pend[q] = Pending{true, ok != 0, pcm_out, tokens_out, t};
@@ -330,7 +362,26 @@ extern "C" int mmi_duplex_set_timeline(mmi_duplex* d, int32_t on) {
     if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (on && !d->tl[0])
         for (hipEvent_t& e : d->tl) MMI_HIP_CHECK(hipEventCreate(&e));
+    if (on && !d->stamps) {
+        MMI_HIP_CHECK(hipMalloc((void**)&d->stamps, (size_t)4 * S_COUNT * sizeof(long)));
+        MMI_HIP_CHECK(hipMemset(d->stamps, 0, (size_t)4 * S_COUNT * sizeof(long)));
+    }
     d->timeline = on != 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_duplex_get_stamps(mmi_duplex* d, double* ms40, int64_t* last_frame) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d || !ms40 || !last_frame) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!d->stamps) return mmi_fail(MMI_ERR_STATE, "the timeline was never switched on");
+    for (hipStream_t s : {d->sE, d->sL, d->sD}) MMI_HIP_CHECK(hipStreamSynchronize(s));
+    long raw[4 * S_COUNT];
+    MMI_HIP_CHECK(hipMemcpy(raw, d->stamps, sizeof(raw), hipMemcpyDeviceToHost));
+    const int khz = 100000;                      // wall_clock64: 100 MHz on gfx950
+    long t0 = 0;
+    for (long v : raw) if (v > 0 && (t0 == 0 || v < t0)) t0 = v;
+    for (int i = 0; i < 4 * S_COUNT; ++i) ms40[i] = raw[i] > 0 ? (double)(raw[i] - t0) / (double)khz : -1.0;
+    *last_frame = d->frame - 1;
     return MMI_OK;
 }
 

@@ -126,6 +126,8 @@ __device__ __forceinline__ void mmi_stores_done() { __builtin_amdgcn_fence(__ATO
 // Why not hipStreamWaitEvent: a wait that stays PENDING makes the command processor poll the producer queue's signal, which
 // slows every dependent launch of the producer (1.60 -> 2.77 ms for a chain of 1000 tiny kernels on this stack; a resident
 // polling wave costs 1.71 ms - scripts/stream_probe.hip test 1e, profiles/r03_logs/stream_probe.txt).
+// constant-rate device clock (100 MHz on gfx950): the pipeline's diagnostic stamps
+__device__ __forceinline__ long mmi_wall_clock() { return (long)wall_clock64(); }
 __device__ __forceinline__ void mmi_flag_publish(long* flag, long v) {
     __threadfence();
     __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -87,3 +87,15 @@ class DuplexStream:
         ms = (C.c_float * 7)()
         self._lib.check(self._lib.mmi_duplex_get_timeline(self._handle, C.cast(ms, C.c_void_p)))
         return {"encode": (ms[0], ms[1]), "lm": (ms[2], ms[4]), "decode": (ms[5], ms[6])}
+
+    STAMPS = ("in", "enc0", "enc1", "wait0", "wait1", "lm0", "phase", "lm1", "dec0", "dec1")
+
+    def stamps(self):
+        """Diagnostics (mmi_duplex_get_stamps): device-clock stamps of the last four frames, {frame: {point: ms}} on one time base."""
+        ms = (C.c_double * 40)()
+        last = C.c_int64(0)
+        self._lib.check(self._lib.mmi_duplex_get_stamps(self._handle, C.cast(ms, C.c_void_p), C.byref(last)))
+        out = {}
+        for f in range(max(0, last.value - 3), last.value + 1):
+            out[f] = {n: ms[(f & 3) * 10 + i] for i, n in enumerate(self.STAMPS) if ms[(f & 3) * 10 + i] >= 0}
+        return out

@@ -83,6 +83,21 @@ def main():
         dup.join(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         show(f"last of {n} back-to-back frames ({1e3*dt/n:.3f} ms/frame wall)", dup.timeline())
+    # device-clock stamps of the last four frames of that run on one time base: where the LM's queue waits between two steps
+    st = dup.stamps()
+    names = DuplexStream.STAMPS
+    print("device-clock stamps (ms), last four frames of the 20-frame run:")
+    print("frame " + " ".join(f"{n:>8s}" for n in names))
+    for f in sorted(st):
+        print(f"{f:5d} " + " ".join(f"{st[f][n]:8.3f}" if n in st[f] else "       -" for n in names))
+    fr = sorted(st)
+    for a_, b_ in zip(fr, fr[1:]):
+        x, y = st[a_], st[b_]
+        if "lm1" in x and "lm0" in y:
+            print(f"frame {b_}: LM idle since step {a_} ended {y['lm0'] - x['lm1']:.3f} ms; its wait for encode({b_}) took "
+                  f"{y.get('wait1', 0) - y.get('wait0', 0):.3f} ms (began {y.get('wait0', 0) - x['lm1']:.3f} ms after that end); "
+                  f"encode({b_}) ended {y.get('enc1', 0) - x['lm1']:+.3f} ms relative to it; phase({a_}) -> end {x['lm1'] - x.get('phase', 0):.3f} ms; "
+                  f"LM begin -> phase {y.get('phase', 0) - y['lm0']:.3f} ms")
 
 
 if __name__ == "__main__":

@@ -264,6 +264,7 @@ inline void mmi_stores_done() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // hand-off flags (duplex.hip).  The simulator runs every launch synchronously in host order, so a wait whose producer has not
 // been launched yet can never be satisfied: abort loudly instead of spinning forever.
+inline long mmi_wall_clock() { static long tick = 0; return ++tick; }
 inline void mmi_flag_publish(long* flag, long v) { __atomic_store_n(flag, v, __ATOMIC_RELEASE); }
 inline void mmi_flag_wait(const long* flag, long v) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < v) {
