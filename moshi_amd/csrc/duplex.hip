@@ -8,12 +8,12 @@
 //     L: LMGen.step(t)  after step(t-1)   [stream order]      and after encode(t)
 //     D: decode(t)      after decode(t-1) [stream order]      and after LMGen.step(t)
 // The user codes are handed over through a two-slot ring indexed by frame parity: a slot is reused by frame t+2, which the host
-// only enqueues once LMGen.step(t) has completed (flow control in mmi_duplex_submit).  The step's tokens go through a THREE-slot
-// ring: decode(t-2) runs beside the depth-transformer phase of step t-1 and, slowed by the company, ends about when that step
-// does - with two slots step t (the next writer of decode(t-2)'s slot) waited for it, 0.35 ms per frame with nothing on the LM's
-// queue (the pipeline's timeline: steps 5.71 ms long, 6.06 ms apart).  With three slots step t follows decode(t-3).
+// only enqueues once LMGen.step(t) has completed (flow control in mmi_duplex_submit).  The step's tokens go through a three-slot
+// ring: decode(t-2) runs beside the depth-transformer phase of step t-1 and ends about when that step does, so step t writes the
+// slot of decode(t-3) instead of waiting for it (no measurable difference at 32 sessions - the device-clock stamps,
+// mmi_duplex_get_stamps, show the LM's queue idle for 15 us between two steps either way - but no dependency either).
 //
-// Gate (default on): the temporal transformer's GEMMs are chip-filling, HBM-bound launches with one workgroup per CU and a
+// Gate: the temporal transformer's GEMMs are chip-filling, HBM-bound launches with one workgroup per CU and a
 // static tile partition - a codec workgroup that takes a CU for 10 us makes such a launch 10 us late.  The depth-transformer
 // phase (1.6 of the LM's 5.7 ms at 32 sessions) is dep_q x 33 small dependent launches on 32-192 of the 256 CUs.  So the codec
 // work of the neighbouring frames - decode(t-1), encode(t+1): 1.5 ms of latency-bound launches - is held until step t reaches
@@ -46,7 +46,7 @@ __global__ void k_flag_wait_stamped(const long* flag, long v, long* p) {
 
 struct Pending { bool live = false, valid = false; float* pcm_out = nullptr; int64_t* tokens_out = nullptr; long frame = 0; };
 
-enum { F_ENC = 0, F_LM = 1, F_PHASE = 2, F_DEC = 3, F_IN = 4, F_COUNT = 5 };
+enum { F_ENC = 0, F_LM = 1, F_DEC = 2, F_IN = 3, F_COUNT = 4 };
 
 }  // namespace
 
@@ -58,17 +58,13 @@ struct mmi_duplex {
     hipStream_t sE = nullptr, sL = nullptr, sD = nullptr;
     hipEvent_t ev_lm[2] = {nullptr, nullptr};      // host flow control: LMGen.step(t) done (never waited on by a stream)
     hipEvent_t ev_dec[3] = {nullptr, nullptr, nullptr};   // decode(t) done: waited on by L `slots` frames later, when it has long completed
-    int slots = 3;                                 // token ring (MMI_DUPLEX_TOKEN_SLOTS=2: round 3's first form, A/B)
+    static constexpr int slots = 3;                // token ring
     long* flags = nullptr;                         // [F_COUNT][16] device counters, one cache line each: frames completed per phase
-    int gate = 3;                                  // bit 0: encode(t+1), bit 1: decode(t-1) held until step t reaches its depth-transformer
-                                                   // phase (MMI_DUPLEX_GATE = 0..3; 0: as soon as they can)
-    bool use_events = false;                       // MMI_DUPLEX_EVENTS=1: hipStreamWaitEvent hand-offs instead of the flags (A/B)
-    hipEvent_t ev_x[F_COUNT][2];                   // the event form of the flags
-    long phase_frame = 0;                          // frame whose phase the callback publishes
-    bool host_gate = true;                         // the gate is kept by the HOST: submit(t) returns to enqueueing only once step t-1 has
-                                                   // reached its phase (ev_phase), so the gated work needs no device-side wait at all -
-                                                   // no polling wave sits on the codec queues through the LM's temporal phase
-                                                   // (MMI_DUPLEX_HOSTGATE=0: device-side, through the F_PHASE flag)
+    long phase_frame = 0;                          // frame whose phase the callback records
+    // The gate is kept by the HOST: submit(t) returns to enqueueing only once step t-1 has reached its depth-transformer phase
+    // (ev_phase), so the gated work - encode(t), decode(t-2) - needs no device-side wait at all and no polling wave sits on the
+    // codec queues through the LM's temporal phase.  (Measured and dropped, profiles/r03_logs/duplex_ab_a_to_l.txt: a device-side
+    // gate through a flag, gating only one codec half, no gate, event hand-offs, other stream priorities, one codec stream.)
     hipEvent_t ev_phase[2] = {nullptr, nullptr};
     // diagnostic timeline (mmi_duplex_set_timeline): timestamps of the last frame's phases
     bool timeline = false;
@@ -86,20 +82,12 @@ long* flag_of(mmi_duplex* d, int which) { return d->flags + 16 * which; }
 
 // producer side: frame `t` of phase `which` is complete once everything enqueued on s so far has run
 int publish(mmi_duplex* d, int which, long t, hipStream_t s) {
-    if (d->use_events) {
-        MMI_HIP_CHECK(hipEventRecord(d->ev_x[which][t & 1], s));
-        return MMI_OK;
-    }
     MMI_LAUNCH(k_flag_publish, 1, 1, 0, s, flag_of(d, which), t + 1);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
 // consumer side: s goes on once frame `t` of phase `which` is complete
 int await(mmi_duplex* d, int which, long t, hipStream_t s) {
-    if (d->use_events) {
-        MMI_HIP_CHECK(hipStreamWaitEvent(s, d->ev_x[which][t & 1], 0));
-        return MMI_OK;
-    }
     MMI_LAUNCH(k_flag_wait, 1, 64, 0, s, (const long*)flag_of(d, which), t + 1);
     MMI_CHECK_LAUNCH();
     return MMI_OK;
@@ -116,15 +104,11 @@ int stamp(mmi_duplex* d, long t, int which, hipStream_t s) {
 int phase_callback(void* user, mmi_stream stream) {
     mmi_duplex* d = (mmi_duplex*)user;
     stamp(d, d->phase_frame, S_PHASE, (hipStream_t)stream);
-    if (d->host_gate) {
-        MMI_HIP_CHECK(hipEventRecord(d->ev_phase[d->phase_frame & 1], (hipStream_t)stream));
-        return MMI_OK;
-    }
-    return publish(d, F_PHASE, d->phase_frame, (hipStream_t)stream);
+    MMI_HIP_CHECK(hipEventRecord(d->ev_phase[d->phase_frame & 1], (hipStream_t)stream));
+    return MMI_OK;
 }
 
 void release(mmi_duplex* d) {
-    if (d->sD == d->sE) d->sD = nullptr;            // MMI_DUPLEX_ONE_CODEC_STREAM
     if (d->flags) {      // a step that failed half-way may have left a polling wave without its producer: let every waiter through
         std::vector<long> big((size_t)F_COUNT * 16, (long)1 << 62);
         hipMemcpy(d->flags, big.data(), big.size() * sizeof(long), hipMemcpyHostToDevice);
@@ -134,8 +118,6 @@ void release(mmi_duplex* d) {
     for (int i = 0; i < 2; ++i) {
         if (d->ev_lm[i]) hipEventDestroy(d->ev_lm[i]);
         if (d->ev_phase[i]) hipEventDestroy(d->ev_phase[i]);
-        for (int w = 0; w < F_COUNT; ++w)
-            if (d->ev_x[w][i]) hipEventDestroy(d->ev_x[w][i]);
         if (d->codes[i]) hipFree(d->codes[i]);
     }
     for (int i = 0; i < 3; ++i) {
@@ -168,47 +150,22 @@ int create_impl(mmi_duplex* d) {
     // Stream priorities.  Streams of one priority share a pool of GPU_MAX_HW_QUEUES (4) hardware queues with everything else the
     // process created at that priority, and two streams that land on one queue do not overlap (profiles/r03_logs: the encoder
     // and the LM shared queue 4 without priorities).  The codec streams get the high-priority pool: distinct queues, and their
-    // short latency-bound launches win arbitration against the bulk LM stream.  (A/B: MMI_DUPLEX_PRIO = "0" none, "lm", "mimi")
-    MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)(F_COUNT + 1) * 16 * sizeof(long)));
-    MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)(F_COUNT + 1) * 16 * sizeof(long)));
-    if (const char* pad = getenv("MMI_DUPLEX_PAD")) {      // experiment: shift which hardware queues / pipes the three streams land on
-        for (int i = 0; i < atoi(pad) && i < 16; ++i) {
-            hipStream_t x;
-            MMI_HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
-            MMI_LAUNCH(k_flag_publish, 1, 1, 0, x, d->flags + 16 * F_COUNT, (long)i);
-            MMI_HIP_CHECK(hipStreamSynchronize(x));
-        }
-    }
+    // short latency-bound launches win arbitration against the bulk LM stream.
+    MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)F_COUNT * 16 * sizeof(long)));
+    MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)F_COUNT * 16 * sizeof(long)));
     int lo = 0, hi = 0;
-    const char* e = getenv("MMI_DUPLEX_PRIO");
-    const std::string mode = e && e[0] ? e : "mimi";
-    const bool have = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi;
-    if (have && mode == "tri" && hi + 2 <= lo) {      // encoder high, LM normal, decoder low: three pools, three queues
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, hi + 1));
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, lo));
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, hi));
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, lo));
-    } else if (have && mode != "0") {
-        const int pl = mode == "lm" ? hi : lo, pm = mode == "lm" ? lo : hi;
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, pl));
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, pm));
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, pm));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, hi));
     } else {
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sL, hipStreamNonBlocking));
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sE, hipStreamNonBlocking));
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sD, hipStreamNonBlocking));
     }
-    if (const char* g = getenv("MMI_DUPLEX_ONE_CODEC_STREAM")) {     // A/B: encoder and decoder share one stream (two chains beside the LM instead of three)
-        if (g[0] == '1') { hipStreamDestroy(d->sD); d->sD = d->sE; }
-    }
-    if (const char* g = getenv("MMI_DUPLEX_GATE")) d->gate = atoi(g) & 3;
-    if (const char* g = getenv("MMI_DUPLEX_EVENTS")) d->use_events = g[0] == '1';
-    if (const char* g = getenv("MMI_DUPLEX_HOSTGATE")) d->host_gate = g[0] != '0';
-    if (const char* g = getenv("MMI_DUPLEX_TOKEN_SLOTS")) d->slots = g[0] == '2' ? 2 : 3;
-    if (!d->gate) d->host_gate = false;
     for (int i = 0; i < 2; ++i) {
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_lm[i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_phase[i], hipEventDisableTiming));
-        for (int w = 0; w < F_COUNT; ++w) MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_x[w][i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipMalloc((void**)&d->codes[i], (size_t)d->B * d->K * sizeof(int64_t)));
     }
     for (int i = 0; i < 3; ++i) {
@@ -220,14 +177,12 @@ int create_impl(mmi_duplex* d) {
 
 // decode(t) of the audio columns of step t's output, read in place; rows still inside the LM's delay hold -2, which the
 // decoder's gather clamps into the codebook exactly where the reference would index unchecked (vq.py:144-146).
-// gate_frame >= 0: not before LMGen.step(gate_frame) has reached its depth-transformer phase.
-int enqueue_decode(mmi_duplex* d, int p, long gate_frame) {
+// host_saw_step: the host has seen the frame's LM step complete (no device-side wait); else the decoder's stream waits for it.
+int enqueue_decode(mmi_duplex* d, int p, bool host_saw_step) {
     Pending& q = d->pend[p];
     if (!q.live) return MMI_OK;
     int rc;
-    // gate_frame -2: the host has seen the step complete (no device-side wait); -1: behind the step itself; >= 0: behind the
-    // phase of step gate_frame (which implies step gate_frame - 1)
-    if (gate_frame > -2 && (rc = await(d, gate_frame >= 0 ? F_PHASE : F_LM, gate_frame >= 0 ? gate_frame : q.frame, d->sD))) return rc;
+    if (!host_saw_step && (rc = await(d, F_LM, q.frame, d->sD))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[6], d->sD));
     stamp(d, q.frame, S_DEC0, d->sD);
     if (q.tokens_out)
@@ -248,7 +203,6 @@ extern "C" int mmi_duplex_create(mmi_mimi* mimi, mmi_lm* lm, mmi_duplex** out) {
     if (!mimi || !lm || !out) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (mmi_lm_device(lm) != mmi_mimi_device(mimi)) return mmi_fail(MMI_ERR_INVALID, "the codec and the LM live on different devices");
     mmi_duplex* d = new mmi_duplex();
-    memset(d->ev_x, 0, sizeof(d->ev_x));
     d->mimi = mimi;
     d->lm = lm;
     d->device = mmi_lm_device(lm);
@@ -273,21 +227,20 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     const long t = d->frame;
     const int p = (int)(t & 1);                            // codes slot, flow-control events
     const int q = (int)(t % d->slots);                     // tokens slot, pending decode, ev_dec
-    const int q_m1 = (int)((t + d->slots - 1) % d->slots), q_m2 = (int)((t + d->slots - 2) % d->slots);    // slots of frames t-1, t-2
+    const int q_m2 = (int)((t + d->slots - 2) % d->slots);     // slot of frame t-2
     int rc;
     // flow control: the host runs at most two LM steps ahead of the device.  It blocks here until LMGen.step(t-2) - the previous
     // writer of codes slot p - has completed, which also bounds the lifetime the caller owes its pcm_in buffers.
     if (t >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
     // host-kept gate: the frame is enqueued once LMGen.step(t-1) has reached its depth-transformer phase
-    if (d->host_gate && t >= 1) MMI_HIP_CHECK(hipEventSynchronize(d->ev_phase[p ^ 1]));
+    if (t >= 1) MMI_HIP_CHECK(hipEventSynchronize(d->ev_phase[p ^ 1]));
     // everything the caller enqueued so far (the frame's input; mask / reset calls made after a join) comes first: the encoder
     // waits for it, and the LM and the decoder of this frame wait for the encoder
     if ((rc = publish(d, F_IN, t, (hipStream_t)caller))) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[0], (hipStream_t)caller));
     stamp(d, t, S_IN, (hipStream_t)caller);
     if ((rc = await(d, F_IN, t, d->sE))) return rc;
-    // ---- E: encode(t) into codes slot p.  Gated: not before the LM step in flight (t-1) has reached its depth-transformer phase
-    if (!d->host_gate && (d->gate & 1) && t >= 1 && (rc = await(d, F_PHASE, t - 1, d->sE))) return rc;
+    // ---- E: encode(t) into codes slot p (the host-kept gate above: step t-1 is in its depth-transformer phase)
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[1], d->sE));
     stamp(d, t, S_ENC0, d->sE);
     if ((rc = mmi_mimi_encode_step(d->mimi, pcm_in, d->codes[p], d->B, 1, d->sE))) return rc;
@@ -296,8 +249,8 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     if ((rc = publish(d, F_ENC, t, d->sE))) return rc;
     // ---- L: LMGen.step(t) into tokens slot q, whose last reader decode(t - slots) was enqueued by an earlier submit
     // host-kept gate: decode(t-2) - step t-2 is complete, step t-1 in its depth-transformer phase - goes out now
-    if (d->host_gate && (rc = enqueue_decode(d, q_m2, -2))) return rc;
-    if (d->timeline && d->stamps && !d->use_events) {      // the LM's wait for the encoder, with the clock at its begin and end
+    if ((rc = enqueue_decode(d, q_m2, true))) return rc;
+    if (d->timeline && d->stamps) {      // the LM's wait for the encoder, with the clock at its begin and end
         MMI_LAUNCH(k_flag_wait_stamped, 1, 64, 0, d->sL, (const long*)flag_of(d, F_ENC), t + 1, stamp_of(d, t, S_WAIT0));
         MMI_CHECK_LAUNCH();
     } else if ((rc = await(d, F_ENC, t, d->sL))) return rc;
@@ -306,21 +259,16 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[3], d->sL));
     stamp(d, t, S_LM0, d->sL);
     d->phase_frame = t;
-    if (d->gate && (rc = mmi_lm_set_phase_callback(d->lm, phase_callback, d))) return rc;
+    if ((rc = mmi_lm_set_phase_callback(d->lm, phase_callback, d))) return rc;
     rc = mmi_lm_step(d->lm, d->codes[p], d->K, d->tokens[q], nullptr, nullptr, nullptr, d->B, &ok, d->sL);
-    if (d->gate) mmi_lm_set_phase_callback(d->lm, nullptr, nullptr);
+    mmi_lm_set_phase_callback(d->lm, nullptr, nullptr);
     if (rc) return rc;
     if (d->timeline) MMI_HIP_CHECK(hipEventRecord(d->tl[5], d->sL));
     stamp(d, t, S_LM1, d->sL);
     if ((rc = publish(d, F_LM, t, d->sL))) return rc;
     MMI_HIP_CHECK(hipEventRecord(d->ev_lm[p], d->sL));
     d->pend[q] = Pending{true, ok != 0, pcm_out, tokens_out, t};
-    // ---- D: gated, decode(t-1) runs beside the depth-transformer phase of step t; ungated, decode(t) follows step t directly
-    if (d->host_gate) {
-        // nothing: this frame's decode is enqueued by submit(t+2), or by join
-    } else if (d->gate & 2) {
-        if ((rc = enqueue_decode(d, q_m1, t))) return rc;
-    } else if ((rc = enqueue_decode(d, q, -1))) return rc;
+    // ---- D: this frame's decode is enqueued by submit(t+2) - beside the depth-transformer phase of step t+1 - or by join / flush
     if (valid) *valid = ok;
     d->frame += 1;
     return MMI_OK;
@@ -333,7 +281,7 @@ extern "C" int mmi_duplex_join(mmi_duplex* d, mmi_stream caller) {
     const long t = d->frame - 1;                  // the last frame: everything earlier precedes it on each stream
     const int q = (int)(t % d->slots), q_m1 = (int)((t + d->slots - 1) % d->slots);
     int rc;
-    if ((rc = enqueue_decode(d, q_m1, -1)) || (rc = enqueue_decode(d, q, -1))) return rc;     // a decode still held back for its gate: now
+    if ((rc = enqueue_decode(d, q_m1, false)) || (rc = enqueue_decode(d, q, false))) return rc;     // a decode still held back for its gate: now
     hipStream_t s = (hipStream_t)caller;
     if ((rc = await(d, F_DEC, t, s))) return rc;  // decode(t) implies step(t) implies encode(t)
     return MMI_OK;
@@ -350,7 +298,7 @@ extern "C" int mmi_duplex_flush(mmi_duplex* d) {
         const int slot = (int)(f % d->slots);
         if (!d->pend[slot].live || d->pend[slot].frame != f) continue;
         MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[f & 1]));
-        if ((rc = enqueue_decode(d, slot, -2))) return rc;
+        if ((rc = enqueue_decode(d, slot, true))) return rc;
     }
     MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[t & 1]));
     MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[t % d->slots]));     // the decoder's stream order: every earlier decode precedes it
