@@ -12,7 +12,6 @@ namespace {
 struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
     int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
-    int gate_oct = 0;         // ... per row octet instead (MMI_EPI_GATE_OCT)
     float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; fp8: weight_scale * input_scale; KSTEPS then counts k-step PAIRS
     int wq = 0;               // 0 bf16, 1 int8, 2 fp8
     float xinv = 1.f;         // fp8: 1 / input_scale
@@ -45,9 +44,6 @@ struct mmi_lm {
     int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py),
                                     // 2 fp8 linears (`weight` e4m3fn + `weight_scale` [+ `input_scale`]) run on the fp8 MFMA
     int NC = 0, CT = 0, max_delay = 0;
-    // RMSNorm folded across GEMM pairs (GemmArgs::ss), decided at create because it changes the packed weights:
-    bool fold2 = false;             // out_proj -> norm2 -> linear_in: norm2's alpha in the linear_in columns, its factor in linear_in's epilogue
-    bool fold1 = false;             // linear_out(l-1) -> norm1 -> in_proj(l), layers >= 1: norm1's alpha in the in_proj columns
     MmiArena wts;
     // weights
     uint16_t* emb = nullptr;        // [n_q][card+1][dim]
@@ -91,9 +87,6 @@ struct mmi_lm {
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
     float *opart = nullptr, *ml = nullptr;
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
-    float* ss = nullptr;                            // [dim / 8][B] sums of squares per 8-feature group of the residual stream (GemmArgs::ss_out)
-    int ss_units_max = 0;
-    unsigned* finish_ctr = nullptr;                 // [n-tile groups] arrival counters of the split-K finish (GemmArgs::finish_ctr), zero between launches
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
     uint16_t* dpre = nullptr;       // [B][dep_q * depformer_dim] depformer_in[k](transformer_out) of every micro-step
@@ -109,9 +102,7 @@ struct mmi_lm {
     mmi_lm_hooks hooks{nullptr, nullptr, nullptr, nullptr};
     bool in_hook = false;
     size_t op_text_sample = 0, op_after_text_sample = 0, op_commit = 0;
-    size_t op_depformer = 0;        // first op after the temporal transformer + text head: the default phase point (mmi_lm_set_phase_callback)
-    std::vector<size_t> op_layer;   // first op of every temporal layer
-    int phase_layer = -1;           // >= 0: the phase point is the start of that temporal layer instead (MMI_LM_PHASE_LAYER, A/B)
+    size_t op_depformer = 0;        // first op after the temporal transformer + text head: where mmi_lm_set_phase_event's event is recorded
     int (*phase_fn)(void*, mmi_stream) = nullptr;   // mmi_lm_set_phase_callback
     void* phase_user = nullptr;
     SampleArgs text_sample_args;    // to rebuild the depth transformer's first input when a hook changed the text token
@@ -151,9 +142,8 @@ __global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict_
 }
 
 // wp_dst / scale_dst: pack into a slice of a caller-owned allocation instead of a fresh one (see load_dep_in_group)
-// col_scale: bf16 [K] folded into the columns at pack time (the consuming RMSNorm's alpha, GemmArgs::ss); bf16 weights only
 int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g,
-                void* wp_dst = nullptr, float* scale_dst = nullptr, const uint16_t* col_scale = nullptr) {
+                void* wp_dst = nullptr, float* scale_dst = nullptr) {
     const mmi_tensor_desc* d = W.find(name);
     if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
     if (d->dtype != MMI_BF16 && d->dtype != MMI_I8 && d->dtype != MMI_F8E4M3)
@@ -165,13 +155,8 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
     const int TN = lm->T;
-    // gate_hidden < 0: a gated linear_in packed with the per-octet interleave (bf16 weights at the 32-row tile only)
-    const bool oct = gate_hidden < 0;
-    if (oct) gate_hidden = -gate_hidden;
-    if (oct && (q8 || lm->T != 32)) return mmi_fail(MMI_ERR_UNSUPPORTED, "octet-interleaved gate needs bf16 weights at the 32-row tile: " + name);
     g->K = K;
     g->gate = gate_hidden > 0 ? 1 : 0;
-    g->gate_oct = oct ? 1 : 0;
     g->N = gate_hidden > 0 ? gate_hidden : N;
     if (g->N % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "out_features must be a multiple of 8: " + name);
     const int rows_per_tile = gate_hidden > 0 ? TN / 2 : TN;
@@ -185,9 +170,8 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         g->wp = reinterpret_cast<u32x4*>(p);
         g->bytes = n * sizeof(uint16_t);
         MMI_LAUNCH(k_pack_w_bf16, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const uint16_t*)d->data, p, N, K,
-                   TN, g->NT, g->KSTEPS, oct ? -gate_hidden : gate_hidden, col_scale);
+                   TN, g->NT, g->KSTEPS, gate_hidden);
     } else {
-        if (col_scale) return mmi_fail(MMI_ERR_UNSUPPORTED, "a folded norm needs bf16 linears: " + name);
         // int8: `<linear>.weight_scb` = row absmax (utils/quantize.py:20-22).  fp8: `<linear>.weight_scale` = dequantisation
         // factor per row, and an optional scalar `<linear>.input_scale` (static activation scale, default 1)
         const std::string stem = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0 ? name.substr(0, name.size() - 7) : name;
@@ -261,29 +245,15 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     // (two n-tiles per workgroup for the 384-tile temporal in_proj look 3.5 us faster in the microbenchmark - 22.5 against
     // 26.0 us, profiles/r01_logs/gemm_microbench_b32_v10.txt - and make no difference in the step: 8.176 / 8.186 ms against
     // 8.190 / 8.176 ms in a same-box A/B, profiles/r01_logs/ab_in_proj_ntw2.txt; not adopted)
-    const char* e = getenv("MMI_GEMM_WAVES");
-    if (e && atoi(e) > 0) p.waves = atoi(e);
-    e = getenv("MMI_GEMM_NTW");
-    if (e && atoi(e) > 0) p.ntw = atoi(e);
     p.osplit = 1;
     return p;
-}
-
-int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T);
-// the fused-norm GEMMs: share when that brings the launch from under 128 workgroups to at most ~256
-int plan_osplit_norm(const GemmW& g, const GemmPlan& p, int epi, int T) {
-    if (epi == MMI_EPI_GATE || epi == MMI_EPI_GATE_OCT || g.wq != 0 || (T != 32 && T != 16)) return 1;
-    if (const char* e = getenv("MMI_GEMM_OSPLIT")) { if (e[0]) return plan_osplit(g, p, epi, T); }
-    int os = 1;
-    while (os < T / 8 && (long)g.NT * os < 128) os *= 2;
-    return os;
 }
 
 // Octet sharing of k_gemm_xp (GemmArgs::osplit): GEMMs with so few n-tiles that most CUs would idle while each busy one is
 // bound by what a single CU can pull (~25 GB/s) - the depth transformer's N = 1024 linears: 32 tiles of 64-180 KB.
 // MMI_GEMM_OSPLIT: "0" = off, "2" / "4" = force (test hook / A-B), default = as many parts as bring the launch to >= 128 workgroups.
 int plan_osplit(const GemmW& g, const GemmPlan& p, int epi, int T) {
-    if (epi == MMI_EPI_GATE || epi == MMI_EPI_GATE_OCT || g.wq != 0 || p.ntw != 1 || (T != 32 && T != 16)) return 1;
+    if (epi == MMI_EPI_GATE || g.wq != 0 || p.ntw != 1 || (T != 32 && T != 16)) return 1;
     const int octs = T / 8;
     int os = 1;
     const char* e = getenv("MMI_GEMM_OSPLIT");
@@ -334,10 +304,8 @@ template <int TN>
 int launch_gemm_t(hipStream_t s, const GemmPlan& p, int NT, int mt, const GemmArgs& a) {
     const dim3 groups(mmi_cdiv(NT, p.ntw) * (a.osplit > 1 ? a.osplit : 1), p.ksplit);
     const int w8 = a.wq;
-    if (mt == 1 && p.ntw == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, w8, a);
-    if (mt == 1 && p.ntw == 2) return launch_gemm_w<TN, 1, 2>(s, groups, p.waves, p.u, w8, a);
-    if (mt == 2 && p.ntw == 1) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, w8, a);
-    if (mt == 2 && p.ntw == 2) return launch_gemm_w<TN, 2, 2>(s, groups, p.waves, p.u, w8, a);
+    if (mt == 1) return launch_gemm_w<TN, 1, 1>(s, groups, p.waves, p.u, w8, a);     // one n-tile per workgroup (two measured slower
+    if (mt == 2) return launch_gemm_w<TN, 2, 1>(s, groups, p.waves, p.u, w8, a);     // in the step, DESIGN 9e: not instantiated)
     return mmi_fail(MMI_ERR_UNSUPPORTED, "batch too large for the skinny GEMM");
 }
 
@@ -352,10 +320,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     const char* en = getenv("MMI_GEMM_LDS");
     const char mode = en && en[0] ? en[0] : (g.wq == 0 ? '2' : '0');
     if (mode == '0' || lm->T != 32 || mt > 2) return p;
-    // no prefetched addend, no split-K: the residual form only in place on a packed buffer (each workgroup reads the 8-feature
-    // groups it then writes)
-    const bool resid_ok = a.epi == MMI_EPI_RESID && a.out_mode == MMI_OUT_PACKED && a.resid == a.out;
-    if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_GATE_OCT && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE && !resid_ok) return p;
+    if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
     if (tg && atoi(tg) > 0) cus = atoi(tg);
@@ -365,15 +330,12 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     else if (tg && g.KSTEPS % 8 == 0) p.kc = 8;
     else if (tg && g.KSTEPS % 4 == 0) p.kc = 4;
     else return p;
-    const int ntmax = (a.epi == MMI_EPI_GATE_OCT && mode == '2' && g.wq == 0) ? 4 : 3;      // tiles a workgroup may touch (launch_xlds_n)
     p.grid = g.NT < cus ? g.NT : cus;
-    // shared out in row octets, a GEMM with fewer n-tiles than CUs still covers the chip (out_proj: 128 tiles = 512 octets)
-    if (a.epi != MMI_EPI_GATE && !a.whole_tiles && a.epi == MMI_EPI_RESID) p.grid = 4L * g.NT < cus ? 4 * g.NT : cus;
     if (mmi_cdiv(g.NT, p.grid) > 3) return p;
-    if (a.epi != MMI_EPI_GATE && !a.whole_tiles) {   // the kernel shares the tiles out in row octets: no workgroup may touch more than ntmax tiles
+    if (a.epi != MMI_EPI_GATE) {   // the kernel shares the tiles out in row octets: no workgroup may touch more than 3 tiles
         for (long b = 0; b < p.grid; ++b) {
             const long u0 = b * 4L * g.NT / p.grid, u1 = (b + 1) * 4L * g.NT / p.grid;
-            if (u1 > u0 && ((u1 + 3) >> 2) - (u0 >> 2) > ntmax) return p;
+            if (u1 > u0 && ((u1 + 3) >> 2) - (u0 >> 2) > 3) return p;
         }
     }
     p.stagger = mode == '2' && g.wq == 0;                     // per-tile epilogues under the last chunk's stream (bf16)
@@ -384,31 +346,16 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     return p;
 }
 
-template <int MT, int KC, bool STAGGER, int WQ, bool NORM, int NTMAX>
-int launch_xlds_t(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, NTMAX, STAGGER, WQ, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_set = true;
-    }
-    MMI_LAUNCH((k_gemm_xlds<MT, KC, NTMAX, STAGGER, WQ, NORM>), p.grid, 512, p.smem, s, a);
-    MMI_CHECK_LAUNCH();
-    return MMI_OK;
-}
-template <int MT, int KC, bool STAGGER, int WQ, bool NORM>
-int launch_xlds_n(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
-    // the octet-interleaved gated linear_in: 11 octets per workgroup touch up to 4 tiles
-    if constexpr (WQ == 0 && STAGGER) {
-        if (a.epi == MMI_EPI_GATE_OCT) return launch_xlds_t<MT, KC, STAGGER, WQ, NORM, 4>(s, p, a);
-    }
-    return launch_xlds_t<MT, KC, STAGGER, WQ, NORM, 3>(s, p, a);
-}
 template <int MT, int KC, bool STAGGER, int WQ>
 int launch_xlds_v(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
-    if constexpr (WQ == 0) {
-        if (a.ss) return launch_xlds_n<MT, KC, STAGGER, WQ, true>(s, p, a);      // RMSNorm folded into the staging
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMI_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm_xlds<MT, KC, 3, STAGGER, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
     }
-    return launch_xlds_n<MT, KC, STAGGER, WQ, false>(s, p, a);
+    MMI_LAUNCH((k_gemm_xlds<MT, KC, 3, STAGGER, WQ>), p.grid, 512, p.smem, s, a);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
 }
 // production chunk (64 / MT k-steps, or 32 / MT two-step entries) or one of the short test chunks
 template <int MT, bool STAGGER, int WQ>
@@ -430,11 +377,9 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
-    if (g.gate_oct && a.epi == MMI_EPI_GATE) a.epi = MMI_EPI_GATE_OCT;     // the weights say how their tiles interleave gate and value rows
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     a.osplit = plan_osplit(g, p, a.epi, lm->T);
-    a.whole_tiles = getenv("MMI_XLDS_WHOLE_TILES") ? 1 : 0;
     const XldsPlan xl = plan_xlds(lm, g, a, mt);
     EvPair* ev = nullptr;
     if (lm->profiling && is_dominant) {
@@ -450,8 +395,6 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     }
     int rc;
     mmi_record_bytes((long)g.bytes);
-    if (a.ss && !xl.on) return mmi_fail(MMI_ERR_UNSUPPORTED, "a GEMM with a folded RMSNorm did not take k_gemm_xlds");
-    if (a.finish_ctr && (p.ksplit > 4 || xl.on)) return mmi_fail(MMI_ERR_UNSUPPORTED, "split-K finish: unsupported plan");
     if (is_dominant) lm->dominant_xlds = xl.on;
     if (xl.on) {
         lm->xlds_launches += 1;
@@ -479,16 +422,11 @@ size_t packed_elems(const mmi_lm* lm, int features) {
 // MMI_EPI_DEP_QKV0 (the depth transformer's in_proj at micro-step 0): where its epilogue writes k / v (frame cache, position 0)
 struct DepKv { uint16_t* kc; uint16_t* vc; int H, Dh, steps; };
 
-// RMSNorm folded across a GEMM pair (GemmArgs::ss_out / ss): `ss_out` on the producer (an in-place EPI_RESID), `ss` + `alpha` on
-// the consumer
-struct NormFold { float* ss_out; const float* ss; int ss_units; const uint16_t* alpha; int D; };
-
 void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
               const uint16_t* resid, const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0,
-              bool dominant = false, const DepKv* kv = nullptr, const NormFold* fold = nullptr) {
+              bool dominant = false, const DepKv* kv = nullptr) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    if (fold) { a.ss_out = fold->ss_out; a.ss = fold->ss; a.ss_units = fold->ss_units; a.alpha = fold->alpha; a.D = fold->D; a.eps = 1e-8f; }
     if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
     a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
@@ -501,26 +439,18 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
 
 // K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
 // Returns the number of partials, 0 when the GEMM is not split (then it applied the residual itself, in place on x).
-// finish: the residual stream is complete when the GEMM returns - the last split-K workgroup of each n-tile group folds the
-// partials into x (GemmArgs::finish_ctr) - and the row statistics of the RMSNorm that follows are in lm->ss (GemmArgs::ss_out):
-// the consuming GEMM needs no norm launch.  Returns 0 pending partials then.
-int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features, bool finish = false) {
+int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features) {
     const GemmPlan p = plan_gemm(g, true);
     if (p.ksplit <= 1) {
-        const NormFold nf{lm->ss, nullptr, 0, nullptr, 0};
-        add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x, nullptr, nullptr, 0, false, nullptr, finish ? &nf : nullptr);
+        add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x);
         return 0;
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.xp = reinterpret_cast<const u32x4*>(in); a.epi = MMI_EPI_PARTIAL; a.partial = lm->partial; a.B = lm->batch;
-    if (finish) {
-        a.finish_ctr = lm->finish_ctr; a.ss_out = lm->ss;
-        a.out = x; a.resid = x; a.out_mode = MMI_OUT_PACKED; a.out_ld = features; a.out_ksteps = packed_ksteps(lm, features);
-    }
     GemmW gw = g;
     lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); }, (long)g.bytes);
-    return finish ? 0 : p.ksplit;
+    return p.ksplit;
 }
 
 // x (+= the P pending split-K partials), y = rms_norm(x) * alpha
@@ -558,13 +488,7 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
     a.wq = g.wq; a.xinv = g.xinv;
-    // octet sharing for the non-gated fused-norm GEMMs too (the depth transformer's in_proj: 96 tiles -> 192 workgroups);
-    // MMI_GEMM_OSPLIT_NORM=1 switches it on (A/B)
-    {
-        GemmPlan pp; pp.ntw = 1; pp.ksplit = 1;
-        const char* e = getenv("MMI_GEMM_OSPLIT_NORM");   // measured neutral at 32 sessions (profiles/r02_logs/ab_osplit_norm*): opt-in
-        a.osplit = (e && atoi(e) != 0) || getenv("MMI_GEMM_OSPLIT") ? plan_osplit_norm(g, pp, epi, lm->T) : 1;
-    }
+    a.osplit = 1;
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
@@ -627,7 +551,6 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
     lm->prog.add([=](hipStream_t s) {
         if (V <= 2048) MMI_LAUNCH((k_sample<256, 8, true>), B, 256, 0, s, sa);
         else if (V <= 8192) MMI_LAUNCH((k_sample<1024, 8, true>), B, 1024, 0, s, sa);
-        else if (getenv("MMI_SAMPLE_TEXT_NOCACHE")) MMI_LAUNCH((k_sample<1024, 32, false>), B, 1024, 0, s, sa);
         else MMI_LAUNCH((k_sample<1024, 32, true>), B, 1024, 0, s, sa);   // 32 logits per thread = 16 VGPRs: read once, not once per pass
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
@@ -672,24 +595,12 @@ TokArgs tok_args(mmi_lm* lm) {
     return t;
 }
 
-// would launch_gemm run this GEMM on k_gemm_xlds?  (the folded norm exists on that kernel only)
-bool takes_xlds(const mmi_lm* lm, const GemmW& g, int epi, bool in_place_packed, int mt) {
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.epi = epi; a.B = mt * lm->T; a.wq = g.wq;
-    a.out_mode = MMI_OUT_PACKED;
-    if (in_place_packed) { a.out = reinterpret_cast<uint16_t*>(0x100); a.resid = a.out; }     // only compared, never dereferenced
-    a.whole_tiles = getenv("MMI_XLDS_WHOLE_TILES") ? 1 : 0;
-    return plan_xlds(lm, g, a, mt).on;
-}
-
 int build_program(mmi_lm* lm) {
     const mmi_lm_cfg& c = lm->cfg;
     const int B = lm->batch, d = c.dim, H = c.num_heads, Dh = d / H;
     const int dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
     const int n_user = c.n_q - c.dep_q;
     MmiProgram& P = lm->prog;
-    lm->op_layer.clear();
     // ---- token ring in, embeddings
     P.site("prepare");
     {
@@ -718,24 +629,18 @@ int build_program(mmi_lm* lm) {
     int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
-        lm->op_layer.push_back(P.ops.size());
-        const bool f1 = lm->fold1 && l > 0;      // the previous layer's linear_out finished the residual stream and left its statistics
-        if (!f1) {
         P.site("L.norm1");
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
-        }
         LmAttnArgs a;
         a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
-        a.mirror = getenv("MMI_ATTN_MIRROR") ? atoi(getenv("MMI_ATTN_MIRROR")) : 0;
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
             memset(&ga, 0, sizeof(ga));
-            ga.xp = reinterpret_cast<const u32x4*>(f1 ? lm->x : lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
-            if (f1) { ga.ss = lm->ss; ga.ss_units = mmi_cdiv(d, 8); ga.alpha = L.n1; ga.D = d; ga.eps = 1e-8f; }
+            ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
             ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context; ga.kv8 = kv8 ? 1 : 0;
             ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
@@ -749,13 +654,8 @@ int build_program(mmi_lm* lm) {
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
-        // out_proj -> norm2 -> linear_in without the launch in between: out_proj's last split-K workgroups finish the residual
-        // stream and leave the row statistics, linear_in (alpha in its columns) applies the per-session factor in its epilogue
-        // (GemmArgs::ss).  MMI_NO_NORM_FOLD=1 at create: the k_resid_rmsnorm launches (A/B)
-        const bool fold2 = lm->fold2;
-        if ((fold2 || lm->fold1) && (!lm->ss || mmi_cdiv(d, 8) > lm->ss_units_max)) return mmi_fail(MMI_ERR_UNSUPPORTED, "folded norm: statistics buffer too small");
         P.site("L.out_proj");
-        pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d, fold2);
+        pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
         if (c.cross_attention) {   // x = x + cross_attention(norm_cross(x), src, src) (transformer.py:779-786)
             P.site("L.norm_cross");
             {
@@ -786,18 +686,12 @@ int build_program(mmi_lm* lm) {
             P.site("L.cross_out");
             pending = add_gemm_resid(lm, L.x_out, lm->att, lm->x, d);
         }
-        if (fold2) {
-            const NormFold nf{nullptr, lm->ss, mmi_cdiv(d, 8), L.n2, d};
-            P.site("L.ffn_in");
-            add_gemm(lm, L.ffn_in, lm->x, lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true, nullptr, &nf);
-        } else {
         P.site("L.norm2");
         add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d);
         P.site("L.ffn_in");
         add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
-        }
         P.site("L.ffn_out");
-        pending = add_gemm_resid(lm, L.ffn_out, lm->hb, lm->x, d, lm->fold1 && l + 1 < c.num_layers);
+        pending = add_gemm_resid(lm, L.ffn_out, lm->hb, lm->x, d);
     }
     P.site("out_norm");
     add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
@@ -835,7 +729,7 @@ int build_program(mmi_lm* lm) {
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
             P.site("dep.attn");
-            const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8 && !getenv("MMI_DEP_ATTN_OLD");
+            const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8;        // else the general one-wave-per-(session, head) kernel
             if (!skip_attn0)
             P.add([=](hipStream_t s) {
                 if (attn8) MMI_LAUNCH((k_dep_attn8<4>), mmi_cdiv(B * Hd, 4), 256, 0, s, da);
@@ -1000,43 +894,12 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
     for (int l = 0; l < c.num_layers; ++l) {
         LayerW& L = lm->layers[l];
         std::string p = "transformer.layers." + std::to_string(l);
+        if ((rc = load_linear(lm, W, p + ".self_attn.in_projs.0.weight", 3 * d, d, 0, &L.in_proj))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".self_attn.out_projs.0.weight", d, d, 0, &L.out_proj))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".gating.linear_in.weight", 2 * c.ffn_hidden, d, c.ffn_hidden, &L.ffn_in))) return fail(rc);
+        if ((rc = load_linear(lm, W, p + ".gating.linear_out.weight", d, c.ffn_hidden, 0, &L.ffn_out))) return fail(rc);
         if ((rc = load_copy(lm, W, p + ".norm1.alpha", 3, d, &L.n1))) return fail(rc);
         if ((rc = load_copy(lm, W, p + ".norm2.alpha", 3, d, &L.n2))) return fail(rc);
-        if (l == 0) {
-            // RMSNorm folded across GEMM pairs (GemmArgs::ss): decided once, here, because the decision changes the packed
-            // weights of the consumers (alpha folded into their columns).  Needs bf16 linears, the 32-row tile and both
-            // consumers on k_gemm_xlds at one and two batch tiles.  MMI_NO_NORM_FOLD=1: the norm launches (A/B)
-            const mmi_tensor_desc* wd = W.find(p + ".self_attn.in_projs.0.weight");
-            const bool bf16 = wd && wd->dtype == MMI_BF16;
-            GemmW pin, pffn;                            // shapes only: what plan_xlds looks at
-            pin.K = pffn.K = d; pin.KSTEPS = pffn.KSTEPS = mmi_cdiv(d, mmi_kstep(lm->T));
-            pin.N = 3 * d; pin.NT = mmi_cdiv(3 * d, lm->T);
-            pffn.N = c.ffn_hidden; pffn.gate = 1; pffn.NT = mmi_cdiv(c.ffn_hidden, lm->T / 2);
-            // OFF by default (MMI_NORM_FOLD=1 opts in): measured on MI355X at 32 sessions it buys nothing as built (LM step 5.68 ms
-            // against 5.66 ms: the finishing workgroups and the consumer's statistics pass cost what the two 5.2 us norm launches
-            // cost) and moves the engine further from the reference (32-layer golden: text median 2.07 % -> 2.39 % of max|logit|,
-            // worst audio mean 1.11 % -> 1.26 %; profiles/r03_logs/norm_fold_ab.txt).
-            const char* nf = getenv("MMI_NORM_FOLD");
-            bool ok2 = nf && nf[0] == '1' && bf16 && !c.cross_attention && lm->T == 32 && !getenv("MMI_NO_NORM_FOLD"), ok1 = ok2;
-            for (int mt = 1; mt <= (max_batch > 32 ? 2 : 1); ++mt) {
-                ok2 = ok2 && takes_xlds(lm, pffn, MMI_EPI_GATE, false, mt);
-                ok1 = ok1 && takes_xlds(lm, pin, MMI_EPI_ROPE_KV, false, mt);
-            }
-            lm->fold2 = ok2;
-            lm->fold1 = ok1 && c.num_layers > 1 && !getenv("MMI_NO_NORM_FOLD1");
-        }
-        if ((rc = load_linear(lm, W, p + ".self_attn.in_projs.0.weight", 3 * d, d, 0, &L.in_proj, nullptr, nullptr,
-                              lm->fold1 && l > 0 ? L.n1 : nullptr))) return fail(rc);
-        if ((rc = load_linear(lm, W, p + ".self_attn.out_projs.0.weight", d, d, 0, &L.out_proj))) return fail(rc);
-        // MMI_GATE_OCT=1: the temporal linear_in interleaves gate / value rows per row octet so that k_gemm_xlds shares its 704
-        // tiles out in octets (11 per workgroup instead of 2 or 3 whole tiles).  OFF by default: measured SLOWER on MI355X - 40.2
-        // against 39.0 us per launch at 32 sessions, 49.5 against 44.6 us at 64 (profiles/r03_logs/gate_oct_ab.txt): a workgroup
-        // then touches up to 4 tiles, i.e. issues 4 weight loads per k-step of which 2.75 carry new bytes, and the stream is
-        // bound by the loads in flight, not by the 8 % imbalance.
-        const bool oct = lm->q8 == 0 && lm->T == 32 && c.ffn_hidden % 4 == 0 && getenv("MMI_GATE_OCT") && getenv("MMI_GATE_OCT")[0] == '1';
-        if ((rc = load_linear(lm, W, p + ".gating.linear_in.weight", 2 * c.ffn_hidden, d, oct ? -c.ffn_hidden : c.ffn_hidden, &L.ffn_in, nullptr, nullptr,
-                              lm->fold2 ? L.n2 : nullptr))) return fail(rc);
-        if ((rc = load_linear(lm, W, p + ".gating.linear_out.weight", d, c.ffn_hidden, 0, &L.ffn_out))) return fail(rc);
         if (c.cross_attention) {
             if (d % lm->T) return fail(mmi_fail(MMI_ERR_UNSUPPORTED, "cross-attention needs dim to be a multiple of the GEMM tile"));
             if ((rc = load_linear(lm, W, p + ".cross_attention.in_projs.0.weight", 3 * d, d, 0, &L.x_in))) return fail(rc);
@@ -1206,9 +1069,6 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
     ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
-    lm->ss_units_max = mmi_cdiv(d, 8);
-    ok &= hipSuccess == A.alloc(&lm->ss, (size_t)lm->ss_units_max * B);
-    ok &= hipSuccess == A.alloc(&lm->finish_ctr, (size_t)mmi_cdiv(d, 8));
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
@@ -1242,7 +1102,6 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
     lm->noise_on = false;
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
-    MMI_HIP_CHECK(hipMemsetAsync(lm->finish_ctr, 0, (size_t)mmi_cdiv(d, 8) * sizeof(unsigned), s));
     lm->forced_armed = false;
     {   // packed activations: the padding rows / columns of a fragment are never written and must read as zero
         struct { uint16_t* p; int f; } pk[] = {{lm->x, d}, {lm->xn, d}, {lm->att, d}, {lm->hb, c.ffn_hidden}, {lm->tout, d},
@@ -1331,8 +1190,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     }
     else if (lm->phase_fn) {
         auto fn = lm->phase_fn; void* user = lm->phase_user;
-        const size_t cut = lm->phase_layer >= 0 && lm->phase_layer < (int)lm->op_layer.size() ? lm->op_layer[lm->phase_layer] : lm->op_depformer;
-        rc = lm->prog.run_split(s, lm->use_graph && !lm->profiling, lm->cap_stream, cut, [fn, user](hipStream_t st) {
+        rc = lm->prog.run_split(s, lm->use_graph && !lm->profiling, lm->cap_stream, lm->op_depformer, [fn, user](hipStream_t st) {
             return fn(user, (mmi_stream)st) ? mmi_fail(MMI_ERR_INVALID, "the phase callback reported an error") : (int)MMI_OK;
         });
     } else rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
@@ -1361,7 +1219,6 @@ extern "C" int mmi_lm_set_phase_callback(mmi_lm* lm, int (*fn)(void*, mmi_stream
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     lm->phase_fn = fn;
     lm->phase_user = user;
-    if (const char* e = getenv("MMI_LM_PHASE_LAYER")) lm->phase_layer = atoi(e);
     return MMI_OK;
 }
 
@@ -1566,11 +1423,8 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
     if (kernel_name)
         *kernel_name = lm->q8 == 1   ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
                        : lm->q8 == 2 ? "k_gemm_xp<32, 1, 1, 8, 2, 2> (temporal FFN linear_in, fp8 weights on the fp8 MFMA + SiLU gate)"
-                       : lm->dominant_xlds ? (!lm->layers.empty() && lm->layers[0].ffn_in.gate_oct
-                                                  ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 4, true, 0> (temporal FFN linear_in + SiLU gate, tiles shared in row octets)"
-                                                                    : "k_gemm_xlds<1, 64, 4, true, 0> (temporal FFN linear_in + SiLU gate, tiles shared in row octets)")
-                                                  : (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
-                                                                    : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)"))
+                       : lm->dominant_xlds ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
+                                                             : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)")
                                      : "k_gemm_xp<32, 1, 1, 8, 2> (temporal FFN linear_in + SiLU gate)";
     lm->ev_used = 0;
     return MMI_OK;

@@ -38,10 +38,8 @@ static inline int mmi_kstep(int T) { return T == 32 ? 16 : 32; }
 
 // gate_hidden == 0: plain [N][K] matrix.  gate_hidden == H: rows [0,H) are gates, [H,2H) values; tile nt carries
 // gate rows nt*TN/2 .. and, in its second half, the matching value rows (so the epilogue forms silu(g)*u locally).
-// col_scale (or null): the consuming RMSNorm's alpha folded into the columns, P = bf16(W[n][k] * alpha[k]) - for the GEMMs that
-// apply the norm's per-session factor in their epilogue instead of reading normalised rows (GemmArgs::ss).
 __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restrict__ P, int N, int K, int TN, int NT,
-                              int KSTEPS, int gate_hidden, const uint16_t* __restrict__ col_scale) {
+                              int KSTEPS, int gate_hidden) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)NT * KSTEPS * 512;
     if (idx >= total) return;
@@ -55,12 +53,7 @@ __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restri
     int k = ks * kstep + 8 * kq + e;
     long row;
     bool valid;
-    if (gate_hidden < 0) {             // per-octet interleave (MMI_EPI_GATE_OCT): row i of the tile -> octet i >> 3, r = i & 7
-        const int H = -gate_hidden;
-        const int f = nt * (TN / 2) + 4 * (i >> 3) + (i & 3);
-        valid = f < H;
-        row = ((i & 7) < 4 ? 0 : H) + f;
-    } else if (gate_hidden > 0) {
+    if (gate_hidden > 0) {
         int half = TN / 2;
         int r = nt * half + (i < half ? i : i - half);
         valid = r < gate_hidden;
@@ -70,10 +63,7 @@ __global__ void k_pack_w_bf16(const uint16_t* __restrict__ W, uint16_t* __restri
         valid = row < N;
     }
     uint16_t v = 0;
-    if (valid && k < K) {
-        v = W[row * K + k];
-        if (col_scale) v = mmi_f32_to_bf16_bits(mmi_bf16_to_f32(v) * mmi_bf16_to_f32(col_scale[k]));
-    }
+    if (valid && k < K) v = W[row * K + k];
     P[idx] = v;
 }
 
@@ -96,12 +86,7 @@ __global__ void k_pack_w_i8(const int8_t* __restrict__ W, int8_t* __restrict__ P
     int k = (2 * kp + (e >> 3)) * kstep + 8 * kq + (e & 7);
     long row;
     bool valid;
-    if (gate_hidden < 0) {             // per-octet interleave (MMI_EPI_GATE_OCT): row i of the tile -> octet i >> 3, r = i & 7
-        const int H = -gate_hidden;
-        const int f = nt * (TN / 2) + 4 * (i >> 3) + (i & 3);
-        valid = f < H;
-        row = ((i & 7) < 4 ? 0 : H) + f;
-    } else if (gate_hidden > 0) {
+    if (gate_hidden > 0) {
         int half = TN / 2;
         int r = nt * half + (i < half ? i : i - half);
         valid = r < gate_hidden;
@@ -155,11 +140,7 @@ __device__ __forceinline__ u32x2 mmi_bf16x8_to_fp8(u32x4 x, float inv) {
 // fragments from L2.  The waves' partial tiles are summed through LDS in a fixed order (deterministic), and the
 // epilogue (bf16 rounding point of nn.Linear, residual add, SiLU gate, embedding add) writes 8 consecutive features
 // of one session as one 16-byte vector.
-enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5, MMI_EPI_DEP_QKV0 = 6,
-       // gated linear_in whose tiles interleave gate and value rows PER ROW OCTET (k_pack_w_bf16 gate_hidden < 0): octet o of tile nt
-       // = gate rows of features 16 nt + 4 o .. + 3, then their value rows - every octet is self-contained, so k_gemm_xlds can
-       // share the tiles out in octets (704 tiles over 256 workgroups = 11 octets each instead of 2 or 3 whole tiles)
-       MMI_EPI_GATE_OCT = 7 };
+enum { MMI_EPI_STORE = 0, MMI_EPI_RESID = 1, MMI_EPI_GATE = 2, MMI_EPI_EMB = 3, MMI_EPI_PARTIAL = 4, MMI_EPI_ROPE_KV = 5, MMI_EPI_DEP_QKV0 = 6 };
 enum { MMI_OUT_ROWMAJOR = 0, MMI_OUT_PACKED = 1 };
 
 struct GemmArgs {
@@ -195,24 +176,6 @@ struct GemmArgs {
     const uint16_t* alpha;  // [D]
     int D;                  // features of a row (the mean is over D, not the padded K)
     float eps;
-    // RMSNorm folded across a GEMM pair (the temporal layer's out_proj -> norm2 -> linear_in, lm_engine.hip build_program): the
-    // PRODUCER's EPI_RESID epilogue also stores, per 8-feature group and session, the sum of squares of the bf16 residual stream
-    // it just wrote - ss_out[(nt * 4 + group) * B + b].  The CONSUMER (k_gemm_xlds<.., NORM>) reads the UN-normalised rows, sums
-    // the ss_units partials of each session in a fixed order and multiplies its accumulators by r_b = rsqrt(eps + sum / D)
-    // before the linear's bf16 rounding; the norm's alpha is folded into its weight columns at pack time (k_pack_w_bf16):
-    //     y[b][n] = bf16( r_b * sum_k bf16(W[n][k] alpha[k]) x[b][k] )   for   bf16( sum_k W[n][k] bf16(x[b][k] alpha[k] r_b) )
-    // i.e. the norm launch between the two GEMMs is gone, at the price of moving one bf16 rounding from the normalised activation
-    // to the scaled weight (transformer.py:45-58; measured against the reference goldens).
-    float* ss_out;
-    const float* ss;
-    int ss_units;
-    // EPI_PARTIAL with a finish: the split-K workgroups of an n-tile group count themselves off on finish_ctr[blockIdx.x]; the
-    // one that arrives last sums the gridDim.y partials in index order (as k_resid_rmsnorm does), adds the residual in place on
-    // the packed `out` (= resid) and stores the row statistics (ss_out) - the work of the split-K finish launch, done at the tail
-    // of the GEMM by a workgroup that holds nothing else.  Partners (x, 0) and (x, 1) of a gridDim.x = 128 launch are 128
-    // workgroup ids apart, i.e. on the same XCD (ids go round the 8 XCDs): the hand-off stays inside one L2.
-    unsigned* finish_ctr;
-    int whole_tiles;        // k_gemm_xlds: share the n-tiles out whole (A/B switch MMI_XLDS_WHOLE_TILES=1) instead of in row octets
     int osplit;             // k_gemm_xp: > 1 = every n-tile is shared by `osplit` workgroups, each owning TN / 8 / osplit of its row octets
                             // (grid.x = NT * osplit).  For GEMMs with few n-tiles (N = 1024 of the depth transformer: 32 tiles on
                             // 256 CUs), where one CU cannot pull its 64-180 KB of weights faster than ~25 GB/s: a workgroup's lanes of
@@ -252,12 +215,9 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 // kernels that own all of the LDS themselves (k_gemm_xlds).
 // g_lo / g_hi: only the tile's 8-feature groups [g_lo, g_hi) are written (k_gemm_xlds hands a tile's row octets to two
 // workgroups when that balances the chip: 384 in_proj tiles over 256 CUs = 6 octets each); default = the whole tile.
-// rscale (or null): per-m-tile factor of the thread's session (q % TN is the same session for all of a thread's tasks): the
-// accumulators are multiplied by it before anything else (the folded RMSNorm, GemmArgs::ss).
 template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
-                                                  int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4,
-                                                  const float* rscale = nullptr) {
+                                                  int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4) {
     constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic).  LDS layout [wave][tile][lane][LS]:
     // a lane's accumulators are contiguous, so they go out and come back as 16-byte vectors; LS = 20 floats (80 B)
@@ -284,9 +244,8 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 
     // ---- epilogue: one task = 8 consecutive output features of one session
     const bool gate = a.epi == MMI_EPI_GATE;
-    const bool gate_oct = a.epi == MMI_EPI_GATE_OCT; // 4 output features per task: one row octet = 4 gate rows + their 4 value rows
-    const int rows_out = (gate || gate_oct) ? TN / 2 : TN;         // output features per tile
-    const int G = gate_oct ? TN / 8 : rows_out / 8;  // feature groups per tile
+    const int rows_out = gate ? TN / 2 : TN;         // output features per tile
+    const int G = rows_out / 8;                      // feature groups per tile
     const int ntasks = NTW * MT * G * TN;
     for (int q = (int)threadIdx.x; q < ntasks; q += WAVES * 64) {
         const int bl = q % TN;
@@ -296,7 +255,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         const int m = rest % MT, t = rest / MT;
         const int nt = nt0 + t;
         const int b = m * TN + bl;
-        const int n0 = nt * rows_out + (gate_oct ? 4 : 8) * gi;
+        const int n0 = nt * rows_out + 8 * gi;
         if (nt >= a.NT || b >= a.B || n0 >= a.N || gi < g_lo || gi >= g_hi) continue;
         const float* rb = red + (t * MT + m) * 64 * LS;
         // features 8*gi .. 8*gi+7 of the tile live in two lanes' accumulator quads (MFMA C layout, lm_kernels.h header):
@@ -329,11 +288,6 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 for (int e = 0; e < 4; ++e) { s2[e] += lo[e]; s2[4 + e] += hi[e]; }
             }
         }
-        if (rscale) {
-            const float rs = rscale[m];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] *= rs; s2[e] *= rs; }
-        }
         if (a.wscale) {   // int8 weights: y = (sum_k q x) * SCB / 127, per original weight row
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.wscale + n0), c1 = *reinterpret_cast<const f32x4*>(a.wscale + n0 + 4);
 #pragma unroll
@@ -344,31 +298,8 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 for (int e = 0; e < 4; ++e) { s2[e] *= g0[e]; s2[4 + e] *= g1[e]; }
             }
         }
-        if (gate_oct) {
-            // s[0..3] = the octet's gate rows (lane bl), s[4..7] = its value rows (lane bl + 32): 4 output features, 8 bytes
-            u32x2 ov;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float y[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float g = mmi_round_bf16(s[2 * e + h]);
-                    const float u = mmi_round_bf16(s[4 + 2 * e + h]);
-                    y[h] = mmi_round_bf16(g / (1.0f + expf(-g))) * u;       // F.silu on a bf16 tensor, times the value
-                }
-                ov[e] = mmi_pack_bf16x2(y[0], y[1]);
-            }
-            uint16_t* dst4 = a.out_mode == MMI_OUT_PACKED ? a.out + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.out + (long)b * a.out_ld + n0;
-            *reinterpret_cast<u32x2*>(dst4) = ov;
-            continue;
-        }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
-            if (a.finish_ctr) {                     // read by the partner workgroup inside this launch: written through (mmi_device.h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mmi_st_agent(pd + 2 * e, f32x2{s[2 * e], s[2 * e + 1]});
-                continue;
-            }
             f32x4 lo = {s[0], s[1], s[2], s[3]}, hi = {s[4], s[5], s[6], s[7]};
             *reinterpret_cast<f32x4*>(pd) = lo;
             *reinterpret_cast<f32x4*>(pd + 4) = hi;
@@ -438,17 +369,11 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         } else if (a.epi == MMI_EPI_RESID) {
             const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps)
                                                               : a.resid + (long)b * a.out_ld + n0;
-            const u32x4 rv = (!EXT && q == (int)threadIdx.x) ? pre : *reinterpret_cast<const u32x4*>(rs);   // EXT callers prefetch nothing
+            const u32x4 rv = q == (int)threadIdx.x ? pre : *reinterpret_cast<const u32x4*>(rs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint16_t h = (uint16_t)((e & 1) ? (rv[e >> 1] >> 16) : (rv[e >> 1] & 0xffffu));
                 o[e] = mmi_round_bf16(s[e]) + mmi_bf16_to_f32(h);           // x_orig + update
-            }
-            if (a.ss_out) {         // the consumer's RMSNorm statistics, over the values as the bf16 residual stream holds them
-                float q2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float r = mmi_round_bf16(o[e]); q2 += r * r; }
-                a.ss_out[((long)nt * G + gi) * a.B + b] = q2;
             }
         } else if (a.epi == MMI_EPI_EMB) {
             u32x4 ev = pre;
@@ -470,59 +395,6 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e], o[2 * e + 1]);
         *reinterpret_cast<u32x4*>(dst) = ov;
-    }
-    if (a.epi == MMI_EPI_PARTIAL && a.finish_ctr) {
-        // ---- split-K finish by the last workgroup of the n-tile group to arrive (GemmArgs::finish_ctr)
-        MMI_SHARED int is_last;
-        mmi_stores_done();                           // this wave's partial sums are out before the count
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = mmi_arrive_agent(a.finish_ctr + blockIdx.x);
-            is_last = old + 1 == gridDim.y ? 1 : 0;
-            if (is_last) a.finish_ctr[blockIdx.x] = 0;   // ready for the next launch: nobody else touches it before then
-        }
-        __syncthreads();
-        if (!is_last) return;
-        const int P = (int)gridDim.y;
-        for (int q = (int)threadIdx.x; q < ntasks; q += WAVES * 64) {
-            const int bl = q % TN;
-            int rest = q / TN;
-            const int gi = rest % G;
-            rest /= G;
-            const int m = rest % MT, t = rest / MT;
-            const int nt = nt0 + t, b = m * TN + bl, n0 = nt * rows_out + 8 * gi;
-            if (nt >= a.NT || b >= a.B || n0 >= a.N || gi < g_lo || gi >= g_hi) continue;
-            f32x4 plo[4], phi[4];                    // P <= 4; unconditional (clamped) loads, all in flight
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float* pp = a.partial + ((long)min(p, P - 1) * a.B + b) * a.N + n0;
-                const f32x2 v0 = mmi_ld_agent(pp), v1 = mmi_ld_agent(pp + 2), v2 = mmi_ld_agent(pp + 4), v3 = mmi_ld_agent(pp + 6);
-                plo[p] = f32x4{v0[0], v0[1], v1[0], v1[1]};
-                phi[p] = f32x4{v2[0], v2[1], v3[0], v3[1]};
-            }
-            uint16_t* xd = a.out + mmi_xp_index(TN, b, n0, a.out_ksteps);
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(xd);
-            float u[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = 0.f;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float on = p < P ? 1.f : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { u[e] += plo[p][e] * on; u[4 + e] += phi[p][e] * on; }
-            }
-            float q2 = 0.f;
-            u32x4 ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = mmi_round_bf16(mmi_round_bf16(u[2 * e]) + mmi_bf16_to_f32((uint16_t)(rv[e] & 0xffffu)));       // x_orig + update
-                const float x1 = mmi_round_bf16(mmi_round_bf16(u[2 * e + 1]) + mmi_bf16_to_f32((uint16_t)(rv[e] >> 16)));
-                q2 += x0 * x0 + x1 * x1;
-                ov[e] = mmi_pack_bf16x2(x0, x1);
-            }
-            *reinterpret_cast<u32x4*>(xd) = ov;
-            if (a.ss_out) a.ss_out[((long)nt * G + gi) * a.B + b] = q2;
-        }
     }
 }
 
@@ -683,12 +555,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    // octet sharing (GemmArgs::osplit, see k_gemm_xp): workgroup = (n-tile, part)
-    const int os = a.osplit > 1 ? a.osplit : 1;
-    const int nt0 = (int)blockIdx.x / os, part = (int)blockIdx.x - nt0 * os;
-    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
-    const int ro = (lane >> 3) & (TN / 8 - 1);
-    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
+    const int nt0 = (int)blockIdx.x;                          // one n-tile per workgroup (octet sharing of these GEMMs measured
+    const int g_lo = 0, g_hi = TN / 8, wlane = lane;          // neutral, profiles/r02_logs/ab_osplit_norm*: not built in)
     const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
     const int ks0 = min(a.KSTEPS, wave * kper);
     const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
@@ -813,12 +681,9 @@ struct MmiFalse { static constexpr bool value = false; };
 // entry meets XS = 2 activation fragments, so the production chunk is 32 / MT entries (the same 64 KiB of activations).
 // Chunks shorter than 8 entries (the tiny shapes of the tests) leave the upper waves without k-steps: they keep zero
 // accumulators and only take part in the barriers and the epilogue.
-// NORM: the activations are the un-normalised residual stream, the weights carry the norm's alpha, and the epilogue applies the
-// per-session factor rsqrt(eps + mean(x^2)) taken from the producer's partial sums (GemmArgs::ss).  bf16 weights only.
-template <int MT, int KC, int NTMAX = 3, bool STAGGER = false, int WQ = 0, bool NORM = false>
+template <int MT, int KC, int NTMAX = 3, bool STAGGER = false, int WQ = 0>
 __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(16)));
-    static_assert(!NORM || WQ == 0, "the folded norm is built for bf16 weight entries");
     constexpr int XS = WQ ? 2 : 1;              // activation fragments per weight entry
     constexpr int KPW = KC >= 8 ? KC / 8 : 1;   // entries per wave per chunk
     constexpr int ACTIVE = KC / KPW;            // waves that own k-steps
@@ -835,7 +700,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     // 384 in_proj tiles over 256 workgroups are 6 octets = 1.5 tiles each instead of 1 or 2 whole tiles, i.e. every CU streams
     // the same number of bytes.  A workgroup that owns only part of a tile loads only those octets' lanes (the other lanes
     // repeat a valid lane's address: rows of the MFMA are independent, their results are simply not written).
-    const bool by_octet = a.epi != MMI_EPI_GATE && !a.whole_tiles;      // MMI_EPI_GATE_OCT: octets are self-contained
+    const bool by_octet = a.epi != MMI_EPI_GATE;
     const long units = by_octet ? 4L * a.NT : (long)a.NT;
     const long u0 = (long)bid * units / G, u1 = (long)(bid + 1) * units / G;          // [u0, u1) octets or tiles
     const int t0 = by_octet ? (int)(u0 >> 2) : (int)u0;
@@ -858,8 +723,6 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
         return a.xp + ((long)m * a.KSTEPS + (long)c * KC) * XS * 64 + rest;
     };
     u32x4 xpre[XPT];
-    // NORM: r_b of the thread's session 32 * m + (tid & 31) - the session of every epilogue task of this thread
-    float rfac[MT];
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
         const int e = min(j * 512 + tid, XE - 1);
@@ -878,34 +741,6 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
         const u32x4* wp = wsrc(0, 0);
 #pragma unroll
         for (int i = 0; i < KPW; ++i) cur[i] = mmi_load_nt(wp + i * 64);
-    }
-    if constexpr (NORM) {
-        // rsqrt(eps + mean(x^2)) of the thread's sessions, behind the first weight requests: 16 threads share a session
-        // (tid & 31), each sums every 16th of the producer's partial sums - 8 unconditional (clamped) loads in flight at a time -
-        // then the 16 parts in a fixed order
-        MMI_SHARED float rpart[16][32 * MT];
-        const int bl = tid & 31, part = tid >> 5;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int b = min(m * 32 + bl, a.B - 1);
-            float sm = 0.f;
-            for (int u0 = part; u0 < a.ss_units; u0 += 16 * 8) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = a.ss[(long)min(u0 + 16 * i, a.ss_units - 1) * a.B + b];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sm += (u0 + 16 * i < a.ss_units) ? v[i] : 0.f;
-            }
-            rpart[part][m * 32 + bl] = sm;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float tot = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tot += rpart[q][m * 32 + bl];
-            rfac[m] = mmi_rsqrtf(a.eps + tot / (float)a.D);
-        }
     }
     // one weight entry against the resident activations
     auto mma = [&](const u32x4& w, const u32x4* xe, acc_t (&ac)[MT]) {
@@ -966,8 +801,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
-                    mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t),
-                                                          NORM ? rfac : nullptr);
+                    mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
                 }
             }
         }
@@ -991,8 +825,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
-            mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t),
-                                                  NORM ? rfac : nullptr);
+            mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
         }
     }
 }
@@ -1269,7 +1102,6 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
-    int mirror;            // k_lm_attn_split: walk every second group of 8 sessions backwards (load balance across CUs)
 };
 
 #define MMI_ATTN_CHUNK 256
@@ -1287,17 +1119,9 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     constexpr int LPR = DH / EPL;      // lanes per row
     constexpr int RPW = 64 / LPR;      // rows per wave instruction
     constexpr int CH = MMI_ATTN_CHUNK;
-    // Which (session, head) a workgroup takes.  Workgroups are placed round-robin, so blocks i, i + 256, i + 512, ... share a CU
-    // and a CU's time is the sum of its sessions' ring depths; sessions admitted one after the other have depths that grow with
-    // the index (the benchmark's 8-frame stagger: 40..290 rows), and the plain order gives CU i the sessions i/32, i/32 + 8, ...
-    // - 17 % more rows on the heaviest CU than on the average one.  Every second group of 8 sessions is therefore walked
-    // backwards (b0, 15 - b0, 16 + b0, 31 - b0: equal sums for any linear profile, no worse for a random one).  A pure
-    // relabelling: results identical.
-    int bh = blockIdx.x;
-    if (a.mirror) {
-        const int bb = bh / a.H, g = bb >> 3;
-        if ((g & 1) && g * 8 + 7 < a.B) bh = (g * 8 + 7 - (bb & 7)) * a.H + (bh - bb * a.H);
-    }
+    // (a mirrored session order - every second group of 8 sessions walked backwards, for load balance across CUs under a linear
+    // stagger of ring depths - measured neutral, round 2: not built in)
+    const int bh = blockIdx.x;
     const int b = bh / a.H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long off = a.offsets[b];

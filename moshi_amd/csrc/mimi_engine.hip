@@ -374,8 +374,7 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
                 {128, 512, 1, 1, 960, 1, 2},    // dec.convtr3                       128.8 -> 99.5
                 {64, 1, 7, 1, 3840, 1, 4},      // dec.final                          31.5 -> 28.1
             };
-            if (!getenv("MMI_CONV_NO_TUNE_TABLE"))
-                for (const Tune& t : kTune)
+            for (const Tune& t : kTune)
                     if (t.Cin == a.Cin && t.Cout == a.Cout && t.K == a.K && t.S == a.S && 4 * nsub >= 3 * t.nsub && 2 * nsub < 3 * t.nsub) {
                         MTB = t.MTB; W = t.W;
                         while (MTB > a.Mt) MTB >>= 1;
@@ -421,7 +420,7 @@ int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
         p->pack = true;
     }
     // small weight matrices (the transformer linears, <= 8 MB): one workgroup per n-subtile, up to 16 waves splitting K
-    const bool spread = nsub >= 2 && (size_t)a.Mt * a.Q * 1024 <= ((size_t)8 << 20) && !getenv("MMI_CONV_NO_SPREAD");
+    const bool spread = nsub >= 2 && (size_t)a.Mt * a.Q * 1024 <= ((size_t)8 << 20);
     int ks = 1;
     if (a.out_mode == MMI_GOUT_NATURAL) {
         // only the large strided convs (>= 2048-deep reductions, tens of MB of weights) are worth a finishing launch
@@ -521,14 +520,12 @@ int add_resblock(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a1, ConvGemmArgs a2
     if (const char* e = getenv("MMI_MIMI_RES_FUSION_MIN")) min_waves = atol(e);      // test hook: the tiny shapes
     // Measured on MI355X (profiles/r02_logs/resblock_*): the 64-channel blocks (one hidden tile, 1920 one-wave workgroups) gain
     // 8-13 us each over two launches; the 128 / 256-channel blocks (480 / 96 workgroups of 2 / 4 waves: one wave per SIMD on part of
-    // the chip) lose 2-15 us to the two-launch path's split-K over waves - they take the fused kernel only when asked
-    // (MMI_MIMI_RES_FUSION_ALL=1: tests, experiments).
-    const bool all_widths = getenv("MMI_MIMI_RES_FUSION_ALL") != nullptr;
+    // the chip) lost 2-15 us to the two-launch path's split-K over waves and are not instantiated.
     const bool fuse = a1.Ntot > 128 && a1.S == 1 && a2.K == 1 && a2.S == 1 && a1.Cout == a2.Cin && a1.Ntot == a2.Ntot &&
-                      a1.T_out == a2.T_out && (a1.Mt == 1 || ((a1.Mt == 2 || a1.Mt == 4) && all_widths)) && w2.wpk_h && a2.Q <= 4 * a1.Mt &&
+                      a1.T_out == a2.T_out && a1.Mt == 1 && w2.wpk_h && a2.Q <= 4 * a1.Mt &&
                       a2.Mt >= a1.Mt && (long)nblk * a1.Mt >= min_waves && !a1.first && !a2.first && !a1.res && !a1.scale && !a2.scale &&
                       a1.T_out % 32 == 0 && a1.Cin <= 64 * a1.Mt && a1.K <= 33 &&
-                      a1.act_out == MMI_ACT_NONE && a2.act_out == MMI_ACT_NONE && !getenv("MMI_MIMI_NO_RES_FUSION");
+                      a1.act_out == MMI_ACT_NONE && a2.act_out == MMI_ACT_NONE;
     if (!fuse) {
         int rc = add_conv(m, prog, a1);
         if (rc) return rc;
@@ -542,12 +539,8 @@ int add_resblock(mmi_mimi* m, MmiProgram& prog, ConvGemmArgs a1, ConvGemmArgs a2
     // LDS: input window Cin x (32 + K - 1) | offset table | the waves' hand-off mailbox
     const size_t smem = ((size_t)((a1.Cin * (32 + a1.K - 1) + 3) & ~3) + (size_t)a1.Q * 8 + (mt1 > 1 ? (size_t)mt1 * 1024 : 0)) * sizeof(float);
     if (smem > 65536) return mmi_fail(MMI_ERR_UNSUPPORTED, "k_resblock: input window does not fit in LDS");
-    prog.add([ra, mt1, nblk, smem](hipStream_t s) {
-        switch (mt1) {
-            case 1: MMI_LAUNCH((k_resblock<1, 4>), nblk, 64, smem, s, ra); break;
-            case 2: MMI_LAUNCH((k_resblock<2, 4>), nblk, 128, smem, s, ra); break;
-            default: MMI_LAUNCH((k_resblock<4, 4>), nblk, 256, smem, s, ra); break;
-        }
+    prog.add([ra, nblk, smem](hipStream_t s) {
+        MMI_LAUNCH((k_resblock<1, 4>), nblk, 64, smem, s, ra);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -663,7 +656,7 @@ int add_transformer(mmi_mimi* m, MmiProgram& prog, const std::vector<TrLayerW>& 
     // LayerNorm fused into the linear that consumes it (k_gemm_f32_ln): the producers of the residual stream inside the
     // transformer (out_proj, linear2) also store it in packed operand order (xrp); only the very first norm, whose input
     // comes from the conv stack, stays a launch of its own.  32 -> 2 norm launches per frame for the two transformers.
-    const bool fuse_ln = packed && d % 8 == 0 && Qd <= 64 && layers.size() > 0 && layers[0].n1w_pk && !getenv("MMI_MIMI_NO_LN_FUSION");
+    const bool fuse_ln = packed && d % 8 == 0 && Qd <= 64 && layers.size() > 0 && layers[0].n1w_pk;
     float* xrp = nullptr;
     if (fuse_ln) {
         MMI_HIP_CHECK(m->st.alloc(&xrp, (size_t)nsub * Qd * 256));
@@ -771,11 +764,10 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
     int mult = 1;
     // ELU hoisted into the producers (mimi_kernels.h ConvGemmArgs::elu_out / out2): a resblock input is kept raw (residual) AND
     // ELU'd (its first conv reads that, history included); everything else a conv reads through ELU is stored ELU'd only
-    const bool hoist = !getenv("MMI_NO_ELU_HOIST");
     {   // conv0: channels -> n_filters, K = kernel_size; consumer = resblock conv (K = residual_kernel_size)
         Buf nxt;
         if ((rc = alloc_buf(m, B, c.n_filters, c.residual_kernel_size - 1, T, &nxt, s0))) return rc;
-        if (hoist && (rc = alloc_twin(m, B, &nxt, s0))) return rc;
+        if ((rc = alloc_twin(m, B, &nxt, s0))) return rc;
         prog.site("enc.conv0");
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, T, nxt, nxt.H, B, false)))) return rc;
         hist.push_back(hist_of_src(nxt, T));
@@ -788,7 +780,7 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         Buf hid, nxt;
         if ((rc = alloc_buf(m, B, ch / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, ch, ratio, T, &nxt, s0))) return rc;
-        hid.elu = nxt.elu = hoist;               // read only by the block's second conv / the strided conv, both behind an ELU
+        hid.elu = nxt.elu = true;               // read only by the block's second conv / the strided conv, both behind an ELU
         prog.site("enc.res" + std::to_string(i));
         const ConvGemmArgs a1 = conv_args(m->enc_convs[ci++], cur, 0, T, hid, 0, B, true);
         const ConvW& w2 = m->enc_convs[ci++];
@@ -802,8 +794,8 @@ int build_encoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? c.residual_kernel_size - 1 : c.last_kernel_size - 1;
         Buf nx2;
         if ((rc = alloc_buf(m, B, 2 * ch, Hn, Tn, &nx2, s0))) return rc;
-        if (hoist && i + 1 < c.n_ratios) { if ((rc = alloc_twin(m, B, &nx2, s0))) return rc; }   // the next resblock's input
-        else nx2.elu = hoist;                                                                     // read by the final conv only
+        if (i + 1 < c.n_ratios) { if ((rc = alloc_twin(m, B, &nx2, s0))) return rc; }   // the next resblock's input
+        else nx2.elu = true;                                                                     // read by the final conv only
         prog.site("enc.down" + std::to_string(i));
         if ((rc = add_conv(m, prog, conv_args(m->enc_convs[ci++], cur, 0, Tn, nx2, nx2.H, B, true)))) return rc;
         hist.push_back(hist_of_src(nx2, Tn));
@@ -908,16 +900,15 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
     size_t ci = 0;
     int mult = 1 << c.n_ratios;
     Buf cur;
-    const bool hoist = !getenv("MMI_NO_ELU_HOIST");       // see build_encoder
     float* conv0_bp = nullptr;                            // dec.conv0's output in the packed operand order of dec.convtr0's GEMM
     {   // conv0: dimension -> mult*n_filters (no activation before it); consumer = conv-transpose GEMM (no history)
         if ((rc = alloc_buf(m, B, mult * c.n_filters, 0, T, &cur, s0))) return rc;
-        cur.elu = hoist;
+        cur.elu = true;
         prog.site("dec.conv0");
         ConvGemmArgs a0 = conv_args(m->dec_convs[ci++], din, 0, T, cur, 0, B, false);
         // its (ELU'd) output is read by the first transposed-conv GEMM only: stored as that GEMM's packed operand as well
         const ConvW& wtr0 = m->dec_convs[ci];
-        if (hoist && B * T <= 128 && wtr0.Q * 8 == mult * c.n_filters && !getenv("MMI_MIMI_PACK_LAUNCHES")) {
+        if (B * T <= 128 && wtr0.Q * 8 == mult * c.n_filters && !getenv("MMI_MIMI_PACK_LAUNCHES")) {
             MMI_HIP_CHECK(m->st.alloc(&conv0_bp, (size_t)mmi_cdiv(B * T, 32) * wtr0.Q * 256));
             MMI_HIP_CHECK(hipMemsetAsync(conv0_bp, 0, (size_t)mmi_cdiv(B * T, 32) * wtr0.Q * 256 * sizeof(float), s0));
             a0.outp = conv0_bp; a0.outQ = wtr0.Q;
@@ -932,7 +923,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         if ((rc = alloc_buf(m, B, cout * K, 0, T, &tmp, s0))) return rc;
         const int Tn = T * ratio;
         if ((rc = alloc_buf(m, B, cout, c.residual_kernel_size - 1, Tn, &up, s0))) return rc;
-        if (hoist && (rc = alloc_twin(m, B, &up, s0))) return rc;           // resblock input: raw for the residual, ELU'd for its conv
+        if ((rc = alloc_twin(m, B, &up, s0))) return rc;           // resblock input: raw for the residual, ELU'd for its conv
         const ConvW& wtr = m->dec_convs[ci++];
         prog.site("dec.convtr" + std::to_string(i));
         {
@@ -963,7 +954,7 @@ int build_decoder(mmi_mimi* m, int B, hipStream_t s0) {
         const int Hn = (i + 1 < c.n_ratios) ? 0 : c.last_kernel_size - 1;
         if ((rc = alloc_buf(m, B, cout / c.compress, 0, T, &hid, s0))) return rc;
         if ((rc = alloc_buf(m, B, cout, Hn, T, &nxt, s0))) return rc;
-        hid.elu = nxt.elu = hoist;               // read only behind an ELU: by the block's second conv / the next layer
+        hid.elu = nxt.elu = true;               // read only behind an ELU: by the block's second conv / the next layer
         prog.site("dec.res" + std::to_string(i));
         const ConvGemmArgs a1 = conv_args(m->dec_convs[ci++], up, 0, T, hid, 0, B, true);
         const ConvW& w2 = m->dec_convs[ci++];

@@ -108,18 +108,6 @@ __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_
 
 __device__ __forceinline__ float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }  // IEEE, matches torch.rsqrt closely
 __device__ __forceinline__ unsigned mmi_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
-// Small cross-workgroup hand-offs inside one launch (the split-K finish, lm_kernels.h): the DATA goes through agent-scope
-// relaxed atomics - stores written through, loads served past the non-coherent cache levels - ordered against the arrival
-// counter by a workgroup-scope release (a wait for the wave's own stores) and the workgroup barrier.  A device-scope fence
-// (__threadfence) would write back and invalidate the whole L2 of the XCD per workgroup: measured 50 us per GEMM launch.
-__device__ __forceinline__ void mmi_st_agent(float* p, f32x2 v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x2 mmi_ld_agent(const float* p) {
-    return __builtin_bit_cast(f32x2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ unsigned mmi_arrive_agent(unsigned* ctr) { return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void mmi_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 
 // Cross-stream hand-off flags (duplex.hip): a monotonic counter in device memory, published with release semantics by a
 // one-thread kernel at the end of a producer stream's work and polled by a one-wave kernel at the head of the consumer's.

@@ -256,11 +256,7 @@ inline f32x4 mmi_mfma_fp8_16x16x32(u32x2 a, u32x2 b, f32x4 c) {
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
 inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }
-inline unsigned mmi_atomic_add(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-inline void mmi_st_agent(float* p, f32x2 v) { p[0] = v[0]; p[1] = v[1]; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-inline f32x2 mmi_ld_agent(const float* p) { __atomic_thread_fence(__ATOMIC_SEQ_CST); f32x2 v; v[0] = p[0]; v[1] = p[1]; return v; }
-inline unsigned mmi_arrive_agent(unsigned* ctr) { return __atomic_fetch_add(ctr, 1u, __ATOMIC_SEQ_CST); }
-inline void mmi_stores_done() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline unsigned mmi_atomic_add(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // hand-off flags (duplex.hip).  The simulator runs every launch synchronously in host order, so a wait whose producer has not
 // been launched yet can never be satisfied: abort loudly instead of spinning forever.

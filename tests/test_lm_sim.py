@@ -86,14 +86,6 @@ def test_depformer_attention_launch_at_micro_step_0_is_optional(sim_lib, monkeyp
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=95, B=3, S=2)
 
 
-def test_two_n_tiles_per_workgroup(sim_lib, monkeypatch):
-    """Two n-tiles per workgroup (`MMI_GEMM_NTW=2`, the variant the 64-session experiments use), forced onto the tiny shapes,
-    with one and two batch tiles."""
-    monkeypatch.setenv("MMI_GEMM_NTW", "2")
-    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=71, B=18, S=2)
-    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=72, B=34, S=2)
-
-
 @pytest.mark.parametrize("B,grid,mode", [(18, 8, "1"), (34, 8, "1"), (20, 64, "1"), (18, 8, "2"), (34, 8, "2"), (18, 5, "2"), (18, 7, "1")])
 def test_gemm_with_activations_resident_in_lds(sim_lib, monkeypatch, B, grid, mode):
     """k_gemm_xlds (one workgroup walking several n-tiles with the activation chunks staged in LDS) on the tiny
@@ -107,49 +99,6 @@ def test_gemm_with_activations_resident_in_lds(sim_lib, monkeypatch, B, grid, mo
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=140 + B, B=B, S=3, stats=st)
     # per step: 2 temporal layers x (in_proj + gated linear_in) + the text head + 8 audio heads take the kernel
     assert st["xlds_launches"] >= 3 * (2 * 2 + 1)
-
-
-@pytest.mark.parametrize("B,ksplit", [(18, "2"), (34, "2"), (20, "3"), (18, None)])
-def test_rmsnorm_folded_across_gemm_pairs(sim_lib, monkeypatch, B, ksplit):
-    """The temporal layer without its two norm launches (GemmArgs::ss): the producer GEMM (out_proj / linear_out) finishes the
-    residual stream itself - the LAST split-K workgroup of each n-tile group to arrive sums the partials, or, un-split, the
-    residual epilogue - and leaves the row statistics; the consumer (in_proj / linear_in on k_gemm_xlds, alpha folded into its
-    weight columns) applies rsqrt(eps + mean(x^2)) per session in its epilogue.  Against the oracle, one and two batch tiles,
-    split-K 2 / 3 forced onto the tiny shapes."""
-    monkeypatch.setenv("MMI_NORM_FOLD", "1")     # opt-in: off by default (no gain measured, further from the reference; DESIGN.md 10c)
-    monkeypatch.setenv("MMI_GEMM_LDS", "2")
-    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "8")
-    if ksplit:
-        monkeypatch.setenv("MMI_GEMM_KSPLIT", ksplit)
-    from moshi_amd.config import tiny_lm_config as cfgf
-    from dataclasses import replace
-    st = {}
-    # the fold moves a bf16 rounding point (weight columns carry alpha, rows are not rounded after the norm): on the simulator,
-    # where the un-folded engine reproduces the oracle's roundings, it sits at up to 3.6 % max / 1.2 % mean from it
-    monkeypatch.setattr(lm_cases, "LOGIT_MAX_REL", 0.06)
-    monkeypatch.setattr(lm_cases, "LOGIT_MEAN_REL", 0.018)
-    lm_cases.oracle_vs_engine("cpu", sim_lib, replace(cfgf(), num_layers=3), seed=170 + B, B=B, S=3, stats=st)
-    assert st["launch_sites"].get("L.norm1", 0) == 1 and st["launch_sites"].get("L.norm2", 0) == 0, st["launch_sites"]
-    assert st["launch_sites"]["L.in_proj"] == 3 and st["launch_sites"]["L.ffn_in"] == 3
-
-
-@pytest.mark.parametrize("B", [18, 34])
-def test_gated_linear_in_shared_out_in_row_octets(sim_lib, monkeypatch, B):
-    """MMI_GATE_OCT=1 (opt-in, measured slower on hardware): gate and value rows interleaved per row octet, the gated GEMM's
-    tiles shared out in octets on k_gemm_xlds (up to 4 tiles per workgroup), 4-feature epilogue tasks."""
-    monkeypatch.setenv("MMI_GATE_OCT", "1")
-    monkeypatch.setenv("MMI_GEMM_LDS", "2")
-    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "7")
-    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=190 + B, B=B, S=2)
-
-
-def test_norm_launches_are_the_default(sim_lib, monkeypatch):
-    """Without MMI_NORM_FOLD=1 the weights stay plain and the k_resid_rmsnorm launches stay (the reference's rounding points)."""
-    monkeypatch.setenv("MMI_GEMM_LDS", "2")
-    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "8")
-    st = {}
-    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=181, B=18, S=2, stats=st)
-    assert st["launch_sites"]["L.norm1"] == 2 and st["launch_sites"]["L.norm2"] == 2
 
 
 @pytest.mark.parametrize("B,quantize", [(18, True), (34, True), (18, "fp8"), (34, "fp8")])
