@@ -292,8 +292,9 @@ int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks_or_null);
 /* Inside a hook: copy one of the step's tensors out (write = 0) or back in (write = 1), stream-ordered on `stream`:
  *   which 0  text logits   bf16 [batch, text_card_out]   (the model dtype, as the reference's hook sees them)
  *   which 1  text token    i64  [batch]
- *   which 2  audio tokens  i64  [batch, dep_q] */
-int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, mmi_stream stream);
+ *   which 2  audio tokens  i64  [batch, dep_q]
+ * nbytes = the size of `buf`; anything but the tensor's size is refused (MMI_ERR_SHAPE). */
+int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, int64_t nbytes, mmi_stream stream);
 
 /* Teacher forcing for the NEXT step only: tokens i64 [batch, 1 + dep_q] (text, then the dep_q audio codebooks);
  * entries >= 0 replace the sampled token at that site (the logits taps are still produced), entries < 0 keep

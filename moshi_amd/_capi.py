@@ -129,7 +129,7 @@ SIGNATURES = {
     "mmi_lm_force_next_tokens": (C.c_int, [_P, _P, _P]),
     "mmi_lm_set_phase_callback": (C.c_int, [_P, _P, _P]),
     "mmi_lm_set_hooks": (C.c_int, [_P, C.POINTER(LMHooks)]),
-    "mmi_lm_hook_io": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "mmi_lm_hook_io": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "mmi_mimi_get_cfg": (C.c_int, [_P, C.POINTER(MimiCfg)]),
     "mmi_lm_get_cfg": (C.c_int, [_P, C.POINTER(LMCfg)]),
     "mmi_batcher_create": (C.c_int, [_P, _P, C.POINTER(BatcherCfg), C.POINTER(_P)]),

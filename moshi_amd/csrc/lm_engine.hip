@@ -1230,13 +1230,16 @@ extern "C" int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks) {
     return MMI_OK;
 }
 
-extern "C" int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, mmi_stream stream) {
+extern "C" int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, int64_t nbytes, mmi_stream stream) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !buf) return mmi_fail(MMI_ERR_INVALID, "null argument");
     if (!lm->streaming || !lm->in_hook) return mmi_fail(MMI_ERR_STATE, "mmi_lm_hook_io is only valid inside a step hook");
     hipStream_t s = (hipStream_t)stream;
     const mmi_lm_cfg& c = lm->cfg;
     const int G = lm->gen_batch;
+    const int64_t want = which == 0 ? (int64_t)G * c.text_card_out * 2 : which == 1 ? (int64_t)G * 8 : which == 2 ? (int64_t)G * c.dep_q * 8 : -1;
+    if (want >= 0 && nbytes != want)
+        return mmi_fail(MMI_ERR_SHAPE, "mmi_lm_hook_io: the buffer holds " + std::to_string(nbytes) + " bytes, the tensor " + std::to_string(want));
     if (which == 0) {            // (guided) text logits, rows [0, G) of the model's logits buffer
         const size_t n = (size_t)G * c.text_card_out * sizeof(uint16_t);
         if (write) MMI_HIP_CHECK(hipMemcpyAsync(lm->text_logits, buf, n, hipMemcpyDeviceToDevice, s));

@@ -339,9 +339,9 @@ class LMGen:
             def cb(_user):
                 try:
                     t = make()
-                    lib.check(lib.mmi_lm_hook_io(h, which, 0, t.data_ptr(), self._stream()))
+                    lib.check(lib.mmi_lm_hook_io(h, which, 0, t.data_ptr(), t.numel() * t.element_size(), self._stream()))
                     hook(view(t))
-                    lib.check(lib.mmi_lm_hook_io(h, which, 1, t.data_ptr(), self._stream()))
+                    lib.check(lib.mmi_lm_hook_io(h, which, 1, t.data_ptr(), t.numel() * t.element_size(), self._stream()))
                     return 0
                 except BaseException as e:                  # never unwind through the C frames: report after the step
                     self._hook_error = e
