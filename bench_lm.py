@@ -135,16 +135,18 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
     out["mfma"] = {"achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak,
                    "instruction": "v_mfma_f32_32x32x16_fp8_fp8" if quant == "fp8" else "v_mfma_f32_32x32x16_bf16",
                    "note": "decode GEMM at B sessions: arithmetic intensity ~B flop/byte, far below the ~310 flop/byte ridge"}
-    # HBM bytes per launch from the PMC counters: rocprofv3 --pmc cannot run inside the benchmark (and crashes on this
-    # process), so the figure is the committed measurement of the same kernel, shape and batch.
+    # HBM bytes per launch from the PMC counters: a counter pass cannot run inside the timed benchmark (it serialises every
+    # dispatch), so the figure is the committed measurement of the same kernel, shape and batch - since round 3 collected on
+    # THIS library inside the LM step (scripts/gpu_pmc.sh: eager launches under rocprofv3 --pmc), before that on a standalone launcher.
     pmc = Path(__file__).resolve().parent / "profiles" / "pmc_dominant_kernel.json"
     if pmc.exists() and lm_gen._batch == 32:
         doc = json.loads(pmc.read_text())
         for rec in doc.get("kernels", [doc]):
             if rec["kernel"] in kname and rec["algorithmic_bytes_per_launch"] == nbytes.value:
                 out["traffic"] = rec["traffic_bytes_per_launch"]
+                where = "inside the LM step of this library (scripts/gpu_pmc.sh)" if rec.get("measured_in_step") else "standalone launcher"
                 out["traffic_source"] = ("profiles/pmc_dominant_kernel.json: a COMMITTED measurement of this kernel, shape and batch (rocprofv3 --pmc "
-                                         "FETCH_SIZE x2 + WRITE_SIZE, separate passes, standalone launcher) - not collected in this run")
+                                         f"FETCH_SIZE x2 + WRITE_SIZE, separate passes, {where}; " + ", ".join(rec.get("sources", [])) + ") - not collected in this run")
                 out["traffic_measured_in_this_run"] = False
                 break
     return out
