@@ -31,8 +31,9 @@ def main():
         vals = c.execute("select kernel_name, counter_name, value, duration from counters_collection where kernel_name like ?",
                          (f"%{sub}%",)).fetchall()
         bins = {}
+        by_dur = "--by-duration" in sys.argv       # cycle / request counters: group by the dispatch's duration (bins of 4 us) instead
         for name, ctr, v, dur in vals:
-            key = (name.split("(")[0].replace("void ", ""), ctr, int(v // 4096))
+            key = (name.split("(")[0].replace("void ", ""), ctr, int(dur // 4000) if by_dur else int(v // 4096))
             b = bins.setdefault(key, [0, 0.0, 0.0])
             b[0] += 1; b[1] += v; b[2] += dur
         print("# clusters: kernel,counter,dispatches,avg_KiB,bytes_corrected,avg_duration_us_under_pmc")
