@@ -45,7 +45,8 @@ def sim_lib():
     sys.path.insert(0, str(ROOT / "tests" / "hipsim"))
     import build_sim
     from moshi_amd import _capi
-    return _capi.load(build_sim.build())
+    # MMI_SIM_LIB: another build of the simulator library (the AddressSanitizer build: tests/hipsim/build_sim.py build_asan)
+    return _capi.load(os.environ.get("MMI_SIM_LIB") or build_sim.build())
 
 
 @pytest.fixture(scope="session")

@@ -70,6 +70,38 @@ def _build_locked(force: bool, verbose: bool) -> Path:
     return LIB
 
 
+def build_asan(out_dir: Path) -> Path:
+    """An AddressSanitizer build of the simulator library (every hipMalloc is its own heap block there, so a kernel reading or
+    writing past a buffer is reported with the kernel's source line).  Run the simulator suites on it with
+
+        python tests/hipsim/build_sim.py --asan /tmp/asan
+        LD_PRELOAD=$(dirname $(dirname /opt/rocm/lib/llvm/bin))/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so \
+        ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MMI_SIM_LIB=/tmp/asan/libmoshi_sim_asan.so \
+        python -m pytest tests/test_mimi_sim.py tests/test_lm_sim.py tests/test_batcher_sim.py tests/test_duplex_sim.py -m "not gpu"
+
+    (round 3: 81 passed, no report; the one failure is test_io_threads_push_and_pop..., whose 60 s deadline the 5x slower
+    instrumented build misses)."""
+    out_dir.mkdir(parents=True, exist_ok=True)
+    flags = [_cxx(), "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value", "-Wno-psabi",
+             "-fsanitize=address", "-fno-omit-frame-pointer", f"-I{HERE}", f"-I{CSRC}"]
+    jobs, objs = [], []
+    for name in SOURCES:
+        obj = out_dir / (Path(name).stem + ".asan.o")
+        jobs.append(subprocess.Popen(flags + ["-x", "c++", "-c", str(CSRC / name), "-o", str(obj)]))
+        objs.append(obj)
+    obj = out_dir / "hipsim.asan.o"
+    jobs.append(subprocess.Popen(flags + ["-c", str(HERE / "hipsim.cpp"), "-o", str(obj)]))
+    objs.append(obj)
+    if any(p.wait() != 0 for p in jobs):
+        raise RuntimeError("asan sim build failed")
+    lib = out_dir / "libmoshi_sim_asan.so"
+    subprocess.check_call([_cxx(), "-shared", "-fPIC", "-pthread", "-fsanitize=address", "-shared-libasan", "-o", str(lib)] + [str(o) for o in objs])
+    return lib
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_asan(Path(sys.argv[sys.argv.index("--asan") + 1])))
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
