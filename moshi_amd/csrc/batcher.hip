@@ -48,19 +48,21 @@ struct Staging {
 
 size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// up / down null: only the block sizes are wanted (no pointer is formed from a null base)
 void carve(Staging* st, unsigned char* up, unsigned char* down, int B, int F, int NTOK) {
+    auto at = [](unsigned char* base, size_t o) -> unsigned char* { return base ? base + o : nullptr; };
     size_t o = 0;
     st->up = up;
-    st->pcm = reinterpret_cast<float*>(up + o); o += align_up((size_t)B * F * sizeof(float));
-    st->exec = up + o; o += align_up(B);
-    st->first = up + o; o += align_up(B);
-    st->reset = up + o; o += align_up(B);
+    st->pcm = reinterpret_cast<float*>(at(up, o)); o += align_up((size_t)B * F * sizeof(float));
+    st->exec = at(up, o); o += align_up(B);
+    st->first = at(up, o); o += align_up(B);
+    st->reset = at(up, o); o += align_up(B);
     st->h2d_bytes = o;
     o = 0;
     st->down = down;
-    st->tokens = reinterpret_cast<int64_t*>(down + o); o += align_up((size_t)B * NTOK * sizeof(int64_t));
-    st->pcm_out = reinterpret_cast<float*>(down + o); o += align_up((size_t)B * F * sizeof(float));
-    st->played = down + o; o += align_up(B);
+    st->tokens = reinterpret_cast<int64_t*>(at(down, o)); o += align_up((size_t)B * NTOK * sizeof(int64_t));
+    st->pcm_out = reinterpret_cast<float*>(at(down, o)); o += align_up((size_t)B * F * sizeof(float));
+    st->played = at(down, o); o += align_up(B);
     st->d2h_bytes = o;
 }
 

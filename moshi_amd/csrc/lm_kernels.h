@@ -104,8 +104,8 @@ __global__ void k_pack_w_i8(const int8_t* __restrict__ W, int8_t* __restrict__ P
 __device__ __forceinline__ void mmi_i8x16_to_bf16(u32x4 q, u32x4& lo, u32x4& hi) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const int w = (int)q[d];
-        const float f0 = (float)((w << 24) >> 24), f1 = (float)((w << 16) >> 24), f2 = (float)((w << 8) >> 24), f3 = (float)(w >> 24);
+        const uint32_t w = q[d];          // byte k sign-extended: shift it to the top as unsigned, arithmetic shift back down
+        const float f0 = (float)((int)(w << 24) >> 24), f1 = (float)((int)(w << 16) >> 24), f2 = (float)((int)(w << 8) >> 24), f3 = (float)((int)w >> 24);
         const uint32_t p0 = mmi_pack_bf16x2(f0, f1), p1 = mmi_pack_bf16x2(f2, f3);
         if (d < 2) { lo[2 * d] = p0; lo[2 * d + 1] = p1; }
         else { hi[2 * (d - 2)] = p0; hi[2 * (d - 2) + 1] = p1; }
