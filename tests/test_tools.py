@@ -52,3 +52,30 @@ def test_sites_take_bytes_from_the_launch_list_and_match_per_stream(tmp_path):
     rows = {ln.split(",")[1]: ln.split(",") for ln in r.stdout.splitlines() if ln.startswith("lm,")}
     assert abs(float(rows["L.ffn_in"][4]) - 10.0) < 1e-6 and abs(float(rows["L.ffn_in"][5]) - 1.0) < 1e-6
     assert abs(float(rows["L.ffn_in"][6]) - 100.0) < 1e-3
+
+
+def test_pmc_summary_clusters_a_kernels_dispatches_by_shape(tmp_path):
+    """scripts/rocpd_pmc.py --clusters: one kernel name serves several GEMM shapes; its dispatches are grouped by counter value
+    (FETCH_SIZE, KiB, doubled on gfx950) - or, for cycle counters, by duration - one line per shape."""
+    import sqlite3
+    db = tmp_path / "pmc.db"
+    c = sqlite3.connect(db)
+    c.execute("create table counters_collection (kernel_name text, counter_name text, value real, duration real)")
+    name = "void k_gemm_xlds<1, 64, 3, true, 0>(GemmArgs)"
+    for i in range(32):
+        c.execute("insert into counters_collection values (?,?,?,?)", (name, "FETCH_SIZE", 93159.0 + i % 3, 35000.0))
+        c.execute("insert into counters_collection values (?,?,?,?)", (name, "FETCH_SIZE", 55626.0 + i % 3, 23000.0))
+    c.execute("insert into counters_collection values (?,?,?,?)", ("k_other(int)", "FETCH_SIZE", 10.0, 5000.0))
+    c.commit()
+    c.close()
+    script = str(ROOT / "scripts" / "rocpd_pmc.py")
+    r = subprocess.run([sys.executable, script, str(db), "--header", "synthetic", "--clusters", "k_gemm_xlds"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "# synthetic"
+    rows = [l for l in lines[lines.index([l for l in lines if l.startswith("# clusters")][0]) + 1:] if l]
+    assert len(rows) == 2 and all(row.split(",")[-4] == "32" for row in rows), rows
+    big = [row for row in rows if ",93160." in row or ",93159." in row][0]
+    assert abs(float(big.split(",")[-2]) - 93160.0 * 1024 * 2) < 4096          # bytes_corrected = KiB x 1024 x 2
+    r = subprocess.run([sys.executable, script, str(db), "--clusters", "k_gemm_xlds", "--by-duration"], capture_output=True, text=True)
+    assert r.returncode == 0 and sum(l.startswith('"k_gemm_xlds') for l in r.stdout.splitlines()) == 2
