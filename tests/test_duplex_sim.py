@@ -20,3 +20,42 @@ def test_duplex_refuses_models_that_are_not_streaming(sim_lib):
     mimi, lm, _, _ = tiny_pair("cpu", sim_lib, 2)
     with pytest.raises(RuntimeError):
         DuplexStream(mimi, LMGen(lm))
+
+
+def test_device_clock_stamps_follow_the_pipeline_order(sim_lib):
+    """mmi_duplex_get_stamps (diagnostics): with the timeline on, every hand-off point of the last four frames carries a stamp of
+    one clock, and they come in the order the pipeline's dependencies demand - input before encode, encode before the LM's
+    step, the depth-transformer phase inside the step, decode after it - while the tokens and PCM stay what they are without
+    the stamping kernels."""
+    import numpy as np
+    import torch
+    from moshi_amd.duplex import DuplexStream
+    from moshi_amd.lm import LMGen
+    from tests.batcher_cases import tiny_pair
+    B = 2
+    mimi, lm, mcfg, lcfg = tiny_pair("cpu", sim_lib, B)
+    rng = np.random.default_rng(5)
+    frames = [torch.from_numpy((0.1 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32)) for _ in range(6)]
+
+    def run(stamped):
+        gen = LMGen(lm, use_sampling=False)
+        with mimi.streaming(B), gen.streaming(B):
+            dup = DuplexStream(mimi, gen)
+            if stamped:
+                dup.timeline(True)
+            outs = [dup.step(x) for x in frames]
+            dup.join()
+            st = dup.stamps() if stamped else None
+            return [None if o is None or o[0] is None else (o[0].numpy().copy(), o[1].numpy().copy()) for o in outs], st
+    plain, _ = run(False)
+    stamped, st = run(True)
+    for a, b in zip(plain, stamped):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert sorted(st) == [2, 3, 4, 5]
+    for f, s in st.items():
+        for before, after in (("in", "enc0"), ("enc0", "enc1"), ("enc1", "wait1"), ("wait0", "wait1"), ("wait1", "lm0"), ("lm0", "phase"),
+                              ("phase", "lm1"), ("lm1", "dec0"), ("dec0", "dec1")):
+            assert s[before] < s[after], (f, before, after, s)
+    assert st[4]["lm1"] < st[5]["lm0"] and st[4]["enc1"] < st[5]["enc0"]       # stream order across frames
