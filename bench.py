@@ -410,7 +410,7 @@ def main():
             ach = step_bytes / (ms * 1e-3) / 1e9
             out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "parts": parts, "achieved": ach, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS, "ms_per_step": ms}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the barrier)
             cpu_sd = {k: v.cpu() for k, v in msd.items()}
             base = cpu_baseline_mimi(mcfg, cpu_sd)
             if workload != "mimi":
