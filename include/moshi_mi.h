@@ -295,6 +295,7 @@ int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks_or_null);
  *   which 2  audio tokens  i64  [batch, dep_q]
  * nbytes = the size of `buf`; anything but the tensor's size is refused (MMI_ERR_SHAPE). */
 int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, int64_t nbytes, mmi_stream stream);
+int32_t mmi_lm_has_hooks(const mmi_lm* lm);         /* 1 while any of the three hooks is set */
 
 /* Teacher forcing for the NEXT step only: tokens i64 [batch, 1 + dep_q] (text, then the dep_q audio codebooks);
  * entries >= 0 replace the sampled token at that site (the logits taps are still produced), entries < 0 keep
@@ -340,37 +341,50 @@ int mmi_lm_get_cfg(const mmi_lm* lm, mmi_lm_cfg* out);
  * pipeline owns three HIP streams (encoder, LM, decoder) and the events between them, so that - when frames are submitted
  * back to back (offline inference, several session groups per GPU, a loaded server) - encode(t+1) and decode(t-1) run in the
  * shadow of LMGen.step(t), whose depth-transformer phase leaves most CUs idle.  Results are bit-identical to the serial
- * schedule (same kernels, same per-stream order).  Nothing synchronises the host.
+ * schedule (same kernels, same per-stream order).  The DEVICE is never synchronised, but the HOST is: mmi_duplex_submit(t)
+ * blocks the calling thread (hipEventSynchronize) until LMGen.step(t-2) has completed (flow control: two steps in flight at
+ * most) and until LMGen.step(t-1) has reached its depth-transformer phase (the gate behind which the codec work of frame t is
+ * enqueued, csrc/duplex.hip) - in steady state it returns about one LM temporal phase after it was called.
  *
  *   mmi_duplex_submit   frame t: pcm_in f32 [batch, 1, frame_size] -> pcm_out f32 [batch, 1, frame_size] (written when the
  *                       frame's decode ran; untouched while *valid == 0, i.e. where LMGen.step returns None) and, optionally,
  *                       tokens_out i64 [batch, 1 + dep_q, 1] (LMGen.step's output, -2 rows included).  Work submitted on
  *                       `caller` before the call is ordered before the frame (inputs, set_exec_mask / reset_streaming issued
  *                       on the handles with that stream after a mmi_duplex_join).  At most two frames are in flight: the call
- *                       blocks the host until frame t-2 has completed.  pcm_in must stay untouched until two further submits
- *                       (or a join) and pcm_out / tokens_out unread until a mmi_duplex_join on the consuming stream.
+ *                       blocks the host until frame t-2 has completed.  pcm_in is copied into the pipeline's own input ring in
+ *                       `caller`'s stream order: the caller may refill it as soon as the call returns (as after
+ *                       MimiModel.encode).  pcm_out / tokens_out stay unread until a mmi_duplex_join on the consuming stream.
+ *                       `batch` must equal the streaming batch (MMI_ERR_SHAPE otherwise, like mmi_lm_step).
+ *                       MMI_ERR_UNSUPPORTED while the LM has per-step hooks installed (mmi_lm_set_hooks): the hooks work on the
+ *                       caller's stream, the pipeline steps the LM on its own - a hooked LMGen goes through mmi_lm_step.
  *   mmi_duplex_join     makes `caller` wait (device side) for every frame submitted so far.
  * Both handles must be streaming with the same batch before mmi_duplex_create and must not be driven through their own
- * step entry points between a submit and the next join. */
+ * step entry points between a submit and the next join.  A call that fails half-way (a launch error inside a frame) leaves the
+ * three stream orders inconsistent: the pipeline is dead from then on - submit / join / flush return MMI_ERR_STATE, waiters are
+ * released - and must be destroyed. */
 typedef struct mmi_duplex mmi_duplex;
 int mmi_duplex_create(mmi_mimi* mimi, mmi_lm* lm, mmi_duplex** out);
 void mmi_duplex_destroy(mmi_duplex* d);
-int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out_or_null, int32_t* valid,
-                      mmi_stream caller);
+int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out_or_null, int32_t batch,
+                      int32_t* valid, mmi_stream caller);
+int32_t mmi_duplex_batch(const mmi_duplex* d);      /* the streaming batch the pipeline was created with */
 int mmi_duplex_join(mmi_duplex* d, mmi_stream caller);
 /* The host-side form: blocks the calling thread until every submitted frame has completed (its outputs are then readable from any
  * stream).  Unlike mmi_duplex_join it leaves no waiter on the device while the frames run. */
 int mmi_duplex_flush(mmi_duplex* d);
 /* Diagnostics: with the timeline on, every submit records timestamps around the frame's three phases on their streams;
- * mmi_duplex_get_timeline synchronises the pipeline and returns, for the LAST submitted frame whose decode was enqueued, ms since
- * the submit reached the caller's stream: {encode begin, encode end, LM begin, -, LM end, decode begin, decode end} (host f32[7]);
- * entries of phases that did not run are -1. */
+ * mmi_duplex_get_timeline synchronises the pipeline and returns ms since the LAST submit reached the caller's stream:
+ * {encode begin, encode end, LM begin, -, LM end, decode begin, decode end} (host f32[7]); entries of phases that did not run
+ * are -1.  One set of events serves every frame, so the seven entries belong to ONE frame only when a mmi_duplex_flush follows
+ * every submit (one frame alone in the pipeline: what bench.py's p50 / p95 measure); with frames in flight the decode entries are
+ * those of frame t-2.  Per-frame figures in steady state: mmi_duplex_get_stamps. */
 int mmi_duplex_set_timeline(mmi_duplex* d, int32_t on);
 int mmi_duplex_get_timeline(mmi_duplex* d, float* ms7);
 /* Diagnostics, finer: with the timeline on the pipeline also stamps the device's constant-rate clock at its hand-off points
  * (one-thread kernels on the three streams).  Returns ms40[4][10] - frames t & 3 of the last four submits; per frame: input
  * published, encode begin / end, the LM's wait for the encoder begin / end, LM begin, depth-transformer phase, LM end, decode
- * begin / end - in ms since the oldest stamp held (-1: not stamped), and the number of the last submitted frame. */
+ * begin / end - in ms since the oldest stamp held (-1: not stamped; the clock's rate is hipDeviceAttributeWallClockRate), and the
+ * number of the last submitted frame. */
 int mmi_duplex_get_stamps(mmi_duplex* d, double* ms40, int64_t* last_frame);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -101,7 +101,9 @@ SIGNATURES = {
     "mmi_lm_streaming_batch": (C.c_int, [_P]),
     "mmi_duplex_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "mmi_duplex_destroy": (None, [_P]),
-    "mmi_duplex_submit": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    "mmi_duplex_submit": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "mmi_duplex_batch": (C.c_int32, [_P]),
+    "mmi_lm_has_hooks": (C.c_int32, [_P]),
     "mmi_duplex_join": (C.c_int, [_P, _P]),
     "mmi_duplex_flush": (C.c_int, [_P]),
     "mmi_duplex_set_timeline": (C.c_int, [_P, C.c_int32]),
@@ -180,6 +182,8 @@ class Lib:
             raise KeyError(msg)
         if rc == MMI_ERR_BUSY:
             raise BufferError(msg)
+        if rc == MMI_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)          # a RuntimeError, like every other engine failure
         raise RuntimeError(msg)
 
 

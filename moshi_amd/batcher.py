@@ -21,6 +21,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _capi
+from .errors import UnknownChannel
 from .lm import LMModel
 from .mimi import MimiModel
 
@@ -107,10 +108,15 @@ class SessionBatcher:
         self._lib.check(self._lib.mmi_batcher_push_pcm(self._handle, int(channel), a.ctypes.data, a.size))
 
     def pop(self, channel: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """The channel's next output frame, or None.  A channel that is not (or no longer) open raises `UnknownChannel` - a
+        ValueError like every MMI_ERR_INVALID, but one a model loop can tell apart from a real argument error."""
         pcm = np.empty(self.frame_size, dtype=np.float32)
         tok = np.empty(self.n_tokens, dtype=np.int64)
         got = C.c_int32(0)
-        self._lib.check(self._lib.mmi_batcher_pop(self._handle, int(channel), pcm.ctypes.data, tok.ctypes.data, C.byref(got)))
+        rc = self._lib.mmi_batcher_pop(self._handle, int(channel), pcm.ctypes.data, tok.ctypes.data, C.byref(got))
+        if rc == _capi.MMI_ERR_INVALID and "unknown channel" in self._lib.last_error():
+            raise UnknownChannel(f"channel {channel} is not open")
+        self._lib.check(rc)
         return (pcm, tok) if got.value else None
 
     # ---- model loop ----------------------------------------------------------------------------------

@@ -73,7 +73,16 @@ struct mmi_duplex {
     Pending pend[3];                               // a frame's decode, enqueued two submits later (behind step t+1's phase) or by join / flush
     int64_t* codes[2] = {nullptr, nullptr};        // [B][K][1]         encoder -> LM
     int64_t* tokens[3] = {nullptr, nullptr, nullptr};   // [B][1 + dep_q][1] LM -> decoder
+    // the frame's input is copied (on the caller's stream, ahead of the F_IN publish) into a slot of this ring, so the caller may
+    // refill its own buffer as soon as submit returns - as it may after MimiModel.encode on one stream (compression.py:376-388);
+    // 4 slots: encode(t) has completed before submit(t+2) returns (flow control on step t ... t-2), one spare
+    static constexpr int in_slots = 4;
+    float* pcm_in[4] = {nullptr, nullptr, nullptr, nullptr};
     long frame = 0;
+    // A failure half-way through a submit leaves the three stream orders inconsistent (the encoder state has advanced, a waiter
+    // may be resident, the frame counter has not moved): the handle is dead from then on - every later submit / join / flush
+    // returns MMI_ERR_STATE until destroy - and the flags are released so that no polling wave is left without its producer.
+    bool failed = false;
 };
 
 namespace {
@@ -103,16 +112,28 @@ int stamp(mmi_duplex* d, long t, int which, hipStream_t s) {
 
 int phase_callback(void* user, mmi_stream stream) {
     mmi_duplex* d = (mmi_duplex*)user;
-    stamp(d, d->phase_frame, S_PHASE, (hipStream_t)stream);
+    if (int rc = stamp(d, d->phase_frame, S_PHASE, (hipStream_t)stream)) return rc;
     MMI_HIP_CHECK(hipEventRecord(d->ev_phase[d->phase_frame & 1], (hipStream_t)stream));
     return MMI_OK;
 }
 
-void release(mmi_duplex* d) {
-    if (d->flags) {      // a step that failed half-way may have left a polling wave without its producer: let every waiter through
-        std::vector<long> big((size_t)F_COUNT * 16, (long)1 << 62);
-        hipMemcpy(d->flags, big.data(), big.size() * sizeof(long), hipMemcpyHostToDevice);
+// a step that failed half-way may have left a polling wave without its producer: let every waiter through
+void open_flags(mmi_duplex* d) {
+    if (!d->flags) return;
+    std::vector<long> big((size_t)F_COUNT * 16, (long)1 << 62);
+    hipMemcpy(d->flags, big.data(), big.size() * sizeof(long), hipMemcpyHostToDevice);
+}
+
+int fail_sticky(mmi_duplex* d, int rc) {
+    if (rc != MMI_OK && !d->failed) {
+        d->failed = true;
+        open_flags(d);
     }
+    return rc;
+}
+
+void release(mmi_duplex* d) {
+    open_flags(d);
     for (hipStream_t s : {d->sE, d->sL, d->sD})
         if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
     for (int i = 0; i < 2; ++i) {
@@ -124,6 +145,7 @@ void release(mmi_duplex* d) {
         if (d->ev_dec[i]) hipEventDestroy(d->ev_dec[i]);
         if (d->tokens[i]) hipFree(d->tokens[i]);
     }
+    for (float* p : d->pcm_in) if (p) hipFree(p);
     if (d->flags) hipFree(d->flags);
     if (d->stamps) hipFree(d->stamps);
     for (hipEvent_t e : d->tl) if (e) hipEventDestroy(e);
@@ -172,6 +194,7 @@ int create_impl(mmi_duplex* d) {
         MMI_HIP_CHECK(hipEventCreateWithFlags(&d->ev_dec[i], hipEventDisableTiming));
         MMI_HIP_CHECK(hipMalloc((void**)&d->tokens[i], (size_t)d->B * d->NTOK * sizeof(int64_t)));
     }
+    for (int i = 0; i < d->in_slots; ++i) MMI_HIP_CHECK(hipMalloc((void**)&d->pcm_in[i], (size_t)d->B * d->F * sizeof(float)));
     return MMI_OK;
 }
 
@@ -220,10 +243,8 @@ extern "C" void mmi_duplex_destroy(mmi_duplex* d) {
     if (d) release(d);
 }
 
-extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out, int32_t* valid,
-                                 mmi_stream caller) {
-    MmiDeviceGuard dev_guard_(d ? d->device : -1);
-    if (!d || !pcm_in || !pcm_out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+namespace {
+int submit_impl(mmi_duplex* d, const float* pcm_caller, float* pcm_out, int64_t* tokens_out, int32_t* valid, mmi_stream caller) {
     const long t = d->frame;
     const int p = (int)(t & 1);                            // codes slot, flow-control events
     const int q = (int)(t % d->slots);                     // tokens slot, pending decode, ev_dec
@@ -234,6 +255,10 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     if (t >= 2) MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[p]));
     // host-kept gate: the frame is enqueued once LMGen.step(t-1) has reached its depth-transformer phase
     if (t >= 1) MMI_HIP_CHECK(hipEventSynchronize(d->ev_phase[p ^ 1]));
+    // the frame's input -> the pipeline's own ring, in the caller's stream order (the caller's buffer is free again
+    // when this call returns, as after MimiModel.encode)
+    float* pcm_in = d->pcm_in[t % d->in_slots];
+    MMI_HIP_CHECK(hipMemcpyAsync(pcm_in, pcm_caller, (size_t)d->B * d->F * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)caller));
     // everything the caller enqueued so far (the frame's input; mask / reset calls made after a join) comes first: the encoder
     // waits for it, and the LM and the decoder of this frame wait for the encoder
     if ((rc = publish(d, F_IN, t, (hipStream_t)caller))) return rc;
@@ -273,23 +298,40 @@ extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_
     d->frame += 1;
     return MMI_OK;
 }
+}  // namespace
+
+extern "C" int mmi_duplex_submit(mmi_duplex* d, const float* pcm_in, float* pcm_out, int64_t* tokens_out, int32_t batch, int32_t* valid,
+                                 mmi_stream caller) {
+    MmiDeviceGuard dev_guard_(d ? d->device : -1);
+    if (!d || !pcm_in || !pcm_out) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (d->failed) return mmi_fail(MMI_ERR_STATE, "mmi_duplex: an earlier call failed half-way; destroy the pipeline");
+    if (batch != d->B) return mmi_fail(MMI_ERR_SHAPE, "mmi_duplex_submit: batch != the streaming batch");     // lm.py:679-682
+    // LMGen's per-step hooks run on the stream the caller made current; the pipeline steps the LM on its own stream, so a hooked
+    // step would race it: refused rather than silently wrong (drive a hooked LMGen through its own step entry point)
+    if (mmi_lm_has_hooks(d->lm)) return mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_duplex_submit: the LM has per-step hooks installed");
+    return fail_sticky(d, submit_impl(d, pcm_in, pcm_out, tokens_out, valid, caller));
+}
+
+extern "C" int32_t mmi_duplex_batch(const mmi_duplex* d) { return d ? d->B : 0; }
 
 extern "C" int mmi_duplex_join(mmi_duplex* d, mmi_stream caller) {
     MmiDeviceGuard dev_guard_(d ? d->device : -1);
     if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (d->failed) return mmi_fail(MMI_ERR_STATE, "mmi_duplex: an earlier call failed half-way; destroy the pipeline");
     if (d->frame == 0) return MMI_OK;
     const long t = d->frame - 1;                  // the last frame: everything earlier precedes it on each stream
     const int q = (int)(t % d->slots), q_m1 = (int)((t + d->slots - 1) % d->slots);
     int rc;
-    if ((rc = enqueue_decode(d, q_m1, false)) || (rc = enqueue_decode(d, q, false))) return rc;     // a decode still held back for its gate: now
+    if ((rc = enqueue_decode(d, q_m1, false)) || (rc = enqueue_decode(d, q, false))) return fail_sticky(d, rc);     // a decode still held back for its gate: now
     hipStream_t s = (hipStream_t)caller;
-    if ((rc = await(d, F_DEC, t, s))) return rc;  // decode(t) implies step(t) implies encode(t)
+    if ((rc = await(d, F_DEC, t, s))) return fail_sticky(d, rc);  // decode(t) implies step(t) implies encode(t)
     return MMI_OK;
 }
 
 extern "C" int mmi_duplex_flush(mmi_duplex* d) {
     MmiDeviceGuard dev_guard_(d ? d->device : -1);
     if (!d) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (d->failed) return mmi_fail(MMI_ERR_STATE, "mmi_duplex: an earlier call failed half-way; destroy the pipeline");
     if (d->frame == 0) return MMI_OK;
     const long t = d->frame - 1;
     int rc;
@@ -298,7 +340,7 @@ extern "C" int mmi_duplex_flush(mmi_duplex* d) {
         const int slot = (int)(f % d->slots);
         if (!d->pend[slot].live || d->pend[slot].frame != f) continue;
         MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[f & 1]));
-        if ((rc = enqueue_decode(d, slot, true))) return rc;
+        if ((rc = enqueue_decode(d, slot, true))) return fail_sticky(d, rc);
     }
     MMI_HIP_CHECK(hipEventSynchronize(d->ev_lm[t & 1]));
     MMI_HIP_CHECK(hipEventSynchronize(d->ev_dec[t % d->slots]));     // the decoder's stream order: every earlier decode precedes it
@@ -325,7 +367,8 @@ extern "C" int mmi_duplex_get_stamps(mmi_duplex* d, double* ms40, int64_t* last_
     for (hipStream_t s : {d->sE, d->sL, d->sD}) MMI_HIP_CHECK(hipStreamSynchronize(s));
     long raw[4 * S_COUNT];
     MMI_HIP_CHECK(hipMemcpy(raw, d->stamps, sizeof(raw), hipMemcpyDeviceToHost));
-    const int khz = 100000;                      // wall_clock64: 100 MHz on gfx950
+    int khz = 0;                                 // wall_clock64's rate (100 MHz on gfx950)
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d->device) != hipSuccess || khz <= 0) khz = 100000;
     long t0 = 0;
     for (long v : raw) if (v > 0 && (t0 == 0 || v < t0)) t0 = v;
     for (int i = 0; i < 4 * S_COUNT; ++i) ms40[i] = raw[i] > 0 ? (double)(raw[i] - t0) / (double)khz : -1.0;

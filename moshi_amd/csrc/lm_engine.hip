@@ -1230,6 +1230,10 @@ extern "C" int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks) {
     return MMI_OK;
 }
 
+extern "C" int32_t mmi_lm_has_hooks(const mmi_lm* lm) {
+    return lm && (lm->hooks.on_text_logits || lm->hooks.on_text_token || lm->hooks.on_audio_tokens) ? 1 : 0;
+}
+
 extern "C" int mmi_lm_hook_io(mmi_lm* lm, int32_t which, int32_t write, void* buf, int64_t nbytes, mmi_stream stream) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm || !buf) return mmi_fail(MMI_ERR_INVALID, "null argument");

@@ -74,9 +74,19 @@ struct MmiProgram {
         MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
         int rc = run_range(capture_stream, i0, i1);
         hipError_t err = hipStreamEndCapture(capture_stream, g);
-        if (rc) return rc;
-        if (err != hipSuccess) return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(err));
-        MMI_HIP_CHECK(hipGraphInstantiate(e, *g, nullptr, nullptr, 0));
+        if (rc || err != hipSuccess) {          // an op failed while capturing: the half-built graph is not kept
+            if (err == hipSuccess && *g) hipGraphDestroy(*g);
+            *g = nullptr;
+            if (rc) return rc;
+            return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(err));
+        }
+        err = hipGraphInstantiate(e, *g, nullptr, nullptr, 0);
+        if (err != hipSuccess) {
+            hipGraphDestroy(*g);
+            *g = nullptr;
+            *e = nullptr;
+            return mmi_fail(MMI_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(err));
+        }
         return MMI_OK;
     }
 

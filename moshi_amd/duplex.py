@@ -39,7 +39,6 @@ class DuplexStream:
         ntok = 1 + lm_gen.lm_model.dep_q
         self._pcm = [torch.zeros(B, mimi.channels, mimi.frame_size, device=self.device, dtype=torch.float32) for _ in range(depth)]
         self._tok = [torch.full((B, ntok, 1), -2, device=self.device, dtype=torch.int64) for _ in range(depth)]
-        self._in = [None] * depth            # a frame's input must outlive its encode: two further submits (include/moshi_mi.h)
         self._n = 0
 
     def close(self) -> None:
@@ -56,18 +55,26 @@ class DuplexStream:
     def step(self, chunk: torch.Tensor, want_tokens: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         """Submit one 80 ms frame [B, C, frame_size].  Returns (tokens [B, 1 + dep_q, 1] or None, pcm [B, C, frame_size] or None)
         - None exactly where `lm_gen.step` returns None (lm.py:774-776).  The tensors are slots of a ring `depth` frames deep:
-        read them after `join()` and before `depth` further steps."""
+        read them after `join()` and before `depth` further steps.
+
+        `chunk` is copied into the pipeline's own input ring in stream order (like `mimi.encode`, the caller may refill a
+        preallocated input buffer as soon as this returns).  The batch must be the streaming batch (AssertionError, as
+        `lm_gen.step`, lm.py:679-682).  An LMGen with per-step hooks is refused (NotImplementedError): hooks work on the caller's
+        stream, the pipeline steps the LM on its own.  `support_out_of_sync` is honoured as `lm_gen.step` does (lm.py:774-776)."""
         x = self.mimi._check_audio(chunk)
         assert x.shape[-1] == self.mimi.frame_size, "one frame per step"
+        assert x.shape[0] == self.mimi._batch, f"batch {x.shape[0]} != streaming batch {self.mimi._batch}"
+        if self.lm_gen._hook_error is not None:          # a hook of an earlier serial step failed: surface it like lm_gen.step does
+            err, self.lm_gen._hook_error = self.lm_gen._hook_error, None
+            raise err
         slot = self._n % len(self._pcm)
         self._n += 1
         pcm, tok = self._pcm[slot], self._tok[slot]
         valid = C.c_int32(0)
-        self._in[slot] = x
         self._lib.check(self._lib.mmi_duplex_submit(self._handle, x.data_ptr(), pcm.data_ptr(), tok.data_ptr() if want_tokens else None,
-                                                    C.byref(valid), _capi.stream_ptr(self.device)))
-        if not valid.value:
-            return None, None
+                                                    x.shape[0], C.byref(valid), _capi.stream_ptr(self.device)))
+        if not valid.value:      # inside the LM's delay nothing is decoded; `support_out_of_sync` still hands the -2 rows out
+            return ((tok if want_tokens else None), None) if self.lm_gen.support_out_of_sync else (None, None)
         return (tok if want_tokens else None), pcm
 
     def join(self) -> None:

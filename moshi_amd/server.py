@@ -24,6 +24,8 @@ from typing import Callable, Dict, Optional, Tuple
 
 import numpy as np
 
+from .errors import UnknownChannel
+
 # ---- wire format (rust/protocol.md:7-31) ---------------------------------------------------------------------------------------
 MT_HANDSHAKE, MT_AUDIO, MT_TEXT, MT_CONTROL, MT_METADATA, MT_ERROR, MT_PING = range(7)
 CONTROL_START, CONTROL_END_TURN, CONTROL_PAUSE, CONTROL_RESTART = range(4)
@@ -195,7 +197,7 @@ class BatchedServer:
                         # pop: a vanished channel is that session's business, not a failure of the model loop
                         try:
                             fr = self.batcher.pop(channel)
-                        except ValueError:
+                        except UnknownChannel:
                             break
                         if fr is None or sess.closed or sess.channel != channel:
                             break

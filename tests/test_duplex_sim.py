@@ -59,3 +59,83 @@ def test_device_clock_stamps_follow_the_pipeline_order(sim_lib):
                               ("phase", "lm1"), ("lm1", "dec0"), ("dec0", "dec1")):
             assert s[before] < s[after], (f, before, after, s)
     assert st[4]["lm1"] < st[5]["lm0"] and st[4]["enc1"] < st[5]["enc0"]       # stream order across frames
+
+
+def test_step_rejects_a_batch_that_is_not_the_streaming_batch(sim_lib):
+    """`DuplexStream.step` with fewer rows than the streaming batch must fail like `lm_gen.step` does
+    (AssertionError, lm.py:679-682) instead of encoding rows it was never given; the C entry refuses it on its own too."""
+    import ctypes as C
+    import torch
+    from moshi_amd import _capi
+    from moshi_amd.duplex import DuplexStream
+    from moshi_amd.lm import LMGen
+    from tests.batcher_cases import tiny_pair
+    B = 3
+    mimi, lm, mcfg, _ = tiny_pair("cpu", sim_lib, B)
+    gen = LMGen(lm, use_sampling=False)
+    with mimi.streaming(B), gen.streaming(B):
+        dup = DuplexStream(mimi, gen)
+        assert sim_lib.mmi_duplex_batch(dup._handle) == B
+        with pytest.raises(AssertionError):
+            dup.step(torch.zeros(B - 1, 1, mcfg.frame_size))
+        x = torch.zeros(B, 1, mcfg.frame_size)
+        valid = C.c_int32(0)
+        rc = sim_lib.mmi_duplex_submit(dup._handle, x.data_ptr(), dup._pcm[0].data_ptr(), None, B - 1, C.byref(valid), None)
+        assert rc == _capi.MMI_ERR_SHAPE
+        assert dup.step(x) == (None, None)          # the refused calls left the pipeline usable
+        dup.join()
+        dup.close()
+
+
+def test_the_callers_input_buffer_may_be_refilled_in_place(sim_lib):
+    """the frame's input is copied into the pipeline's ring in stream order, so a caller that reuses ONE
+    preallocated input tensor (safe with `mimi.encode`) gets the same bits as one that hands over a fresh tensor per frame."""
+    import numpy as np
+    import torch
+    from moshi_amd.duplex import DuplexStream
+    from moshi_amd.lm import LMGen
+    from tests.batcher_cases import tiny_pair
+    B = 2
+    mimi, lm, mcfg, _ = tiny_pair("cpu", sim_lib, B)
+    rng = np.random.default_rng(11)
+    frames = [(0.1 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32) for _ in range(6)]
+
+    def run(reuse):
+        gen = LMGen(lm, use_sampling=False)
+        buf = torch.zeros(B, 1, mcfg.frame_size)
+        with mimi.streaming(B), gen.streaming(B):
+            dup = DuplexStream(mimi, gen)
+            outs = []
+            for f in frames:
+                if reuse:
+                    buf.copy_(torch.from_numpy(f))
+                    outs.append(dup.step(buf))
+                    buf.fill_(float("nan"))          # the caller's buffer is free again as soon as step() returns
+                else:
+                    outs.append(dup.step(torch.from_numpy(f)))
+            dup.join()
+            res = [None if o[0] is None else (o[0].numpy().copy(), o[1].numpy().copy()) for o in outs]
+            dup.close()
+            return res
+    for a, b in zip(run(False), run(True)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_a_hooked_lmgen_is_refused(sim_lib):
+    """LMGen's hooks work on the caller's stream while the pipeline steps the LM on its own - refused
+    (NotImplementedError) rather than racing; without hooks the same objects run."""
+    import torch
+    from moshi_amd.duplex import DuplexStream
+    from moshi_amd.lm import LMGen
+    from tests.batcher_cases import tiny_pair
+    B = 2
+    mimi, lm, mcfg, _ = tiny_pair("cpu", sim_lib, B)
+    gen = LMGen(lm, use_sampling=False, on_text_hook=lambda t: None)
+    x = torch.zeros(B, 1, mcfg.frame_size)
+    with mimi.streaming(B), gen.streaming(B):
+        dup = DuplexStream(mimi, gen)
+        with pytest.raises(NotImplementedError):
+            dup.step(x)
+        dup.close()

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from moshi_amd import server as srv
+from moshi_amd.errors import UnknownChannel
 from tests import batcher_cases
 
 
@@ -157,7 +158,7 @@ def test_a_vanished_channel_does_not_stop_the_model_loop():
 
         def pop(self, channel):
             if channel == 1:
-                raise ValueError("unknown channel (mmi status -1)")
+                raise UnknownChannel("unknown channel (mmi status -1)")
             q = self.queues.get(channel, [])
             return q.pop(0) if q else None
 
@@ -180,3 +181,30 @@ def test_a_vanished_channel_does_not_stop_the_model_loop():
     assert not server.errors, server.errors
     assert server.batcher.steps >= 50
     assert len(alive.calls) == 3 and not gone.calls
+
+
+def test_any_other_invalid_argument_is_not_swallowed_by_the_model_loop():
+    """Only the unknown-channel status ends a session's drain quietly; every other MMI_ERR_INVALID (a ValueError) is a real
+    failure of the model loop and is recorded as one."""
+    import time
+
+    class FakeBatcher:
+        frame_size = 4
+        steps = 0
+
+        def step(self):
+            self.steps += 1
+            return 1
+
+        def pop(self, channel):
+            raise ValueError("null argument (mmi status -1)")
+
+    server = srv.BatchedServer(FakeBatcher(), model_version=3, idle_sleep=0.001)
+    loop = type("L", (), {"call_soon_threadsafe": lambda self, fn, arg: None})()
+    server._sessions[1] = srv._Session(1, type("Q", (), {"put_nowait": None})(), loop)
+    server.start()
+    deadline = time.time() + 5
+    while not server.errors and time.time() < deadline:
+        time.sleep(0.01)
+    server.stop()
+    assert server.errors and isinstance(server.errors[0], ValueError) and not isinstance(server.errors[0], UnknownChannel)
