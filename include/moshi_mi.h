@@ -303,6 +303,13 @@ int32_t mmi_lm_has_hooks(const mmi_lm* lm);         /* 1 while any of the three 
  * replay the reference's token history exactly. */
 int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream stream);
 
+/* Parity tap of the residual stream (test aid; the reference has none - it is what a forward hook on
+ * `transformer.layers[0]` / `layers[-1]` would see, transformer.py:814-929): switched on BEFORE streaming_start, every step also
+ * keeps the hidden state after the first and after the last temporal layer; get copies bf16 [2][model rows][dim] (row-major)
+ * out, stream-ordered.  Off by default: no launch is added. */
+int mmi_lm_set_hidden_taps(mmi_lm* lm, int32_t on);
+int mmi_lm_get_hidden_taps(mmi_lm* lm, void* buf_bf16, int64_t nbytes, mmi_stream stream);
+
 /* The launch list of one frame step, recorded while the step ran for the first time: one line "site<TAB>kernel[<TAB>weight bytes]" per kernel
  * launch in launch order (sites: "L.in_proj", "L.ffn_in", "dep.out_proj", "text_linear", ...).  scripts/rocpd_sites.py joins
  * it with a rocprofv3 kernel trace by position inside the step, which is how per-site durations of kernels that share one

@@ -104,6 +104,8 @@ SIGNATURES = {
     "mmi_duplex_submit": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     "mmi_duplex_batch": (C.c_int32, [_P]),
     "mmi_lm_has_hooks": (C.c_int32, [_P]),
+    "mmi_lm_set_hidden_taps": (C.c_int, [_P, C.c_int32]),
+    "mmi_lm_get_hidden_taps": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mmi_duplex_join": (C.c_int, [_P, _P]),
     "mmi_duplex_flush": (C.c_int, [_P]),
     "mmi_duplex_set_timeline": (C.c_int, [_P, C.c_int32]),

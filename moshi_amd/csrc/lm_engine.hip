@@ -88,6 +88,8 @@ struct mmi_lm {
     float *opart = nullptr, *ml = nullptr;
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
+    bool hidden_taps = false;                       // mmi_lm_set_hidden_taps: the next streaming_start adds the two copies below
+    uint16_t* htap = nullptr;                       // [2][B][dim] residual stream after the first / the last temporal layer
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
     uint16_t* dpre = nullptr;       // [B][dep_q * depformer_dim] depformer_in[k](transformer_out) of every micro-step
     uint16_t *dkc = nullptr, *dvc = nullptr;        // [dep_layers][B][Hd][dep_q][Dhd]
@@ -466,6 +468,19 @@ void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, ui
     });
 }
 
+// parity tap (mmi_lm_set_hidden_taps; off in production: no op is added): the residual stream, row-major, into htap[which]
+void add_hidden_tap(mmi_lm* lm, int which) {
+    if (!lm->htap) return;
+    const int B = lm->batch, d = lm->cfg.dim, T = lm->T, ksteps = packed_ksteps(lm, d);
+    const uint16_t* x = lm->x;
+    uint16_t* dst = lm->htap + (size_t)which * B * d;
+    lm->prog.add([=](hipStream_t s) {
+        MMI_LAUNCH(k_unpack_rows, mmi_cdiv(B * d, 256), 256, 0, s, x, B, d, dst, T, ksteps);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
+}
+
 // RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
@@ -631,6 +646,7 @@ int build_program(mmi_lm* lm) {
         const LayerW& L = lm->layers[l];
         P.site("L.norm1");
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
+        if (l == 1) add_hidden_tap(lm, 0);     // x is complete (the previous linear_out's partials folded in) right after this norm
         LmAttnArgs a;
         a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
@@ -695,6 +711,8 @@ int build_program(mmi_lm* lm) {
     }
     P.site("out_norm");
     add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
+    if (c.num_layers == 1) add_hidden_tap(lm, 0);
+    add_hidden_tap(lm, 1);
     P.site("text_linear");
     add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr);
     // depformer_in[k](transformer_out) for every micro-step in one launch; each sampler then adds its token's embedding row
@@ -1070,6 +1088,8 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
     ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
+    lm->htap = nullptr;
+    if (lm->hidden_taps) ok &= hipSuccess == A.alloc(&lm->htap, (size_t)2 * B * d);
     ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);
@@ -1227,6 +1247,23 @@ extern "C" int mmi_lm_set_hooks(mmi_lm* lm, const mmi_lm_hooks* hooks) {
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (hooks) lm->hooks = *hooks;
     else lm->hooks = mmi_lm_hooks{nullptr, nullptr, nullptr, nullptr};
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_set_hidden_taps(mmi_lm* lm, int32_t on) {
+    if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
+    if (lm->streaming) return mmi_fail(MMI_ERR_STATE, "mmi_lm_set_hidden_taps: call before streaming_start");
+    lm->hidden_taps = on != 0;
+    return MMI_OK;
+}
+
+extern "C" int mmi_lm_get_hidden_taps(mmi_lm* lm, void* buf, int64_t nbytes, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !buf) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (!lm->streaming || !lm->htap) return mmi_fail(MMI_ERR_STATE, "hidden taps were not enabled before streaming_start");
+    const int64_t want = (int64_t)2 * lm->batch * lm->cfg.dim * 2;
+    if (nbytes != want) return mmi_fail(MMI_ERR_SHAPE, "mmi_lm_get_hidden_taps: the buffer holds " + std::to_string(nbytes) + " bytes, the taps " + std::to_string(want));
+    MMI_HIP_CHECK(hipMemcpyAsync(buf, lm->htap, (size_t)want, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MMI_OK;
 }
 

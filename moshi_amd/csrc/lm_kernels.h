@@ -994,6 +994,14 @@ __global__ void k_pack_rows(const uint16_t* __restrict__ src, int n, int D, uint
     xp[mmi_xp_index(T, r, k, ksteps)] = src[idx];
 }
 
+// packed activation operand -> row-major rows [B][D] (the parity tap of the residual stream, mmi_lm_set_hidden_taps)
+__global__ void k_unpack_rows(const uint16_t* __restrict__ xp, int B, int D, uint16_t* __restrict__ dst, int T, int ksteps) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= B * D) return;
+    const int r = idx / D, k = idx - r * D;
+    dst[idx] = xp[mmi_xp_index(T, r, k, ksteps)];
+}
+
 // Cross-attention of the one new query per (model row, head) over the T_c projected condition positions (transformer.py:
 // 544-552, 584: no mask, no rope, keys / values fixed for the stream).  kv: [rows][T_c][2 * H * Dh] bf16 (keys, then values, as
 // the in_proj's rows dim.. produce them); q: [rows][H * Dh] bf16.  One wave per (row, head); lane (r, c) = position slot r x

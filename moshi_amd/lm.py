@@ -155,6 +155,11 @@ class LMModel:
         except Exception:
             pass
 
+    def enable_hidden_taps(self, on: bool = True) -> None:
+        """Parity tap (tests): every step of the NEXT `LMGen.streaming()` also keeps the residual stream after the first and
+        the last temporal layer (`LMGen.hidden_taps()`)."""
+        self._lib.check(self._lib.mmi_lm_set_hidden_taps(self._handle, 1 if on else 0))
+
     # attributes callers read (SURVEY.md 8b)
     @property
     def dep_q(self) -> int:
@@ -412,6 +417,14 @@ class LMGen:
         assert len(offs) == self._batch
         arr = (C.c_int64 * len(offs))(*offs)
         self._lib.check(self._lib.mmi_lm_seek(self.lm_model._handle, C.cast(arr, C.c_void_p), self._stream()))
+
+    def hidden_taps(self) -> torch.Tensor:
+        """Parity tap (tests): the residual stream of the LAST step after the first and after the last temporal layer, bf16
+        [2, model rows, dim].  `lm_model.enable_hidden_taps()` must have been called before `streaming()`."""
+        rows = self._lib.mmi_lm_model_rows(self.lm_model._handle)
+        out = torch.empty(2, rows, self.lm_model.config.dim, device=self.device, dtype=torch.bfloat16)
+        self._lib.check(self._lib.mmi_lm_get_hidden_taps(self.lm_model._handle, out.data_ptr(), out.numel() * 2, self._stream()))
+        return out
 
     def launch_list(self, with_bytes: bool = False):
         """[(site, kernel)] per kernel launch of one step, in launch order (recorded during the first step); with_bytes: a

@@ -287,6 +287,7 @@ class LMOracle:
         self.CT = max(c.delays) + 2
         H, Dh = c.num_heads, c.dim // c.num_heads
         self.kv = [np.zeros((2, B, H, c.context, Dh), f32) for _ in range(c.num_layers)]
+        self.hidden_taps = {}      # {0: x after the first temporal layer, 1: after the last} of the last forward_text ([rows, dim], bf16 values)
         self.tr_offset = np.zeros(B, np.int64)          # MHA offset == RingKVCache.end_offset for every layer
 
     def reset_streaming(self, mask=None):
@@ -364,6 +365,10 @@ class LMOracle:
                 xa = bf16r(np.einsum("bht,bhtd->bhd", p, vc).astype(f32).reshape(B, H * Dh))
                 x = bf16r(x + linear(xa, L["x_out"], self.acc64))
             x = bf16r(x + gated_ffn(rms_norm(x, L["n2"]), L["w_in"], L["w_out"], self.acc64))
+            if l == 0 or l == len(self.layers) - 1:              # what a forward hook on layers[0] / layers[-1] returns
+                self.hidden_taps[0 if l == 0 else 1] = x.copy()
+                if len(self.layers) == 1:
+                    self.hidden_taps[1] = x.copy()
         tout = rms_norm(x, self.out_norm)
         return tout, linear(tout, self.text_linear, self.acc64)
 

@@ -172,6 +172,71 @@ def check_golden_full(device, lib, max_batch=None, name=None):
                                 set_mask=lambda m: gen.set_exec_mask(torch.from_numpy(m).to(device)))
 
 
+def check_free_running(device, lib, g, cfg, widen, name, max_batch=None, on_cuda_weights=False):
+    """NOT teacher-forced: the engine runs greedy on its own tokens through a golden run of the reference - what
+    it samples at step s is what it reads at step s + 1.  Per row, the first (step, site) where its token differs from the
+    reference's is reported, and it must be a near-tie of the REFERENCE's logits at that site (all inputs up to there were
+    identical, so those logits are comparable); from there on the row is on another trajectory and is not compared (until a
+    reset of that row puts it back on the reference's)."""
+    import json
+    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+    if on_cuda_weights and torch.device(device).type == "cuda":
+        sd = {k: v.to(device) for k, v in sd.items()}
+    S, B = g["g_text_tok"].shape
+    gen = make_engine(cfg, sd, device, lib, max_batch or B, use_sampling=False, support_out_of_sync=True)
+    del sd
+    off_track, events = {}, []
+    compared = 0
+    masks = g["masks"] if "masks" in g else np.ones((S, B), bool)
+    reset_step = int(g["reset_step"][0]) if "reset_step" in g else -1
+    with gen.streaming(B):
+        for s in range(S):
+            if s == reset_step:
+                gen.reset_streaming(torch.from_numpy(g["reset_mask"]).to(device))
+                for b in np.flatnonzero(g["reset_mask"]):
+                    off_track.pop(int(b), None)
+            gen.set_exec_mask(torch.from_numpy(masks[s]).to(device))
+            out, tl, al = gen.step_with_taps(torch.from_numpy(g["codes"][s]).to(device))
+            tl, al = tl.cpu().numpy(), al.cpu().numpy()
+            for b in range(B):
+                if not masks[s, b] or b in off_track:
+                    continue
+                sites = [("text", tl[b], g["g_text_logits"][s, b], int(g["g_text_tok"][s, b]))]
+                sites += [(f"audio{k}", al[b, k], g["g_audio_logits"][s, b, k], int(g["g_audio_tok"][s, b, k])) for k in range(cfg.dep_q)]
+                for site, lg, ref, tok_ref in sites:
+                    tok = int(lg.argmax())
+                    compared += 1
+                    if tok != tok_ref:
+                        scale = float(np.abs(ref).max()) + 1e-6
+                        off_track[b] = True
+                        events.append({"row": b, "step": s, "site": site, "engine": tok, "reference": tok_ref,
+                                       "reference_logit_gap_rel": abs(float(ref[tok]) - float(ref[tok_ref])) / scale,
+                                       "near_tie": bool(near_tie(ref, tok, tok_ref, widen))})
+                        break               # later sites of this step already condition on the different token
+    res = {"case": name, "steps": int(S), "rows": int(B), "token_decisions_compared": compared, "divergences": events}
+    print(f"[parity] {name}: free-running greedy vs the reference, {compared} token decisions compared on the reference's trajectory; "
+          + ("no row left it" if not events else "; ".join(f"row {v['row']}: step {v['step']} {v['site']} (reference logit gap "
+                                                          f"{v['reference_logit_gap_rel']:.4f} of max|logit|, near-tie: {v['near_tie']})" for v in events)))
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out.is_dir():
+        (out / f"parity_{name}.json").write_text(json.dumps(res, indent=1))
+    for v in events:
+        assert v["near_tie"], f"row {v['row']} left the reference's trajectory at step {v['step']} ({v['site']}) where its logits do not tie: {v}"
+    return res
+
+
+def check_golden_full_free_running(device, lib, max_batch=None, name="golden_full_free_running"):
+    """The benchmark model (32 layers, context 3000) free-running against the reference's own run (lm_full.npz)."""
+    g, cfg = load_full()
+    return check_free_running(device, lib, g, cfg, FULL_WIDEN, name, max_batch=max_batch, on_cuda_weights=True)
+
+
+def check_golden_tiny_free_running(device, lib):
+    """The same on the tiny golden schedule (exec masks + a partial reset, which puts a row back on the reference's trajectory)."""
+    return check_free_running(device, lib, np.load(GOLDEN / "lm_tiny.npz"), tiny_lm_config(), 1.0,
+                              f"golden_tiny_free_running_{torch.device(device).type}", max_batch=3)
+
+
 def check_golden_sampled(device, lib):
     """Replays the reference's sampled run with the Exp(1) draws recorded at its `multinomial`."""
     g = np.load(GOLDEN / "lm_tiny.npz")
@@ -306,6 +371,46 @@ class ErrorLog:
         return worst, worst_mean
 
 
+class HiddenLog:
+    """The residual stream after the first / the last temporal layer, engine vs checker, in units of one bf16 ulp at the row's
+    RMS (2^-7 * rms(row): the spacing of bf16 values of typical magnitude in that row), per element.  The logit gate (5 % of
+    max|logit|) is a wide net at the END of the network; this is the net in the middle: after ONE layer two correct bf16
+    implementations differ by isolated last-bit flips, after all of them by the accumulated drift the yardstick measures."""
+
+    def __init__(self):
+        self.units = {0: [], 1: []}
+
+    def add(self, which: int, a: np.ndarray, ref: np.ndarray):
+        rms = np.sqrt((ref.astype(np.float64) ** 2).mean(-1, keepdims=True)) + 1e-30
+        self.units[which].append((np.abs(a.astype(np.float64) - ref) / (rms * 2.0 ** -7)).ravel())
+
+    def summary(self) -> dict:
+        out = {}
+        for w, v in self.units.items():
+            if not v:
+                continue
+            u = np.concatenate(v)
+            out[w] = {"n": int(u.size), "mean": float(u.mean()), "p99": float(np.quantile(u, 0.99)), "max": float(u.max()),
+                      "exact": float((u == 0).mean())}
+        return out
+
+    def check_against(self, yard: "HiddenLog", name: str, num_layers: int):
+        import json
+        es, ys = self.summary(), yard.summary()
+        for w, label in ((0, "layer 0"), (1, f"layer {num_layers - 1}")):
+            print(f"[parity] {name} after {label}: engine mean {es[w]['mean']:.3f} p99 {es[w]['p99']:.2f} max {es[w]['max']:.1f} bf16 ulps at the "
+                  f"row RMS, {100 * es[w]['exact']:.1f} % bit-equal | fp64-vs-fp32 oracle mean {ys[w]['mean']:.3f} p99 {ys[w]['p99']:.2f} max {ys[w]['max']:.1f}")
+        out = Path(__file__).resolve().parent.parent / "gpurun_out"
+        if out.is_dir():
+            (out / f"parity_{name}.json").write_text(json.dumps({"case": name, "unit": "bf16 ulp at the row RMS", "engine": es, "yardstick": ys}, indent=1))
+        # after ONE layer: isolated last-bit flips only - the mean is a small fraction of an ulp whatever the summation order
+        assert es[0]["mean"] <= max(0.25, FULL_DEPTH_FACTOR * ys[0]["mean"]), f"layer 0: {es[0]} vs yardstick {ys[0]}"
+        assert es[0]["p99"] <= max(2.0, FULL_DEPTH_FACTOR * ys[0]["p99"]), f"layer 0: {es[0]} vs yardstick {ys[0]}"
+        # after the last layer: within FULL_DEPTH_FACTOR x what a different (fp64) accumulation order alone produces
+        for key in ("mean", "p99"):
+            assert es[1][key] <= FULL_DEPTH_FACTOR * ys[1][key] + 0.25, f"last layer {key}: engine {es[1][key]:.3f} vs yardstick {ys[1][key]:.3f}"
+
+
 def lazy_temporal_linears(sd):
     """The checker keeps the temporal transformer's big linears where they are (bf16 on the GPU) and widens each to fp32 only
     while it multiplies with it (oracle.lm_oracle.LazyWeight): the 32-layer oracle then needs ~2 GB of host memory, not 30."""
@@ -334,6 +439,8 @@ def full_depth_vs_oracle(device, lib, B=32, S=3, num_layers=32, seed=4242, name=
     cfg = cfg or LMConfig(num_layers=num_layers)
     sd = random_lm_state_dict(cfg, seed=seed, device=device)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    gen.lm_model.enable_hidden_taps()              # the residual stream after temporal layers 0 and num_layers - 1
+    hid, hid_yard = HiddenLog(), HiddenLog()
     lazy = lazy_temporal_linears(sd)
     orc = LMOracle(lazy, replace(cfg, context=64))
     ref64 = LMOracle(lazy, replace(cfg, context=64), accumulate64=True)     # the yardstick's second implementation
@@ -351,12 +458,16 @@ def full_depth_vs_oracle(device, lib, B=32, S=3, num_layers=32, seed=4242, name=
             out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
             out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
             assert np.array_equal(out, oo), f"step {s}: ring output differs"
+            taps = gen.hidden_taps().float().cpu().numpy()
+            for w in (0, 1):
+                hid.add(w, taps[w], orc.hidden_taps[w]); hid_yard.add(w, ref64.hidden_taps[w], orc.hidden_taps[w])
             for b in range(B):
                 log.add("text", tl[b], otl[b]); yard.add("text", ytl[b], otl[b])
                 for k in range(cfg.dep_q):
                     log.add(f"audio{k}", al[b, k], oal[b, k]); yard.add(f"audio{k}", yal[b, k], oal[b, k])
     log.dump(name)
     yard.dump(name + "_yardstick_fp64_accumulation")
+    hid.check_against(hid_yard, name + "_hidden", cfg.num_layers)
     es, ys = log.summary(), yard.summary()
     bad = []
     for site in es:

@@ -189,6 +189,13 @@ def test_benchmark_model_matches_the_reference_at_full_depth(gpu_lib):
     lm_cases.check_golden_full(DEV, None)
 
 
+def test_benchmark_model_free_running_follows_the_reference(gpu_lib):
+    """Greedy and NOT teacher-forced against the reference's own 32-layer run (lm_full.npz), on the benchmark's kernels (32-row
+    tile): the step of first divergence per row is reported (gpurun_out/parity_golden_full_free_running.json) and must be a
+    near-tie of the reference's logits."""
+    lm_cases.check_golden_full_free_running(DEV, None, max_batch=32)
+
+
 def test_benchmark_kernels_match_the_reference_at_full_depth(gpu_lib):
     """The same golden run on a handle built for 32 sessions: the 32-row tile, k_gemm_xlds, the split-K temporal GEMMs - the
     kernels `bench.py` times - against the reference's own logits (a 2-session handle takes the 16-row tile)."""

@@ -12,6 +12,11 @@ def test_greedy_schedule_matches_reference_golden(sim_lib):
     lm_cases.check_golden_greedy("cpu", sim_lib)
 
 
+def test_free_running_greedy_follows_the_reference_golden(sim_lib):
+    res = lm_cases.check_golden_tiny_free_running("cpu", sim_lib)
+    assert res["token_decisions_compared"] > 50
+
+
 def test_sampled_run_matches_reference_golden_given_its_noise(sim_lib):
     lm_cases.check_golden_sampled("cpu", sim_lib)
 

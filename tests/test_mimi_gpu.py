@@ -36,6 +36,18 @@ def test_full_size_matches_oracle(factory):
     mimi_cases.oracle_vs_engine(factory, DEV, MimiConfig(), seed=77, B=2, F=2, K=8, use_masks=True)
 
 
+def test_full_size_c2_recipe_crosses_the_ring_wrap(factory):
+    """8 streams, 200 frames, random exec masks, one mid-run reset - the 250-slot rings of the codec's
+    transformers wrap at frame 126 (the state bench.py runs in, never parity-tested at full size before)."""
+    import json
+    from pathlib import Path
+    res = mimi_cases.check_c2_recipe(factory, DEV, MimiConfig(), B=8, F=200)
+    assert res["wrapped"]
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out.is_dir():
+        (out / "parity_mimi_c2_recipe.json").write_text(json.dumps(res, indent=1))
+
+
 def test_rvq_indices_bit_exact_on_many_vectors(factory):
     """131 072 index decisions (4096 latents x 32 levels) against the oracle's fp32 cdist restatement.
     The engine evaluates distances in fp64, i.e. it returns the exact nearest centroid; the fp32 reference formula
