@@ -50,7 +50,49 @@ def parse():
                     help="duplex workload: the reference's serving loop on ONE stream (encode -> step -> decode back to back) instead of "
                          "the three-stream pipeline of mmi_duplex_* (encode(t+1) and decode(t-1) under LMGen.step(t))")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
+    ap.add_argument("--kv-depth", default="mid", choices=["mid", "start"],
+                    help="mid (default): before the warm-up every session is moved (mmi_lm_seek) to the MIDPOINT of the configuration's run "
+                         "(SURVEY.md 8d: C4 = 500 steps, sessions 8 frames apart -> ring depth 250 + 8 b; C3 = 300 steps -> depth 150), so "
+                         "the measured step does not depend on --steps; start: sessions start at depth 8 b (rounds 1-3)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra figures of the default line: `full_context` (every session 3000 positions deep) and `c3` (one session)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank's host thread to its own block of cores")
     return ap.parse_args()
+
+
+def pin_host_thread(rank, world):
+    """The duplex pipeline's gate is a HOST wait (mmi_duplex_submit blocks in hipEventSynchronize), so with N ranks on one
+    node N host threads' scheduling jitter lands in ms_per_step: rank r's main thread - and every thread it starts from here on
+    (the HIP runtime's) - is confined to its own block of cores.  The BLAS pool numpy started at import keeps the whole machine
+    (the CPU-baseline leg lifts the pin again for its own thread).  Returns the cores, for the JSON line."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    per = max(1, min(16, len(allowed) // max(world, 1)))
+    mine = allowed[rank * per:(rank + 1) * per] or allowed
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
+def unpin_host_thread():
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except (AttributeError, OSError):
+        pass
+
+
+def gather_per_rank(x, dist, dev, world):
+    """One float per rank -> the list over ranks (every rank gets it)."""
+    if dist is None:
+        return [float(x)]
+    t = torch.tensor([float(x)], device=dev, dtype=torch.float64)
+    allr = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allr, t)
+    return [float(v[0]) for v in allr]
 
 
 def _free_port():
@@ -218,7 +260,11 @@ def launchcheck_main(args, backend):
     dev = torch.device("cpu") if backend == "gloo" else torch.device("cuda", local)
     if dist is not None:
         dist.barrier()
-    dt = job_time(0.5 + 0.25 * rank, dist, dev)
+    cores = None if args.no_pin else pin_host_thread(rank, world)
+    dt_local = 0.5 + 0.25 * rank
+    dt = job_time(dt_local, dist, dev)
+    ms_ranks = [1e3 * v / args.steps for v in gather_per_rank(dt_local, dist, dev, world)]
+    first_core = gather_per_rank(-1 if not cores else cores[0], dist, dev, world)
     p50, p95, p50s, p95s = job_latency(5.0 + rank, 6.0 + rank, dist, dev, world)      # rank r pretends to be r ms slower
     if dist is not None:
         dist.barrier()
@@ -226,6 +272,7 @@ def launchcheck_main(args, backend):
         print(json.dumps({"metric": "launchcheck", "value": job_value(world, args.batch, args.steps, dt), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50s, "p95_ms_per_rank": p95s,
+                          "ms_per_step_per_rank": ms_ranks, "host_first_core_per_rank": [int(c) for c in first_core],
                           "backend": backend}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -240,6 +287,7 @@ def main():
         return launchcheck_main(args, os.environ.get("MMI_BENCH_BACKEND", "nccl"))
     rank, local, world, dist = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
+    cores = None if args.no_pin else pin_host_thread(rank, world)
     from moshi_amd import MimiConfig, MimiModel
     from moshi_amd.weights import random_mimi_state_dict
 
@@ -263,7 +311,9 @@ def main():
         lm_gen = make_lm(dev, B, args)
 
     torch.cuda.synchronize(dev)
-    load_s = job_time(time.perf_counter() - t_load, dist, dev)      # rank 0 draws, RCCL broadcasts in 1 GiB buckets, every rank packs
+    load_local = time.perf_counter() - t_load
+    load_s = job_time(load_local, dist, dev)      # rank 0 draws, RCCL broadcasts in 1 GiB buckets, every rank packs
+    load_ranks = gather_per_rank(load_local, dist, dev, world)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
     user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)
@@ -304,6 +354,15 @@ def main():
     if lm_gen is not None:
         from bench_lm import stagger
         staggered = stagger(mimi if workload == "duplex" else None, lm_gen, step, B, args.stagger, dev, before_mask=join)
+    # ring depth of session b when the warm-up starts.  "mid": the midpoint of the configuration's run as SURVEY.md 8d states it
+    # (C4: 500 steps, sessions `stagger` frames apart; C3: one session, 300 steps) - the rings' skipped positions hold zeros, the
+    # kernels read them all the same (no data-dependent control flow), and the codec's rings are where the stagger left them
+    # (rows >= 16 of 32 are past their 250-slot wrap).  "start": what the stagger alone leaves (rounds 1-3).
+    base_depth = [args.stagger * b if B > 1 else staggered for b in range(B)]
+    if lm_gen is not None and args.kv_depth == "mid":
+        join()
+        base_depth = [250 + args.stagger * b for b in range(B)] if B > 1 else [150]
+        lm_gen.seek(base_depth)
     trace("staggered")
     for _ in range(args.warmup):
         step()
@@ -314,7 +373,10 @@ def main():
         step()
     join()
     torch.cuda.synchronize(dev)
-    dt = job_time(time.perf_counter() - t0, dist, dev)
+    dt_local = time.perf_counter() - t0
+    dt = job_time(dt_local, dist, dev)
+    ms_ranks = [1e3 * v / args.steps for v in gather_per_rank(dt_local, dist, dev, world)]
+    first_core = gather_per_rank(-1 if not cores else cores[0], dist, dev, world)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -367,7 +429,11 @@ def main():
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50_ranks, "p95_ms_per_rank": p95_ranks,
-        "load_s": load_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step_per_rank": ms_ranks, "load_s": load_s, "load_s_per_rank": load_ranks,
+        "host_affinity": {"cores_per_rank": None if not cores else len(cores), "first_core_per_rank": [int(c) for c in first_core],
+                          "note": "each rank's main thread (the duplex pipeline's host-kept gate) and the HIP runtime threads it starts are "
+                                  "confined to a disjoint block of cores; -1 = not pinned"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"none": "bf16", "q8": "bf16 x int8 weights", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
@@ -383,7 +449,11 @@ def main():
                    "sampling": "temp .8/.7 top-k 250/25 (LMGen defaults), on-device RNG",
                    "kv_cache": args.kv,
                    "session_stagger_frames": args.stagger if lm_gen is not None else 0,
-                   "kv_positions_at_end": ([args.stagger * b + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
+                   "kv_depth": ({"mid": "sessions moved (mmi_lm_seek) to the midpoint of the configuration's run before the warm-up: ring depth "
+                                        "250 + 8 b of SURVEY 8d C4's 500-step run (150 for the single session of C3); skipped ring rows hold zeros",
+                                 "start": "sessions start at depth 8 b (the stagger alone; rounds 1-3)"}[args.kv_depth] if lm_gen is not None else None),
+                   "kv_positions_at_start": ([base_depth[0], base_depth[-1]] if lm_gen is not None else None),
+                   "kv_positions_at_end": ([base_depth[b] + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
     }
     if rank == 0:
         if workload == "mimi":
@@ -397,11 +467,11 @@ def main():
             from bench_lm import lm_step_algorithmic_bytes, roofline_lm
             # ring depth of every session in the middle of the profiled steps (they follow the timed region and the latency pass)
             done = args.warmup + args.steps + max(8, min(args.steps, 40)) + max(4, min(args.steps, 20)) // 2
-            out["roofline"] = roofline_lm(lm_gen, step, args, sync, kv_rows=[(args.stagger * b if B > 1 else staggered) + done for b in range(B)])
+            out["roofline"] = roofline_lm(lm_gen, step, args, sync, kv_rows=[base_depth[b] + done for b in range(B)])
             # the WHOLE step against the HBM roofline: LM weights once + every session's KV at its depth at
             # the middle of the timed region (+ Mimi's weights / rings / KV when the step includes the codec)
             mid = args.warmup + args.steps // 2
-            L_rows = [args.stagger * b + mid if B > 1 else staggered + mid for b in range(B)]
+            L_rows = [base_depth[b] + mid for b in range(B)]
             step_bytes = lm_step_algorithmic_bytes(lm_gen.lm_model.config, L_rows, quant=args.quant, kv=args.kv)
             parts = {"lm": step_bytes}
             if workload == "duplex":
@@ -410,12 +480,19 @@ def main():
             ach = step_bytes / (ms * 1e-3) / 1e9
             out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "parts": parts, "achieved": ach, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS, "ms_per_step": ms}
+        if workload == "duplex" and world == 1 and not args.no_extras and not args.lm_layers and args.quant == "none" and args.kv == "bf16":
+            # the other figures SURVEY 8d asks of this model, measured in the same process after the headline
+            from bench_lm import extra_full_context, extra_c3
+            join()
+            out["full_context"] = extra_full_context(lm_gen, user_codes, B, dev)
+            out["c3"] = extra_c3(dev, args)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the barrier)
+            unpin_host_thread()
             cpu_sd = {k: v.cpu() for k, v in msd.items()}
             base = cpu_baseline_mimi(mcfg, cpu_sd)
             if workload != "mimi":
                 from bench_lm import cpu_baseline_duplex
-                base = cpu_baseline_duplex(base, args)
+                base = cpu_baseline_duplex(base, args, dev=dev)
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -152,6 +152,98 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
     return out
 
 
+def _time_lm_steps(gen, codes, n_warm, n, dev):
+    """ms of each of n LMGen.step calls after n_warm untimed ones (device events around every step, one synchronisation)."""
+    for _ in range(n_warm):
+        gen.step(codes)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(); gen.step(codes); b.record()
+    torch.cuda.synchronize(dev)
+    wall = 1e3 * (time.perf_counter() - t0) / n
+    return wall, sorted(a.elapsed_time(b) for a, b in evs)
+
+
+def extra_full_context(lm_gen, user_codes, B, dev, steps=10):
+    """`full_context` of the default line: LMGen.step ALONE on the benchmark's handle with every session's ring full (SURVEY.md
+    8d: "B=32, L=3000: 14.75 + 50.3 GB -> 8.1 ms" floor) - the sessions are moved to position `context` (mmi_lm_seek), so every
+    step reads all 3000 slots of every ring.  Runs after everything else (it leaves the sessions there)."""
+    cfg = lm_gen.lm_model.config
+    lm_gen.seek([cfg.context] * B)
+    wall, lat = _time_lm_steps(lm_gen, user_codes, 3, steps, dev)
+    nbytes = lm_step_algorithmic_bytes(cfg, [cfg.context] * B)
+    ach = nbytes / (wall * 1e-3) / 1e9
+    return {"workload": f"LMGen.step alone, {B} sessions, every KV ring full ({cfg.context} positions, bf16)", "steps": steps,
+            "ms_per_step": wall, "p50_ms_per_step": lat[len(lat) // 2], "algorithmic_bytes": nbytes, "achieved_GBps": ach,
+            "frac": ach / HBM_PEAK_GBS}
+
+
+def extra_c3(dev, args, steps=30):
+    """`c3` of the default line (BASELINE configs[2]: Moshi-7B bf16 LMGen.step, batch 1 - the single real-time session): a
+    second handle built for ONE session (16-row MFMA tile), moved to the midpoint of SURVEY 8d's 300-step run, sampled."""
+    import copy
+    a1 = copy.copy(args)
+    gen = make_lm(dev, 1, a1)
+    cfg = gen.lm_model.config
+    gen.seek([150])
+    codes = torch.randint(0, cfg.card, (1, cfg.n_q - cfg.dep_q, 1), device=dev)
+    wall, lat = _time_lm_steps(gen, codes, 5, steps, dev)
+    nbytes = lm_step_algorithmic_bytes(cfg, [150 + 5 + steps // 2])
+    ach = nbytes / (wall * 1e-3) / 1e9
+    out = {"workload": "Moshi-7B bf16 LMGen.step, ONE session (BASELINE configs[2]), ring 150 + deep (midpoint of a 300-step run)",
+           "steps": steps, "ms_per_step": wall, "p50_ms_per_step": lat[len(lat) // 2], "p95_ms_per_step": lat[min(len(lat) - 1, int(0.95 * len(lat)))],
+           "budget_ms": 80.0, "algorithmic_bytes": nbytes, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBS}
+    try:        # the per-site table of the one-session step, live (hipEvents around every op of un-graphed steps)
+        a1.steps = 8
+        r = roofline_lm(gen, lambda: gen.step(codes), a1, lambda: torch.cuda.synchronize(dev), kv_rows=[150 + 5 + steps + 4])
+        out["sites"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in r["sites"].items()}
+    except Exception as e:      # noqa: BLE001 - a diagnostic, never worth the line
+        out["sites_error"] = repr(e)
+    del gen
+    torch.cuda.empty_cache()
+    return out
+
+
+def _mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_lm_measured(dev, timed=3):
+    """The LM oracle at the model's FULL depth (32 temporal layers, full depformer and text head, fp32 numpy on the host cores,
+    B = 1): one warm-up step, then the median of `timed` steps.  The weights are the benchmark's own (same seed), drawn on the
+    GPU and copied to the host (15 GB bf16 -> 30 GB fp32).  Needs a host with >= 64 GB free."""
+    from moshi_amd.config import LMConfig
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle
+    cfg = LMConfig()
+    t0 = time.perf_counter()
+    sd = random_lm_state_dict(cfg, seed=4242, device=dev)
+    sd = {k: v.cpu() for k, v in sd.items()}
+    torch.cuda.empty_cache()
+    o = LMOracle(sd, cfg)
+    del sd
+    o.streaming(1)
+    t_build = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    o.step(rng.integers(0, cfg.card, (1, 8, 1)), use_sampling=False)
+    ts = []
+    for _ in range(timed):
+        codes = rng.integers(0, cfg.card, (1, 8, 1))
+        t0 = time.perf_counter()
+        o.step(codes, use_sampling=False)
+        ts.append(time.perf_counter() - t0)
+    del o
+    return float(np.median(ts)), ts, t_build
+
+
 def _host_info():
     ram = None
     try:
@@ -163,7 +255,20 @@ def _host_info():
     return os.cpu_count(), ram
 
 
-def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5):
+def _reference_quote():
+    """The reference ITSELF cannot travel to the GPU box (no copy of its sources is kept here): its own CPU path, timed on the
+    build container by scripts/reference_cpu_baseline.py (recipe of scripts/moshi_benchmark.py:76-100), is quoted beside the port."""
+    rp = Path(__file__).resolve().parent / "profiles" / "r03_logs" / "reference_cpu_baseline.json"
+    if not rp.exists():
+        return None
+    rd = json.loads(rp.read_text())
+    return {"value": rd["duplex_b1_frames_per_s"], "unit": "frames/s", "cores": rd["host"]["cores"], "cpu": rd["host"]["cpu"],
+            "measured_on": rd["host"].get("where", "build container"), "mimi_b1_ms": rd["mimi_b1"], "mimi_b8_ms": rd["mimi_b8"],
+            "lm_7b_bf16_b1_step_ms": rd["lm_7b_bf16_b1"]["step_p50_ms"],
+            "note": "kyutai-labs/moshi PyTorch CPU path, B=1, NOT measured in this run (committed: profiles/r03_logs/reference_cpu_baseline.json)"}
+
+
+def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5, dev=None):
     """`port` baseline for the full frame on the host cores: the numpy oracles (the reference itself cannot travel to the GPU
     box).  Mimi is timed directly (mimi_base); the LM oracle (fp32, B=1, full depformer and text head) is timed at two reduced
     depths - median of `timed` steps after one warm-up step each, the temporal stack (`forward_text`) also on its own clock -
@@ -172,6 +277,18 @@ def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5):
     from moshi_amd.config import LMConfig
     from moshi_amd.weights import random_lm_state_dict
     from oracle.lm_oracle import LMOracle
+    # the full 32-layer oracle, MEASURED, whenever the host can hold it; the layer-scaled proxy below is the
+    # fallback SURVEY.md 8d describes for a host that cannot (or a run with --lm-layers / MMI_BENCH_CPU_PROXY=1)
+    if dev is not None and not args.lm_layers and not os.environ.get("MMI_BENCH_CPU_PROXY") and _mem_available_gib() >= 64:
+        lm_s, ts, t_build = cpu_lm_measured(dev)
+        mimi_s = 1.0 / mimi_base["value"]
+        cores, ram = _host_info()
+        return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": cores, "host_ram_gib": ram, "kind": "port",
+                "reference_on_build_host": _reference_quote(),
+                "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle (fp32 numpy): 32 layers, measured - "
+                           f"the whole Moshi-7B step (32 temporal layers, text head, 8 x 6 depth-transformer layers), 1 warm-up + median of "
+                           f"{len(ts)} steps = {lm_s:.3f} s ({', '.join(f'{t:.3f}' for t in ts)}); weights drawn on the GPU and widened to fp32 on "
+                           f"the host in {t_build:.0f} s (not timed)")}
     times, text_times = {}, {}
     for nl in layers:
         cfg = LMConfig(num_layers=nl, context=64)
@@ -205,16 +322,7 @@ def cpu_baseline_duplex(mimi_base, args, layers=(1, 5), timed=5):
     lm_s = times[lo] + (full_layers - lo) * per_layer
     mimi_s = 1.0 / mimi_base["value"]
     cores, ram = _host_info()
-    # the reference ITSELF cannot travel to the GPU box (no copy of its sources is kept here): its own CPU path, timed on the
-    # build container by scripts/reference_cpu_baseline.py (recipe of scripts/moshi_benchmark.py:76-100), is quoted beside the port
-    ref = None
-    rp = Path(__file__).resolve().parent / "profiles" / "r03_logs" / "reference_cpu_baseline.json"
-    if rp.exists():
-        rd = json.loads(rp.read_text())
-        ref = {"value": rd["duplex_b1_frames_per_s"], "unit": "frames/s", "cores": rd["host"]["cores"], "cpu": rd["host"]["cpu"],
-               "measured_on": rd["host"].get("where", "build container"), "mimi_b1_ms": rd["mimi_b1"], "mimi_b8_ms": rd["mimi_b8"],
-               "lm_7b_bf16_b1_step_ms": rd["lm_7b_bf16_b1"]["step_p50_ms"],
-               "note": "kyutai-labs/moshi PyTorch CPU path, B=1, NOT measured in this run (committed: profiles/r03_logs/reference_cpu_baseline.json)"}
+    ref = _reference_quote()
     return {"value": 1.0 / (lm_s + mimi_s), "unit": "frames/s", "cores": cores, "host_ram_gib": ram, "kind": "port", "reference_on_build_host": ref,
             "sample": (f"B=1: Mimi oracle {mimi_s*1e3:.0f} ms/frame ({mimi_base['sample']}); LM oracle (fp32 numpy) median of "
                        f"{timed} steps at {lo} and {hi} temporal layers + full depformer and text head ({times[lo]:.3f} s, "

@@ -28,11 +28,17 @@ def broadcast_state_dict(state_dict: Optional[Dict[str, torch.Tensor]], spec: Sp
 
     `spec` is what `moshi_amd.weights.lm_state_spec` / `mimi_state_spec` return, so that the receiving ranks can allocate
     without any metadata exchange.  Returns the full state dict on every rank (on `device`)."""
+    import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    # MMI_FORCE_BCAST (test switch; tests/test_loaders_gpu.py): "1" = run the bucket pack + collective even when the job has one
+    # rank (so the device path executes on a 1-GPU box); "recv" = this rank also UNPACKS like a receiver (its result is the
+    # views into the buckets, not its own tensors)
+    force = os.environ.get("MMI_FORCE_BCAST", "")
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         assert state_dict is not None
         return state_dict
     rank = dist.get_rank(group)
+    as_receiver = force == "recv"
     esize = torch.empty((), dtype=dtype).element_size()
     per_bucket = max(1, bucket_bytes // esize)
     out: Dict[str, torch.Tensor] = {}
@@ -61,6 +67,6 @@ def broadcast_state_dict(state_dict: Optional[Dict[str, torch.Tensor]], spec: Sp
         for name, shape in items:
             n = _numel(shape)
             # the source keeps its own tensors (the bucket is scratch there); receivers keep views into the bucket
-            out[name] = state_dict[name] if rank == src else flat[at:at + n].view(shape)
+            out[name] = state_dict[name] if (rank == src and not as_receiver) else flat[at:at + n].view(shape)
             at += n
     return out

@@ -90,6 +90,11 @@ def test_bench_spawns_its_own_ranks():
     # the latency figure is the job's: MAX over ranks (rank 1 pretends to be 1 ms slower), the per-rank figures alongside
     assert out["p50_ms_per_step"] == 6.0 and out["p95_ms_per_step"] == 7.0
     assert out["p50_ms_per_rank"] == [5.0, 6.0] and out["p95_ms_per_rank"] == [6.0, 7.0]
+    # per-rank step time beside the job's (rank 0: 0.5 s, rank 1: 0.75 s over 10 steps), and each rank's host thread pinned to
+    # its own block of cores
+    assert out["ms_per_step_per_rank"] == [50.0, 75.0] and out["ms_per_step"] == 75.0
+    cores = out["host_first_core_per_rank"]
+    assert len(cores) == 2 and (cores[0] != cores[1] or len(os.sched_getaffinity(0)) < 2)
 
 
 def test_bench_refuses_more_gpus_than_visible():

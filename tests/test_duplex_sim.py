@@ -139,3 +139,63 @@ def test_a_hooked_lmgen_is_refused(sim_lib):
         with pytest.raises(NotImplementedError):
             dup.step(x)
         dup.close()
+
+
+def _replica(rank, out):
+    """One of N replicas of the deployment (one process per GPU, swarm-config.yml:57-63), on the simulator: the pipelined frame
+    loop of tests/duplex_cases.py, with the host thread pinned like bench.py pins it."""
+    import hashlib
+    import os
+    import sys
+    from pathlib import Path
+    import numpy as np
+    import torch
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    os.environ["HIPSIM_WORKERS"] = "2"
+    torch.set_num_threads(1)
+    import bench
+    from moshi_amd import _capi
+    from moshi_amd.lm import LMGen
+    from tests import duplex_cases
+    from tests.batcher_cases import tiny_pair
+    from tests.hipsim.build_sim import LIB
+    bench.pin_host_thread(rank, 8)
+    lib = _capi.load(LIB)
+    B, steps = 2, 7
+    mimi, lm, mcfg, _ = tiny_pair("cpu", lib, B)
+    rng = np.random.default_rng(7)
+    frames = [(0.1 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32) for _ in range(steps)]
+    gen = LMGen(lm, use_sampling=True, temp=0.8, temp_text=0.7, top_k=5, top_k_text=5, seed=99)
+    with mimi.streaming(B), gen.streaming(B):
+        res = duplex_cases._pipelined(mimi, gen, frames, {}, torch.device("cpu"), 3)
+    h = hashlib.sha256()
+    for r in res:
+        h.update(b"none" if r is None else r[0].tobytes() + r[1].tobytes())
+    out[rank] = h.hexdigest()
+
+
+def test_eight_replicas_in_eight_processes_stay_bit_identical_under_contention(sim_lib):
+    """the pipeline's gate is a host wait, so N ranks on one node are N host threads competing for cores.
+    Eight processes, each with its own simulator-backed DuplexStream over the same seeded session group, oversubscribing this
+    machine's cores: every replica must produce the very same tokens and PCM as the serial loop run alone."""
+    import hashlib
+    import numpy as np
+    import torch
+    import torch.multiprocessing as mp
+    from moshi_amd.lm import LMGen
+    from tests import duplex_cases
+    from tests.batcher_cases import tiny_pair
+    B, steps = 2, 7
+    mimi, lm, mcfg, _ = tiny_pair("cpu", sim_lib, B)
+    rng = np.random.default_rng(7)
+    frames = [(0.1 * rng.standard_normal((B, 1, mcfg.frame_size))).astype(np.float32) for _ in range(steps)]
+    gen = LMGen(lm, use_sampling=True, temp=0.8, temp_text=0.7, top_k=5, top_k_text=5, seed=99)
+    with mimi.streaming(B), gen.streaming(B):
+        ref = duplex_cases._serial(mimi, gen, frames, {}, torch.device("cpu"))
+    h = hashlib.sha256()
+    for r in ref:
+        h.update(b"none" if r is None else r[0].tobytes() + r[1].tobytes())
+    out = mp.Manager().dict()
+    mp.spawn(_replica, args=(out,), nprocs=8, join=True)
+    assert len(out) == 8 and set(out.values()) == {h.hexdigest()}, dict(out)
