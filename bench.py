@@ -50,10 +50,11 @@ def parse():
                     help="duplex workload: the reference's serving loop on ONE stream (encode -> step -> decode back to back) instead of "
                          "the three-stream pipeline of mmi_duplex_* (encode(t+1) and decode(t-1) under LMGen.step(t))")
     ap.add_argument("--lm-layers", type=int, default=0, help="debug: override the number of temporal layers (invalidates the result)")
-    ap.add_argument("--kv-depth", default="mid", choices=["mid", "start"],
+    ap.add_argument("--kv-depth", default="mid", choices=["mid", "start", "full"],
                     help="mid (default): before the warm-up every session is moved (mmi_lm_seek) to the MIDPOINT of the configuration's run "
                          "(SURVEY.md 8d: C4 = 500 steps, sessions 8 frames apart -> ring depth 250 + 8 b; C3 = 300 steps -> depth 150), so "
-                         "the measured step does not depend on --steps; start: sessions start at depth 8 b (rounds 1-3)")
+                         "the measured step does not depend on --steps; start: sessions start at depth 8 b (rounds 1-3); "
+                         "full: every ring full (depth = context, 3000)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra figures of the default line: `full_context` (every session 3000 positions deep) and `c3` (one session)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank's host thread to its own block of cores")
@@ -359,9 +360,12 @@ def main():
     # kernels read them all the same (no data-dependent control flow), and the codec's rings are where the stagger left them
     # (rows >= 16 of 32 are past their 250-slot wrap).  "start": what the stagger alone leaves (rounds 1-3).
     base_depth = [args.stagger * b if B > 1 else staggered for b in range(B)]
-    if lm_gen is not None and args.kv_depth == "mid":
+    if lm_gen is not None and args.kv_depth != "start":
         join()
-        base_depth = [250 + args.stagger * b for b in range(B)] if B > 1 else [150]
+        if args.kv_depth == "full":
+            base_depth = [lm_gen.lm_model.config.context] * B
+        else:
+            base_depth = [250 + args.stagger * b for b in range(B)] if B > 1 else [150]
         lm_gen.seek(base_depth)
     trace("staggered")
     for _ in range(args.warmup):
@@ -451,7 +455,8 @@ def main():
                    "session_stagger_frames": args.stagger if lm_gen is not None else 0,
                    "kv_depth": ({"mid": "sessions moved (mmi_lm_seek) to the midpoint of the configuration's run before the warm-up: ring depth "
                                         "250 + 8 b of SURVEY 8d C4's 500-step run (150 for the single session of C3); skipped ring rows hold zeros",
-                                 "start": "sessions start at depth 8 b (the stagger alone; rounds 1-3)"}[args.kv_depth] if lm_gen is not None else None),
+                                 "start": "sessions start at depth 8 b (the stagger alone; rounds 1-3)",
+                                 "full": "every session moved (mmi_lm_seek) to position `context`: all 3000 slots of every ring are read"}[args.kv_depth] if lm_gen is not None else None),
                    "kv_positions_at_start": ([base_depth[0], base_depth[-1]] if lm_gen is not None else None),
                    "kv_positions_at_end": ([base_depth[b] + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
     }

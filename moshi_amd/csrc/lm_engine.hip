@@ -574,14 +574,44 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
 
 // workgroups per (session, head) of the decode attention: 1 once B*H alone fills the chip, else split the ring
 int attn_splits(const mmi_lm_cfg& c, int B) {
+    if (const char* e = getenv("MMI_ATTN_NS")) {          // test hook: the split + combine path on rings too short to need it
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) return v;
+    }
     const int chunks = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
     int want = 1024 / (B * c.num_heads);
     if (want < 1) want = 1;
     return want < chunks ? want : chunks;
 }
 
+// MMI_ATTN: "wave" (default since round 4) = k_lm_attn_wave, one online softmax per wave, no barrier in the loop; "split" = the
+// chunked kernel of rounds 1-3 (same-box A/Bs)
+static bool attn_wave_kernel() {
+    const char* e = getenv("MMI_ATTN");
+    return !(e && e[0] == 's');
+}
+
 int launch_attn_split(hipStream_t s, const LmAttnArgs& a, bool kv8) {
     dim3 grid(a.B * a.H, a.NS);
+    if (attn_wave_kernel()) {
+        if (kv8) {
+            switch (a.Dh) {
+                case 128: MMI_LAUNCH((k_lm_attn_wave<128, true>), grid, 256, 0, s, a); break;
+                case 64: MMI_LAUNCH((k_lm_attn_wave<64, true>), grid, 256, 0, s, a); break;
+                case 32: MMI_LAUNCH((k_lm_attn_wave<32, true>), grid, 256, 0, s, a); break;
+                default: return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be 32, 64 or 128");
+            }
+        } else {
+            switch (a.Dh) {
+                case 128: MMI_LAUNCH((k_lm_attn_wave<128>), grid, 256, 0, s, a); break;
+                case 64: MMI_LAUNCH((k_lm_attn_wave<64>), grid, 256, 0, s, a); break;
+                case 32: MMI_LAUNCH((k_lm_attn_wave<32>), grid, 256, 0, s, a); break;
+                default: return mmi_fail(MMI_ERR_UNSUPPORTED, "head dim must be 32, 64 or 128");
+            }
+        }
+        MMI_CHECK_LAUNCH();
+        return MMI_OK;
+    }
     if (kv8) {
         switch (a.Dh) {
             case 128: MMI_LAUNCH((k_lm_attn_split<128, true>), grid, 256, 0, s, a); break;

@@ -1273,6 +1273,164 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
     }
 }
 
+// The same attention with ONE online softmax per lane group and no workgroup barrier inside the loop (round 4).  k_lm_attn_split
+// walks a 256-row chunk in four dependent memory round trips (keys x 2, softmax through LDS, values x 2) with three barriers
+// in between, and all of a CU's co-resident workgroups do so in lockstep: at the benchmark's ring depths (150 ... 550 rows per
+// head) the kernel is bound by those round trips, not by HBM (23 us for 78 MB).  Here the ring's rows are dealt out in
+// row groups (one wave instruction = RPW consecutive rows = 1 KiB) round-robin over ALL waves that serve the (session, head)
+// pair - 4 per workgroup x gridDim.y workgroups - and every wave keeps, per row slot (the lanes that share `rsub`), its own
+// running (max, sum, accumulator): a round requests NB key groups AND their NB value groups at once (the values do not depend
+// on the scores), the next round's 2 NB loads are issued before this round's arithmetic, and nothing but registers and
+// cross-lane shuffles is touched until the slots and the waves are merged once at the end.
+template <int DH, bool KV8 = false>
+__global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a) {      // bf16 ring: <= 128 VGPRs, 4 workgroups per CU
+    constexpr int EPL = KV8 ? 16 : 8;  // elements per lane (16 bytes)
+    constexpr int ES = KV8 ? 1 : 2;    // bytes per element
+    constexpr int LPR = DH / EPL;      // lanes per row
+    constexpr int RPW = 64 / LPR;      // rows per wave instruction
+    constexpr int NB = 4;              // row groups per round (x 2 buffers x (key + value) = 16 loads of 16 bytes in flight per lane)
+    const int bh = blockIdx.x;
+    const int b = bh / a.H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long off = a.offsets[b];
+    const int end_index = (int)(off % a.cap);
+    const long end_new = off + 1;
+    const int L = (int)(end_new < (long)a.cap ? end_new : (long)a.cap);
+    const int seg = lane % LPR, rsub = lane / LPR;
+    float qv[EPL];
+#pragma unroll
+    for (int v = 0; v < EPL / 8; ++v) {
+        u32x4 qq = *reinterpret_cast<const u32x4*>(a.qrot + (long)bh * DH + seg * EPL + v * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            qv[v * 8 + 2 * q] = mmi_bf16_to_f32((uint16_t)(qq[q] & 0xffffu));
+            qv[v * 8 + 2 * q + 1] = mmi_bf16_to_f32((uint16_t)(qq[q] >> 16));
+        }
+    }
+    auto widen = [](const u32x4& r, float* f) {
+        if constexpr (KV8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mmi_fp8x4_to_f32(r[q], f + 4 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f[2 * q] = mmi_bf16_to_f32((uint16_t)(r[q] & 0xffffu));
+                f[2 * q + 1] = mmi_bf16_to_f32((uint16_t)(r[q] >> 16));
+            }
+        }
+    };
+    // wave-uniform base (scalar registers) + a 32-bit lane offset: the loads take the saddr form, no 64-bit address per lane
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * DH * ES;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
+    const unsigned loff = (unsigned)(seg * EPL * ES);
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int total = (int)gridDim.y * 4, wg = (int)blockIdx.y * 4 + wave;       // waves serving this pair, and which one this is
+    const int ngroups = (L + RPW - 1) / RPW;
+    const int nmine = wg < ngroups ? (ngroups - wg + total - 1) / total : 0;       // row groups wg, wg + total, ...
+    const int nrounds = (nmine + NB - 1) / NB;
+    float m_run = -INFINITY, l_run = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    u32x4 kA[NB], vA[NB], kB[NB], vB[NB];
+    // every load is unconditional from a clamped (valid) slot - a load under a branch would be serialised behind
+    // s_waitcnt vmcnt(0) - and rows past the end carry probability 0
+#define MMI_AW_LOAD(KK, VV, j0)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                            \
+        const int slot_ = min((wg + ((j0) + i) * total) * RPW + rsub, L - 1);                   \
+        const unsigned o_ = (unsigned)slot_ * (unsigned)(DH * ES) + loff;                       \
+        KK[i] = *reinterpret_cast<const u32x4*>(kbase + o_);                                    \
+        VV[i] = *reinterpret_cast<const u32x4*>(vbase + o_);                                    \
+    }
+#define MMI_AW_USE(KK, VV, j0)                                                                   \
+    {                                                                                            \
+        float s_[NB];                                                                            \
+        float mx_ = -INFINITY;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                        \
+            const int j_ = (j0) + i;                                                             \
+            const int slot_ = (wg + j_ * total) * RPW + rsub;                                    \
+            bool valid_ = j_ < nmine && slot_ < L;                                               \
+            if (valid_) {   /* absolute position of the slot (transformer.py:258-286), causal / context mask (:574-582) */ \
+                const int delta_ = slot_ - end_index;                                            \
+                const long pos_ = delta_ <= 0 ? off + delta_ : off + delta_ - a.cap;             \
+                const long dq_ = off - pos_;                                                     \
+                valid_ = pos_ >= 0 && dq_ >= 0 && dq_ < a.context;                               \
+            }                                                                                    \
+            float kf_[EPL];                                                                      \
+            widen(KK[i], kf_);                                                                   \
+            float dot_ = 0.f;                                                                    \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot_ += qv[e] * kf_[e];             \
+            _Pragma("unroll") for (int mk = LPR / 2; mk >= 1; mk >>= 1) dot_ += mmi_shfl_xor(dot_, mk); \
+            s_[i] = valid_ ? dot_ * scale : -INFINITY;                                           \
+            mx_ = fmaxf(mx_, s_[i]);                                                             \
+        }                                                                                        \
+        const float m_new_ = fmaxf(m_run, mx_);                                                  \
+        if (m_new_ != -INFINITY) {                                                               \
+            const float resc_ = m_run == -INFINITY ? 0.f : expf(m_run - m_new_);                 \
+            l_run *= resc_;                                                                      \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] *= resc_;                    \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                    \
+                const float p_ = expf(s_[i] - m_new_);        /* exp(-inf) = 0 for masked rows */ \
+                l_run += p_;                                                                     \
+                float vf_[EPL];                                                                  \
+                widen(VV[i], vf_);                                                               \
+                _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] += p_ * vf_[e];          \
+            }                                                                                    \
+            m_run = m_new_;                                                                      \
+        }                                                                                        \
+    }
+    if (nrounds > 0) {
+        MMI_AW_LOAD(kA, vA, 0)
+        for (int r = 0; r < nrounds; r += 2) {
+            MMI_AW_LOAD(kB, vB, (r + 1) * NB)          // clamped past the end: re-reads the last row (cache hit), masked on use
+            MMI_AW_USE(kA, vA, r * NB)
+            MMI_AW_LOAD(kA, vA, (r + 2) * NB)
+            MMI_AW_USE(kB, vB, (r + 1) * NB)
+        }
+    }
+#undef MMI_AW_LOAD
+#undef MMI_AW_USE
+    // ---- merge the RPW row slots of the wave (lanes that share `seg`): butterflies over the slot bits
+#pragma unroll
+    for (int mk = LPR; mk < 64; mk <<= 1) {
+        const float mo = mmi_shfl_xor(m_run, mk), lo = mmi_shfl_xor(l_run, mk);
+        const float mn = fmaxf(m_run, mo);
+        const float sa = m_run == -INFINITY ? 0.f : expf(m_run - mn), sb = mo == -INFINITY ? 0.f : expf(mo - mn);
+        l_run = l_run * sa + lo * sb;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * sa + mmi_shfl_xor(acc[e], mk) * sb;
+        m_run = mn;
+    }
+    // ---- merge the 4 waves through LDS (the only barrier of the kernel)
+    MMI_SHARED float wm[4], wl[4];
+    MMI_SHARED float wacc[4 * DH];
+    if (rsub == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) wacc[wave * DH + seg * EPL + e] = acc[e];
+        if (seg == 0) { wm[wave] = m_run; wl[wave] = l_run; }
+    }
+    __syncthreads();
+    if (tid < DH) {
+        const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sw = wm[w] == -INFINITY ? 0.f : expf(wm[w] - M);
+            num += sw * wacc[w * DH + tid];
+            den += sw * wl[w];
+        }
+        if (gridDim.y == 1) {
+            a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
+        } else {
+            a.opart[((long)bh * gridDim.y + blockIdx.y) * DH + tid] = num;
+            if (tid == 0) {
+                float* mlp = a.ml + ((long)bh * gridDim.y + blockIdx.y) * 2;
+                mlp[0] = M;
+                mlp[1] = den;
+            }
+        }
+    }
+}
+
 // merge the chunk partials: out = sum_c e^{m_c-M} O_c / sum_c e^{m_c-M} l_c  -> bf16 [B][H*Dh]
 __global__ void k_lm_attn_combine(LmAttnArgs a) {
     const int bh = blockIdx.x;

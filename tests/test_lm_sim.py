@@ -47,6 +47,16 @@ def test_wide_batch_tiles_match_oracle(sim_lib, B):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=60 + B, B=B, S=3)
 
 
+@pytest.mark.parametrize("kernel", ["wave", "split"])
+def test_attention_ring_split_over_several_workgroups(sim_lib, monkeypatch, kernel):
+    """Fewer (session, head) pairs than CUs (one real-time session: 32 pairs): the ring is shared out over several workgroups
+    per pair and their partial (max, sum, output) merged by k_lm_attn_combine - forced here on the tiny model, for the
+    barrier-free kernel of round 4 and the chunked one it replaces."""
+    monkeypatch.setenv("MMI_ATTN_NS", "3")
+    monkeypatch.setenv("MMI_ATTN", kernel)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=61, B=2, S=9)
+
+
 def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     """The K-split GEMM path (fp32 partials folded into the residual stream by k_resid_rmsnorm) that the 4096-wide
     layers take at 17..64 sessions, forced onto the tiny shapes."""
