@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger", type=int, default=8, help="frames between session starts (SURVEY.md 8d C4)")
     ap.add_argument("--quant", default="none", choices=["none", "q8", "fp8"],
-                    help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears widened to bf16 in registers; fp8 = e4m3 linears on the fp8 MFMA")
+                    help="BASELINE configs[4] weight formats: q8 = row-wise int8 linears x row-wise int8 activations on the int8 MFMA (the reference's "
+                         "bitsandbytes rule; MMI_Q8_ACT=bf16 in the environment: weight-only, widened to bf16 in registers); fp8 = e4m3 linears on the fp8 MFMA")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "fp8"], help="KV ring of the temporal transformer: the reference's bf16, or e4m3 (half the attention stream)")
     ap.add_argument("--launch-lists", default="", help="directory to write the step's launch lists (site per kernel launch) into, for scripts/rocpd_sites.py")
     ap.add_argument("--serial", action="store_true",
@@ -438,7 +439,7 @@ def main():
                           "note": "each rank's main thread (the duplex pipeline's host-kept gate) and the HIP runtime threads it starts are "
                                   "confined to a disjoint block of cores; -1 = not pinned"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"none": "bf16", "q8": "bf16 x int8 weights", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
+        "dtype": {"none": "bf16", "q8": ("bf16 x int8 weights (weight-only)" if os.environ.get("MMI_Q8_ACT", "")[:1] == "b" else "int8 weights x int8 activations (int32 accumulate), bf16 elsewhere"), "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)"}[args.quant] if workload != "mimi" else "f32", "data": "synthetic",
         "config": {"workload": {"duplex": "full duplex Mimi enc -> Moshi-7B LMGen.step -> Mimi dec (BASELINE configs[3])",
                                 "mimi": "Mimi streaming encode+RVQ+decode (BASELINE configs[1])",
                                 "lm": "Moshi-7B LMGen.step (BASELINE configs[2])"}[workload],

@@ -88,6 +88,17 @@ struct mmi_lm {
     float *opart = nullptr, *ml = nullptr;
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
+    // int8 activations (BASELINE configs[4], the reference's own arithmetic: QLinear.forward -> bitsandbytes' int8 x int8 matmul,
+    // utils/quantize.py:24-40): on for int8 linears unless MMI_Q8_ACT=bf16 (weight-only, rounds 1-3) or the model has
+    // cross-attention layers.  xnq / attq / hbq / toutq: the int8 operand Xq[mt][kp][lane][16] next to its bf16 tensor;
+    // sx_*: the rows' absmax (SCA) where ONE workgroup sees the whole row (the norm kernel); amax_pool: one slot [rows] per
+    // producing site of the step whose row is spread over workgroups (attention, gated epilogue, ...), folded with atomic max
+    // and zeroed by one memset at the head of the step.
+    bool act8 = false;
+    uint8_t *xnq = nullptr, *attq = nullptr, *hbq = nullptr, *toutq = nullptr, *dxnq = nullptr;
+    float *sx_xn = nullptr, *sx_tout = nullptr, *sx_dxn = nullptr;
+    float* amax_pool = nullptr;
+    int amax_slots = 0, amax_used = 0, amax_rows = 0;
     bool hidden_taps = false;                       // mmi_lm_set_hidden_taps: the next streaming_start adds the two copies below
     uint16_t* htap = nullptr;                       // [2][B][dim] residual stream after the first / the last temporal layer
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
@@ -286,6 +297,8 @@ template <int TN, int MT, int NTW>
 int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, int wq, const GemmArgs& a) {
     if (wq == 1) return launch_gemm_q<TN, MT, NTW, 1>(s, groups, waves, a);
     if (wq == 2) return launch_gemm_q<TN, MT, NTW, 2>(s, groups, waves, a);
+    if (wq == 3) return launch_gemm_q<TN, MT, NTW, 3>(s, groups, waves, a);
+    if (wq == 4) return launch_gemm_q<TN, MT, NTW, 4>(s, groups, waves, a);
     if (waves == 8 && u == 2 && MT * NTW == 1) {
         if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
         MMI_CHECK_LAUNCH();
@@ -321,12 +334,12 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
     const char mode = en && en[0] ? en[0] : (g.wq == 0 ? '2' : '0');
-    if (mode == '0' || lm->T != 32 || mt > 2) return p;
+    if (mode == '0' || lm->T != 32 || mt > 2 || a.wq == 4) return p;
     if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
     if (tg && atoi(tg) > 0) cus = atoi(tg);
-    const int xs = g.wq ? 2 : 1;                               // activation fragments per weight entry
+    const int xs = (g.wq && a.wq != 3) ? 2 : 1;                // activation fragments per weight entry (int8 activations: one entry)
     const int big = (g.wq ? 32 : 64) / mt;                     // 64 KiB of activations per chunk buffer
     if (g.KSTEPS % big == 0 && g.NT >= 128) p.kc = big;       // the large temporal GEMMs
     else if (tg && g.KSTEPS % 8 == 0) p.kc = 8;
@@ -372,13 +385,15 @@ template <int MT>
 int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
     if (a.wq == 1) return launch_xlds_kc<MT, false, 1>(s, p, a);
     if (a.wq == 2) return launch_xlds_kc<MT, false, 2>(s, p, a);
+    if (a.wq == 3) return launch_xlds_kc<MT, false, 3>(s, p, a);
     return p.stagger ? launch_xlds_kc<MT, true, 0>(s, p, a) : launch_xlds_kc<MT, false, 0>(s, p, a);
 }
 
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
-    a.wq = g.wq; a.xinv = g.xinv;
+    a.wq = (g.wq == 1 && a.wq >= 3) ? a.wq : g.wq;             // int8 linears: 3 / 4 = int8 activations (set by the program builder)
+    a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
     a.osplit = plan_osplit(g, p, a.epi, lm->T);
@@ -423,13 +438,23 @@ size_t packed_elems(const mmi_lm* lm, int features) {
 // x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
 // MMI_EPI_DEP_QKV0 (the depth transformer's in_proj at micro-step 0): where its epilogue writes k / v (frame cache, position 0)
 struct DepKv { uint16_t* kc; uint16_t* vc; int H, Dh, steps; };
+// int8 activations of one GEMM (lm->act8): wq 3 = `x` is the int8 operand Xq and sx its rows' absmax; wq 4 = `x` is the bf16
+// tensor, quantised inside the GEMM with the absmax sx the producer left behind; amax_out = fold the absmax of THIS GEMM's output
+struct Q8 { int wq = 0; const float* sx = nullptr; float* amax_out = nullptr; };
+
+// a fresh absmax slot [rows] of the step's pool (zeroed by the memset at the head of the program)
+float* new_amax_slot(mmi_lm* lm) {
+    if (!lm->act8 || lm->amax_used >= lm->amax_slots) return nullptr;
+    return lm->amax_pool + (size_t)(lm->amax_used++) * lm->amax_rows;
+}
 
 void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
               const uint16_t* resid, const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0,
-              bool dominant = false, const DepKv* kv = nullptr) {
+              bool dominant = false, const DepKv* kv = nullptr, const Q8* q8 = nullptr) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
+    if (q8) { a.wq = q8->wq; a.sx = q8->sx; a.amax_out = q8->amax_out; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
     a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
@@ -441,14 +466,15 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
 
 // K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
 // Returns the number of partials, 0 when the GEMM is not split (then it applied the residual itself, in place on x).
-int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features) {
+int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features, const Q8* q8 = nullptr) {
     const GemmPlan p = plan_gemm(g, true);
     if (p.ksplit <= 1) {
-        add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x);
+        add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x, nullptr, nullptr, 0, false, nullptr, q8);
         return 0;
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
+    if (q8) { a.wq = q8->wq; a.sx = q8->sx; }                  // (no absmax of a split-K partial: the norm that folds it has the row)
     a.xp = reinterpret_cast<const u32x4*>(in); a.epi = MMI_EPI_PARTIAL; a.partial = lm->partial; a.B = lm->batch;
     GemmW gw = g;
     lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); }, (long)g.bytes);
@@ -456,13 +482,14 @@ int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, 
 }
 
 // x (+= the P pending split-K partials), y = rms_norm(x) * alpha
-void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, uint16_t* y, int D) {
+// yq / sx: also store the row quantised row-wise to int8 (+ its absmax) for the int8 linears that read it (lm->act8)
+void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, uint16_t* y, int D, uint8_t* yq = nullptr, float* sx = nullptr) {
     const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, D);
     const float* partial = lm->partial;
     lm->prog.add([=](hipStream_t s) {
         int nth = mmi_cdiv(D / 8, 64) * 64;            // one 16-byte piece per thread where the row allows it
         if (nth > 1024) nth = 1024;
-        MMI_LAUNCH(k_resid_rmsnorm, B, nth, 0, s, x, partial, P, B, alpha, y, D, T, ksteps, 1e-8f);
+        MMI_LAUNCH(k_resid_rmsnorm, B, nth, 0, s, x, partial, P, B, alpha, y, D, T, ksteps, 1e-8f, yq, sx);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -483,17 +510,27 @@ void add_hidden_tap(mmi_lm* lm, int which) {
 
 // RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
+// amax_out (lm->act8): fold the absmax of the GEMM's OUTPUT rows into that slot; the input is quantised inside (fused: the
+// workgroup holds the whole normalised row) or by the norm launch
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
-                   int out_features, bool out_packed, int epi, const DepKv* kv = nullptr) {
-    const int wq = g.wq;
+                   int out_features, bool out_packed, int epi, const DepKv* kv = nullptr, float* amax_out = nullptr) {
+    const bool a8 = lm->act8 && g.wq == 1;
+    const int wq = a8 ? 3 : g.wq;
     const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
+        if (a8) {
+            add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn);
+            Q8 q{3, lm->sx_dxn, amax_out};
+            add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->dxnq), out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv, &q);
+            return;
+        }
         add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
         add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv);
         return;
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
+    a.amax_out = amax_out;
     if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
@@ -502,7 +539,7 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.alpha = alpha; a.D = D; a.eps = 1e-8f;
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
-    a.wq = g.wq; a.xinv = g.xinv;
+    a.wq = wq; a.xinv = g.xinv;
     a.osplit = 1;
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     const long gbytes = (long)g.bytes;
@@ -512,6 +549,10 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
             else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
+        } else if (wq == 3) {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 3>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 3>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 3>), NT, 512, 0, s, a);
         } else if (wq == 2) {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 2>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 2>), NT, 512, 0, s, a);
@@ -524,6 +565,17 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     }, gbytes);
+}
+
+// bf16 packed tensor + its rows' absmax -> the int8 operand (lm->act8; one small chip-wide launch)
+void add_quant_apply(mmi_lm* lm, const uint16_t* xp, const float* sx, uint8_t* xq, int features) {
+    const int B = lm->batch, T = lm->T, MT = mmi_cdiv(B, T), kp = packed_ksteps(lm, features) / 2;
+    lm->prog.add([=](hipStream_t s) {
+        MMI_LAUNCH(k_quant_apply_i8, mmi_cdiv(MT * kp * 64, 256), 256, 0, s, reinterpret_cast<const u32x4*>(xp), sx,
+                   reinterpret_cast<u32x4*>(xq), B, T, kp, MT);
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    });
 }
 
 // next_k >= 0: the sampled token opens depth-transformer micro-step next_k, whose input row the sampler writes itself
@@ -646,8 +698,14 @@ int build_program(mmi_lm* lm) {
     const int dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
     const int n_user = c.n_q - c.dep_q;
     MmiProgram& P = lm->prog;
+    const bool a8 = lm->act8;
+    lm->amax_used = 0;
     // ---- token ring in, embeddings
     P.site("prepare");
+    if (a8) {   // the step's absmax slots start at 0 (|x| >= 0: the identity of the atomic max)
+        float* pool = lm->amax_pool; const size_t nb = (size_t)lm->amax_slots * lm->amax_rows * sizeof(float);
+        P.add([=](hipStream_t s) { MMI_HIP_CHECK(hipMemsetAsync(pool, 0, nb, s)); return (int)MMI_OK; });
+    }
     {
         TokArgs t = tok_args(lm);
         const int* user = lm->user_i32; int* tokens = lm->tokens;
@@ -675,18 +733,20 @@ int build_program(mmi_lm* lm) {
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
         P.site("L.norm1");
-        add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d);
+        add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d, a8 ? lm->xnq : nullptr, a8 ? lm->sx_xn : nullptr);
         if (l == 1) add_hidden_tap(lm, 0);     // x is complete (the previous linear_out's partials folded in) right after this norm
         LmAttnArgs a;
         a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
+        a.amax = new_amax_slot(lm);             // int8 activations: the attention output's row absmax, for out_proj (null otherwise)
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
             memset(&ga, 0, sizeof(ga));
             ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
+            if (a8) { ga.xp = reinterpret_cast<const u32x4*>(lm->xnq); ga.sx = lm->sx_xn; ga.wq = 3; }
             ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context; ga.kv8 = kv8 ? 1 : 0;
             ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
@@ -701,6 +761,11 @@ int build_program(mmi_lm* lm) {
             return (int)MMI_OK;
         });
         P.site("L.out_proj");
+        if (a8) {
+            add_quant_apply(lm, lm->att, a.amax, lm->attq, d);
+            Q8 q{3, a.amax, nullptr};
+            pending = add_gemm_resid(lm, L.out_proj, reinterpret_cast<const uint16_t*>(lm->attq), lm->x, d, &q);
+        } else
         pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
         if (c.cross_attention) {   // x = x + cross_attention(norm_cross(x), src, src) (transformer.py:779-786)
             P.site("L.norm_cross");
@@ -733,24 +798,39 @@ int build_program(mmi_lm* lm) {
             pending = add_gemm_resid(lm, L.x_out, lm->att, lm->x, d);
         }
         P.site("L.norm2");
-        add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d);
+        add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d, a8 ? lm->xnq : nullptr, a8 ? lm->sx_xn : nullptr);
         P.site("L.ffn_in");
+        if (a8) {
+            float* shb = new_amax_slot(lm);       // the gated tensor's row absmax, folded by linear_in's epilogue, read by linear_out
+            Q8 qi{3, lm->sx_xn, shb};
+            add_gemm(lm, L.ffn_in, reinterpret_cast<const uint16_t*>(lm->xnq), lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0,
+                     /*dominant=*/true, nullptr, &qi);
+            P.site("L.ffn_out");
+            add_quant_apply(lm, lm->hb, shb, lm->hbq, c.ffn_hidden);
+            Q8 qo{3, shb, nullptr};
+            pending = add_gemm_resid(lm, L.ffn_out, reinterpret_cast<const uint16_t*>(lm->hbq), lm->x, d, &qo);
+            continue;
+        }
         add_gemm(lm, L.ffn_in, lm->xn, lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0, /*dominant=*/true);
         P.site("L.ffn_out");
         pending = add_gemm_resid(lm, L.ffn_out, lm->hb, lm->x, d);
     }
     P.site("out_norm");
-    add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d);
+    add_resid_rmsnorm(lm, lm->x, pending, lm->out_norm, lm->tout, d, a8 ? lm->toutq : nullptr, a8 ? lm->sx_tout : nullptr);
     if (c.num_layers == 1) add_hidden_tap(lm, 0);
     add_hidden_tap(lm, 1);
+    // the int8 linears that read transformer_out (text head, depformer_in) take its int8 copy
+    const uint16_t* tout_in = a8 ? reinterpret_cast<const uint16_t*>(lm->toutq) : lm->tout;
+    const Q8 q_tout{3, lm->sx_tout, nullptr};
+    const Q8* qt = a8 ? &q_tout : nullptr;
     P.site("text_linear");
-    add_gemm(lm, lm->text_linear, lm->tout, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr);
+    add_gemm(lm, lm->text_linear, tout_in, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr, nullptr, nullptr, 0, false, nullptr, qt);
     // depformer_in[k](transformer_out) for every micro-step in one launch; each sampler then adds its token's embedding row
     // and writes the next micro-step's input (lm.py:465-470) - 8 dependent launches less on the sequential chain
     const bool grouped = lm->dep_in_grouped;
     lm->op_depformer = P.ops.size();
     P.site("dep.in_all");
-    if (grouped) add_gemm(lm, lm->dep_in_all, lm->tout, lm->dpre, c.dep_q * dd, false, MMI_EPI_STORE, nullptr);
+    if (grouped) add_gemm(lm, lm->dep_in_all, tout_in, lm->dpre, c.dep_q * dd, false, MMI_EPI_STORE, nullptr, nullptr, nullptr, 0, false, nullptr, qt);
     P.site("text_sample");
     add_sample(lm, lm->text_logits, c.text_card_out, c.text_card_out, true, 0, lm->text_tok, 1, grouped ? 0 : -1);
     // ---- depformer: dep_q sequential micro-steps
@@ -758,8 +838,9 @@ int build_program(mmi_lm* lm) {
     for (int k = 0; k < c.dep_q; ++k) {
         const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
         const int prev_stride = k == 0 ? 1 : c.dep_q;
+        float* s_lin = nullptr;          // absmax of the micro-step's final residual stream, for the logits head (int8 activations)
         P.site("dep.in");
-        if (!grouped) add_gemm(lm, lm->dep_in[k], lm->tout, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride);
+        if (!grouped) add_gemm(lm, lm->dep_in[k], tout_in, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride, false, nullptr, qt);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
             const DepLayerW& L = lm->dep_layers[l];
             P.site("dep.in_proj");
@@ -767,15 +848,21 @@ int build_program(mmi_lm* lm) {
             // epilogue writes k / v into the frame's cache and v as out_proj's operand, and the attention launch is dropped
             // (bit-identical: 1 * v / 1; MMI_DEP_ATTN0_LAUNCH=1 keeps the launch)
             const bool skip_attn0 = k == 0 && Dhd % 8 == 0 && !getenv("MMI_DEP_ATTN0_LAUNCH");
+            // int8 activations: the small linears of the chain quantise their bf16 input themselves (wq 4) with the row absmax
+            // their producer folded into a slot - the attention (or in_proj's epilogue at micro-step 0), the gated epilogue, and
+            // the last layer's residual epilogue for the logits head
+            float* s_att = new_amax_slot(lm);
+            float* s_hb = new_amax_slot(lm);
             if (skip_attn0) {
                 DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
-                add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv);
+                add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv, s_att);
             } else
             add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
+            da.amax = s_att;
             P.site("dep.attn");
             const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8;        // else the general one-wave-per-(session, head) kernel
             if (!skip_attn0)
@@ -785,16 +872,20 @@ int build_program(mmi_lm* lm) {
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
+            const bool last = l + 1 == c.depformer_num_layers;
+            if (a8 && last) s_lin = new_amax_slot(lm);
+            const Q8 q_att{4, s_att, nullptr}, q_hb{4, s_hb, last ? s_lin : nullptr};
             P.site("dep.out_proj");
-            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, nullptr, 0, false, nullptr, a8 ? &q_att : nullptr);
             P.site("dep.ffn_in");
-            add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE);
+            add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr, s_hb);
             P.site("dep.ffn_out");
-            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, nullptr, 0, false, nullptr, a8 ? &q_hb : nullptr);
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
+        const Q8 q_lin{4, s_lin, nullptr};
         P.site("dep.lin");
-        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr);
+        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr, nullptr, nullptr, 0, false, nullptr, a8 ? &q_lin : nullptr);
         P.site("dep.sample");
         add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q, grouped && k + 1 < c.dep_q ? k + 1 : -1);
     }
@@ -1120,6 +1211,28 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     lm->htap = nullptr;
     if (lm->hidden_taps) ok &= hipSuccess == A.alloc(&lm->htap, (size_t)2 * B * d);
+    {   // int8 activations (see mmi_lm::act8)
+        const char* e8 = getenv("MMI_Q8_ACT");
+        lm->act8 = lm->q8 == 1 && !c.cross_attention && !(e8 && e8[0] == 'b');
+        lm->xnq = lm->attq = lm->hbq = lm->toutq = lm->dxnq = nullptr;
+        lm->sx_xn = lm->sx_tout = lm->sx_dxn = lm->amax_pool = nullptr;
+        lm->amax_slots = lm->amax_used = 0;
+        if (lm->act8) {
+            const size_t mtiles = (size_t)mmi_cdiv(B, lm->T);
+            auto qbytes = [&](int features) { return mtiles * (size_t)(packed_ksteps(lm, features) / 2) * 1024; };
+            lm->amax_rows = (int)mtiles * lm->T;
+            lm->amax_slots = c.num_layers * 2 + c.dep_q * (c.depformer_num_layers * 2 + 1) + 4;
+            ok &= hipSuccess == A.alloc(&lm->xnq, qbytes(d));
+            ok &= hipSuccess == A.alloc(&lm->attq, qbytes(d));
+            ok &= hipSuccess == A.alloc(&lm->hbq, qbytes(c.ffn_hidden));
+            ok &= hipSuccess == A.alloc(&lm->toutq, qbytes(d));
+            ok &= hipSuccess == A.alloc(&lm->dxnq, qbytes(dd > 0 ? dd : 8));
+            ok &= hipSuccess == A.alloc(&lm->sx_xn, (size_t)lm->amax_rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_tout, (size_t)lm->amax_rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_dxn, (size_t)lm->amax_rows);
+            ok &= hipSuccess == A.alloc(&lm->amax_pool, (size_t)lm->amax_slots * lm->amax_rows);
+        }
+    }
     ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
     ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);
@@ -1495,7 +1608,8 @@ extern "C" int mmi_lm_profile_end(mmi_lm* lm, double* mean_ms, int64_t* n_launch
         *bytes_per_launch = wbytes + (int64_t)lm->batch * c.dim * 2 + (int64_t)lm->batch * c.ffn_hidden * 2;
     }
     if (kernel_name)
-        *kernel_name = lm->q8 == 1   ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
+        *kernel_name = lm->act8      ? "k_gemm_xp<32, MT, 1, 8, 2, 3> (temporal FFN linear_in, int8 weights x int8 activations on v_mfma_i32_32x32x32_i8 + SiLU gate)"
+                       : lm->q8 == 1 ? "k_gemm_xp<32, 1, 1, 8, 2, 1> (temporal FFN linear_in, int8 weights + SiLU gate)"
                        : lm->q8 == 2 ? "k_gemm_xp<32, 1, 1, 8, 2, 2> (temporal FFN linear_in, fp8 weights on the fp8 MFMA + SiLU gate)"
                        : lm->dominant_xlds ? (lm->batch > 32 ? "k_gemm_xlds<2, 32, 3, true, 0> (temporal FFN linear_in + SiLU gate)"
                                                              : "k_gemm_xlds<1, 64, 3, true, 0> (temporal FFN linear_in + SiLU gate)")

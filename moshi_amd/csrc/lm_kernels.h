@@ -131,6 +131,40 @@ __device__ __forceinline__ u32x2 mmi_bf16x8_to_fp8(u32x4 x, float inv) {
     return r;
 }
 
+// ---- int8 activations (bitsandbytes int8_vectorwise_quant, utils/quantize.py:24-40; restated in oracle/lm_oracle.py) ----------
+// max |v| over 8 packed bf16 values
+__device__ __forceinline__ float mmi_absmax_bf16x8(u32x4 v) {
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        m = fmaxf(m, fabsf(__builtin_bit_cast(float, v[q] << 16)));
+        m = fmaxf(m, fabsf(__builtin_bit_cast(float, v[q] & 0xffff0000u)));
+    }
+    return m;
+}
+// row absmax -> atomic slot (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void mmi_amax_fold(float* slot, float v) {
+    atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
+}
+// CA = int8(round_half_even(x * (127 / SCA))): 8 bf16 values -> 8 bytes (scale = 127 / SCA, 0 for an all-zero row)
+__device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
+    u32x2 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned w = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned x = v[2 * h + q];
+            const int lo = (int)mmi_rint(__builtin_bit_cast(float, x << 16) * scale);
+            const int hi = (int)mmi_rint(__builtin_bit_cast(float, x & 0xffff0000u) * scale);
+            w |= ((unsigned)lo & 0xffu) << (16 * q) | ((unsigned)hi & 0xffu) << (16 * q + 8);
+        }
+        r[h] = w;
+    }
+    return r;
+}
+__device__ __forceinline__ float mmi_i8_scale(float sca) { return sca > 0.f ? 127.0f / sca : 0.f; }
+
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
 // ------------------------------------------------------------------------------------------------
@@ -157,7 +191,13 @@ struct GemmArgs {
     int epi;
     const float* wscale;    // int8 / fp8 weights: dequantisation factor per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
     float xinv;             // fp8: 1 / input_scale, applied to the activations before the e4m3 conversion
-    int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights
+    int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights, 3 int8 weights x int8 activations
+    float* amax_out;        // int8 activations: the epilogue folds max |y| of the bf16 values it writes into amax_out[b] (atomic max of the
+                            // bit patterns of non-negative floats: order-independent, so deterministic) - the row absmax (bitsandbytes'
+                            // SCA) the NEXT linear quantises this tensor with; the slots are zeroed once per step
+    const float* sx;        // WQ = 3 with pre-quantised activations: xp holds int8 entries Xq[mt][kp][lane][16] (k_quant_rows_i8 / the
+                            // norm kernel) and sx[b] the row absmax they were scaled by (bitsandbytes' SCA); the epilogue multiplies
+                            // the int32 sum by SCA[b] / 127 * SCB[n] / 127.  k_gemm_q8: written here for the epilogue (LDS)
     int gate_rows;          // H of a gated linear_in (value row of feature n is H + n)
     float* partial;         // EPI_PARTIAL: fp32 partial sums [gridDim.y][B][N] (K split over gridDim.y workgroups so that
                             // GEMMs with few n-tiles still cover every CU); summed by k_resid_rmsnorm
@@ -217,7 +257,8 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 // workgroups when that balances the chip: 384 in_proj tiles over 256 CUs = 6 octets each); default = the whole tile.
 template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
-                                                  int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4) {
+                                                  int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4,
+                                                  const float* sx_local = nullptr) {
     constexpr int R = TN == 32 ? 16 : 4;
     // ---- split-K reduction across the block's waves (fixed order -> deterministic).  LDS layout [wave][tile][lane][LS]:
     // a lane's accumulators are contiguous, so they go out and come back as 16-byte vectors; LS = 20 floats (80 B)
@@ -298,6 +339,11 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 for (int e = 0; e < 4; ++e) { s2[e] *= g0[e]; s2[4 + e] *= g1[e]; }
             }
         }
+        if (a.sx || sx_local) {       // int8 activations: x ~= q * SCA / 127 (bitsandbytes' int8_mm_dequant: out32 * SCA * SCB / 127^2)
+            const float sa = (sx_local ? sx_local[m * TN + bl] : a.sx[b]) * (1.0f / 127.0f);     // sx_local: the kernel's own row absmax (LDS)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] *= sa; s2[e] *= sa; }
+        }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
             f32x4 lo = {s[0], s[1], s[2], s[3]}, hi = {s[4], s[5], s[6], s[7]};
@@ -317,7 +363,10 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
             for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(s[2 * e], s[2 * e + 1]);      // nn.Linear output in bf16
             uint16_t* cache = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap) * a.Dh + d0;
             *reinterpret_cast<u32x4*>(cache) = ov;
-            if (sec == 2) *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)) = ov;
+            if (sec == 2) {
+                *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)) = ov;
+                if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
+            }
             continue;
         }
         if (a.epi == MMI_EPI_ROPE_KV) {
@@ -395,16 +444,30 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e], o[2 * e + 1]);
         *reinterpret_cast<u32x4*>(dst) = ov;
+        if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
     }
 }
 
 // WQ = 1 (int8) / 2 (fp8) weights: one 16-byte weight entry carries two k-steps, so the loop runs over k-step PAIRS
 // (a.KSTEPS then counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
+// WQ = 3: int8 weight entries x int8 activation entries (a.xp = Xq, one 16-byte entry per weight entry, a.sx = row absmax) on
+// v_mfma_i32_{32x32x32,16x16x64}_i8; the int32 sums are converted to fp32 once per wave and go through the common epilogue.
 template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
-    constexpr int XS = WQ ? 2 : 1;                // activation fragments per weight entry
+    constexpr int XS = (WQ == 1 || WQ == 2 || WQ == 4) ? 2 : 1;   // activation fragments per weight entry
+    typedef int iacc_t __attribute__((ext_vector_type(R)));
+    // WQ = 4: int8 weights x bf16 activations that are quantised HERE, entry by entry, with the row absmax a.sx[b] the producer
+    // left behind (the depth transformer's small linears: no separate quantisation launch on their dependent chain)
+    float qs4[MT];
+    if constexpr (WQ == 4) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int bq = m * TN + ((int)threadIdx.x & (TN - 1));
+            qs4[m] = mmi_i8_scale(a.sx[bq < a.B ? bq : a.B - 1]);
+        }
+    }
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     // octet sharing (a.osplit > 1, NTW == 1): workgroup = (n-tile, part); part owns the 8-feature groups [g_lo, g_hi)
@@ -470,7 +533,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     }
 #define MMI_G_MMA1(W_, X_, u)                                                                 \
         if constexpr (WQ == 2) MMI_G_MMA8(W_, X_, u)                                          \
-        else {                                                                                \
+        else if constexpr (WQ == 4) {                                                         \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
+                const u32x2 qlo_ = mmi_quant_i8x8(X_[u][m][0], qs4[m]), qhi_ = mmi_quant_i8x8(X_[u][m][1], qs4[m]); \
+                const u32x4 xq_ = {qlo_[0], qlo_[1], qhi_[0], qhi_[1]};                       \
+                _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                             \
+                    if constexpr (TN == 32) acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(W_[u][t], xq_, __builtin_bit_cast(iacc_t, acc[t][m]))); \
+                    else acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_16x16x64(W_[u][t], xq_, __builtin_bit_cast(iacc_t, acc[t][m]))); \
+                }                                                                             \
+            }                                                                                 \
+        } else if constexpr (WQ == 3) {                                                       \
+            _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                   \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                              \
+                    if constexpr (TN == 32) acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(W_[u][t], X_[u][m][0], __builtin_bit_cast(iacc_t, acc[t][m]))); \
+                    else acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_16x16x64(W_[u][t], X_[u][m][0], __builtin_bit_cast(iacc_t, acc[t][m]))); \
+                }                                                                             \
+        } else {                                                                              \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                     \
             if constexpr (W8) {                                                               \
                 u32x4 wlo_, whi_;                                                             \
@@ -536,7 +614,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < R; ++r) accv[t][m][r] = acc[t][m][r];
+            for (int r = 0; r < R; ++r) {
+                if constexpr (WQ == 3 || WQ == 4) accv[t][m][r] = (float)__builtin_bit_cast(iacc_t, acc[t][m])[r];   // the wave's int32 sum
+                else accv[t][m][r] = acc[t][m][r];
+            }
     mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
 
@@ -546,12 +627,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // everything in flight at once, these GEMMs are latency bound - the waves combine their sums of squares through
 // LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
 // WQ = 1 / 2: int8 / fp8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
+// WQ = 3: int8 weights x int8 activations - the normalised row (a bf16 tensor, held in registers) is quantised row-wise like
+// bitsandbytes' int8_vectorwise_quant: the workgroup reduces its absmax through LDS next to the sum of squares, every lane
+// converts its own fragments, and the int32 sums are scaled by SCA[b] * SCB[n] / 127^2 in the epilogue.
 template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
     constexpr int XS = WQ ? 2 : 1;
+    typedef int iacc_t __attribute__((ext_vector_type(R)));
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -623,6 +708,50 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+    MMI_SHARED float sxl[MT * TN];                     // WQ = 3: the rows' absmax, for the epilogue
+    if constexpr (WQ == 3) {
+        MMI_SHARED float amx[WAVES][MT][TN];
+        float scl[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < XMAX; ++u) {
+                u32x4 xn;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4& xr = xv[m][u];
+                    const u32x4& ar = al[u];
+                    const float lo = mmi_bf16_to_f32((uint16_t)(xr[q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xr[q] >> 16));
+                    const float alo = mmi_bf16_to_f32((uint16_t)(ar[q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(ar[q] >> 16));
+                    xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
+                }
+                xv[m][u] = xn;                          // the norm's output, a bf16 tensor: what the linear quantises
+                am = fmaxf(am, mmi_absmax_bf16x8(xn));
+            }
+            if constexpr (TN == 32) am = fmaxf(am, mmi_shfl_xor(am, 32));
+            else { am = fmaxf(am, mmi_shfl_xor(am, 16)); am = fmaxf(am, mmi_shfl_xor(am, 32)); }
+            if (lane < TN) amx[wave][m][lane] = am;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) tot = fmaxf(tot, amx[w][m][lane & (TN - 1)]);
+            scl[m] = mmi_i8_scale(tot);
+            if (wave == 0 && lane < TN) sxl[m * TN + lane] = tot;
+        }
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x2 qlo = mmi_quant_i8x8(xv[m][2 * u], scl[m]), qhi = mmi_quant_i8x8(xv[m][2 * u + 1], scl[m]);
+                const u32x4 xq = {qlo[0], qlo[1], qhi[0], qhi[1]};
+                if constexpr (TN == 32) acc[m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(wv[u], xq, __builtin_bit_cast(iacc_t, acc[m])));
+                else acc[m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_16x16x64(wv[u], xq, __builtin_bit_cast(iacc_t, acc[m])));
+            }
+    } else
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         u32x4 wf[XS];
@@ -655,8 +784,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
-    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi);
+        for (int r = 0; r < R; ++r) {
+            if constexpr (WQ == 3) accv[0][m][r] = (float)__builtin_bit_cast(iacc_t, acc[m])[r];
+            else accv[0][m][r] = acc[m][r];
+        }
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi, WQ == 3 ? sxl : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,7 +816,7 @@ struct MmiFalse { static constexpr bool value = false; };
 template <int MT, int KC, int NTMAX = 3, bool STAGGER = false, int WQ = 0>
 __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
     typedef float acc_t __attribute__((ext_vector_type(16)));
-    constexpr int XS = WQ ? 2 : 1;              // activation fragments per weight entry
+    constexpr int XS = (WQ == 1 || WQ == 2) ? 2 : 1;   // activation fragments per weight entry (WQ = 3: int8 entries, one each)
     constexpr int KPW = KC >= 8 ? KC / 8 : 1;   // entries per wave per chunk
     constexpr int ACTIVE = KC / KPW;            // waves that own k-steps
     constexpr int XE = MT * KC * XS * 64;       // 16-byte activation pieces per chunk
@@ -747,6 +879,10 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
         if constexpr (WQ == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) ac[m] = mmi_mfma_bf16_32x32x16(w, xe[m * KC * XS * 64], ac[m]);
+        } else if constexpr (WQ == 3) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                ac[m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(w, xe[m * KC * XS * 64], __builtin_bit_cast(i32x16, ac[m])));
         } else if constexpr (WQ == 1) {
             u32x4 lo, hi;
             mmi_i8x16_to_bf16(w, lo, hi);
@@ -824,7 +960,10 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (WQ == 3) accv[0][m][r] = (float)__builtin_bit_cast(i32x16, acc[t][m])[r];
+                    else accv[0][m][r] = acc[t][m][r];
+                }
             mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
         }
     }
@@ -839,9 +978,12 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 //        x <- x + bf16(sum_p partial[p][b][:])      (transformer.py:739-741,772-776: x_orig + update, bf16 tensors)
 // then   y <- rms_norm_f32(x) * alpha               (transformer.py:45-58)
 #define MMI_NORM_MAXP 4      // pieces per thread kept in registers (D <= 8 * 1024 * MMI_NORM_MAXP)
+// yq != null (int8 activations): the normalised row is also stored quantised row-wise for the int8 linears that read it -
+// Xq[mt][kp][lane][16] (the bytes of k-steps 2 kp and 2 kp + 1) and sx[b] = its absmax (bitsandbytes' CA / SCA).
 __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x, const float* __restrict__ partial, int P,
                                                         int B, const uint16_t* __restrict__ alpha, uint16_t* __restrict__ y,
-                                                        int D, int T, int ksteps, float eps) {
+                                                        int D, int T, int ksteps, float eps, uint8_t* __restrict__ yq = nullptr,
+                                                        float* __restrict__ sx = nullptr) {
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float f[MMI_NORM_MAXP][8];
     u32x4 al[MMI_NORM_MAXP];
@@ -892,6 +1034,8 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
     float tot = 0.f;
     for (int w = 0; w < (nth + 63) / 64; ++w) tot += red[w];
     const float rs = mmi_rsqrtf(eps + tot / (float)D);
+    u32x4 ov[MMI_NORM_MAXP];
+    float am = 0.f;
 #pragma unroll
     for (int j = 0; j < MMI_NORM_MAXP; ++j) {
         const int i = (tid + j * nth) * 8;
@@ -903,7 +1047,47 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
             o[q] = mmi_pack_bf16x2(f[j][2 * q] * (alo * rs), f[j][2 * q + 1] * (ahi * rs));
         }
         *reinterpret_cast<u32x4*>(y + mmi_xp_index(T, b, i, ksteps)) = o;
+        ov[j] = o;
+        am = fmaxf(am, mmi_absmax_bf16x8(o));
     }
+    if (!yq) return;
+    // ---- row-wise int8 copy of the normalised row
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) am = fmaxf(am, mmi_shfl_xor(am, m));
+    MMI_SHARED float redm[16];
+    if ((tid & 63) == 0) redm[tid >> 6] = am;
+    __syncthreads();
+    float sca = 0.f;
+    for (int w = 0; w < (nth + 63) / 64; ++w) sca = fmaxf(sca, redm[w]);
+    if (tid == 0) sx[b] = sca;
+    const float scale = mmi_i8_scale(sca);
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        const long at = mmi_xp_index(T, b, i, ksteps);            // bf16 element index of the piece: fragment (mt * ksteps + ks), lane
+        const long frag = at >> 9;
+        const int ln = (int)((at >> 3) & 63);
+        const long mt = frag / ksteps;
+        const int ks = (int)(frag - mt * ksteps);
+        *reinterpret_cast<u32x2*>(yq + ((mt * (ksteps >> 1) + (ks >> 1)) * 64 + ln) * 16 + (ks & 1) * 8) = mmi_quant_i8x8(ov[j], scale);
+    }
+}
+
+// packed bf16 activations + the rows' absmax sx[b] (left behind by the producing epilogues / attention kernels) -> the int8
+// operand Xq[mt][kp][lane][16] of the int8 x int8 linears; one thread per 16-byte entry (two bf16 fragments in, one out)
+__global__ void k_quant_apply_i8(const u32x4* __restrict__ xp, const float* __restrict__ sx, u32x4* __restrict__ xq, int B, int T,
+                                 int kp_total, int MT) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)MT * kp_total * 64) return;
+    const int lane = (int)(idx & 63);
+    const long rest = idx >> 6;
+    const int kp = (int)(rest % kp_total), mt = (int)(rest / kp_total);
+    const int b = mt * T + (lane & (T - 1));
+    const float scale = mmi_i8_scale(sx[b < B ? b : B - 1]);
+    const u32x4 lo = xp[(((long)mt * 2 * kp_total) + 2 * kp) * 64 + lane], hi = xp[(((long)mt * 2 * kp_total) + 2 * kp + 1) * 64 + lane];
+    const u32x2 qlo = mmi_quant_i8x8(lo, scale), qhi = mmi_quant_i8x8(hi, scale);
+    xq[idx] = u32x4{qlo[0], qlo[1], qhi[0], qhi[1]};
 }
 
 // The cross-attention block's norm (transformer.py:731-732, 779-783: `norm_cross` is always an nn.LayerNorm with weight and
@@ -1110,7 +1294,15 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
+    float* amax;           // int8 activations: row absmax slot of the output (folded atomically, see GemmArgs::amax_out), or null
 };
+
+// max |bf16(o)| of the calling wave's lanes (inactive lanes pass 0) -> the row's absmax slot
+__device__ __forceinline__ void mmi_amax_fold_wave(float* slot, float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, mmi_shfl_xor(v, m));
+    if (((int)threadIdx.x & 63) == 0) mmi_amax_fold(slot, v);
+}
 
 #define MMI_ATTN_CHUNK 256
 // Decode attention of the one new query per (session, head) over the VALID part of the ring only (the reference reads
@@ -1258,6 +1450,10 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         for (int e = 0; e < EPL; ++e) ored[wave * DH + seg * EPL + e] = acc[e];
     }
     __syncthreads();
+    if (gridDim.y == 1 && a.amax && tid < ((DH + 63) & ~63)) {       // whole waves: the shuffle reduction needs every lane
+        const float o = tid < DH ? (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]) : 0.f;
+        mmi_amax_fold_wave(a.amax + b, tid < DH ? fabsf(mmi_round_bf16(o / l_run)) : 0.f);
+    }
     if (tid < DH) {
         const float o = (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]);
         if (gridDim.y == 1) {
@@ -1358,8 +1554,8 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
             float kf_[EPL];                                                                      \
             widen(KK[i], kf_);                                                                   \
             float dot_ = 0.f;                                                                    \
-            _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot_ += qv[e] * kf_[e];             \
-            _Pragma("unroll") for (int mk = LPR / 2; mk >= 1; mk >>= 1) dot_ += mmi_shfl_xor(dot_, mk); \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot_ = mmi_fma(qv[e], kf_[e], dot_); \
+            dot_ = mmi_group_sum<LPR>(dot_);                /* DPP row operations, no trip through the LDS crossbar */ \
             s_[i] = valid_ ? dot_ * scale : -INFINITY;                                           \
             mx_ = fmaxf(mx_, s_[i]);                                                             \
         }                                                                                        \
@@ -1373,7 +1569,7 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
                 l_run += p_;                                                                     \
                 float vf_[EPL];                                                                  \
                 widen(VV[i], vf_);                                                               \
-                _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] += p_ * vf_[e];          \
+                _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] = mmi_fma(p_, vf_[e], acc[e]); \
             }                                                                                    \
             m_run = m_new_;                                                                      \
         }                                                                                        \
@@ -1409,16 +1605,21 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
         if (seg == 0) { wm[wave] = m_run; wl[wave] = l_run; }
     }
     __syncthreads();
-    if (tid < DH) {
+    if (tid < ((DH + 63) & ~63)) {                       // whole waves (DH = 32: lanes 32..63 idle but present for the shuffles)
         const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        float num = 0.f, den = 0.f;
+        float num = 0.f, den = 1.f;
+        if (tid < DH) {
+            den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float sw = wm[w] == -INFINITY ? 0.f : expf(wm[w] - M);
-            num += sw * wacc[w * DH + tid];
-            den += sw * wl[w];
+            for (int w = 0; w < 4; ++w) {
+                const float sw = wm[w] == -INFINITY ? 0.f : expf(wm[w] - M);
+                num += sw * wacc[w * DH + tid];
+                den += sw * wl[w];
+            }
         }
-        if (gridDim.y == 1) {
+        if (gridDim.y == 1 && a.amax) mmi_amax_fold_wave(a.amax + b, tid < DH ? fabsf(mmi_round_bf16(num / den)) : 0.f);
+        if (tid >= DH) {
+        } else if (gridDim.y == 1) {
             a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
         } else {
             a.opart[((long)bh * gridDim.y + blockIdx.y) * DH + tid] = num;
@@ -1438,6 +1639,7 @@ __global__ void k_lm_attn_combine(LmAttnArgs a) {
     const float* ml = a.ml + (long)bh * a.NS * 2;
     float M = -INFINITY;
     for (int c = 0; c < a.NS; ++c) M = fmaxf(M, ml[2 * c]);
+    float am = 0.f;
     for (int d = threadIdx.x; d < Dh; d += blockDim.x) {
         float num = 0.f, den = 0.f;
         for (int c = 0; c < a.NS; ++c) {
@@ -1448,7 +1650,9 @@ __global__ void k_lm_attn_combine(LmAttnArgs a) {
             den += w * ml[2 * c + 1];
         }
         a.out[mmi_xp_index(a.T, bh / a.H, (bh % a.H) * Dh + d, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
+        am = fmaxf(am, fabsf(mmi_round_bf16(num / den)));
     }
+    if (a.amax) mmi_amax_fold_wave(a.amax + bh / a.H, am);      // blockDim is a multiple of 64: whole waves
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1463,6 +1667,7 @@ struct DepAttnArgs {
     uint16_t* out;         // packed (T, out_ksteps), feature = h*Dh + lane
     int B, H, Dh, steps, k;
     int T, out_ksteps;
+    float* amax;           // int8 activations: row absmax slot of the output, or null
 };
 
 __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
@@ -1517,6 +1722,7 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
         }
     }
     if (on) a.out[mmi_xp_index(a.T, b, h * Dh + lane, a.out_ksteps)] = mmi_f32_to_bf16(o / den);
+    if (a.amax) mmi_amax_fold_wave(a.amax + b, on ? fabsf(mmi_round_bf16(o / den)) : 0.f);
 }
 
 // The same attention for Dh a multiple of 8 (<= 64) and <= 8 positions per frame - Moshi's depth transformer - with far fewer
@@ -1574,6 +1780,7 @@ __global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
         *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
+        if (a.amax) mmi_amax_fold(a.amax + b, mmi_absmax_bf16x8(ov));
     }
 }
 

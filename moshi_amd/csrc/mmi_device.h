@@ -53,6 +53,21 @@ __device__ __forceinline__ T mmi_shfl_xor(T v, int mask) { return __shfl_xor(v, 
 template <class T>
 __device__ __forceinline__ T mmi_shfl(T v, int src) { return __shfl(v, src, 64); }
 
+// Sum over groups of W consecutive lanes (W = 2, 4, 8, 16; a group never straddles a 16-lane row), every lane of the group
+// receiving the total: DPP row operations - quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - which are
+// plain VALU operand modifiers.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0) per step: a dependent trip
+// through the LDS crossbar each (the decode attention spent most of its issue slots waiting on four of them per key row).
+template <int W>
+__device__ __forceinline__ float mmi_group_sum(float x) {
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "group of 1..16 lanes inside a DPP row");
+    if constexpr (W >= 2) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+    if constexpr (W >= 4) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+    if constexpr (W >= 8) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+    if constexpr (W >= 16) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+    return x;
+}
+__device__ __forceinline__ float mmi_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // D(32x32) += A(32x2) * B(2x32), exact fp32 fma chain.  lane l: a = A[l&31][l>>5], b = B[l>>5][l&31];
 // d[r] = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 __device__ __forceinline__ f32x16 mmi_mfma_f32_32x32x2(float a, float b, f32x16 c) {
@@ -101,6 +116,22 @@ __device__ __forceinline__ f32x16 mmi_mfma_fp8_32x32x16(u32x2 a, u32x2 b, f32x16
 __device__ __forceinline__ f32x4 mmi_mfma_fp8_16x16x32(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
 }
+
+// ---- int8 x int8 on the matrix core (BASELINE configs[4]: the reference's bitsandbytes int8 matmul, utils/quantize.py:24-40) ----
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+// D(32x32) += A(32x32) * B(32x32), int8 in / int32 acc (v_mfma_i32_32x32x32_i8): 16 bytes per operand per lane.  Both operands
+// are packed with the SAME (lane, byte) -> k map (k_pack_w_i8: lane (i, kq), byte e <-> k = 32 kp + 16 (e >> 3) + 8 kq + (e & 7)),
+// and the sum over k does not depend on the order the hardware walks it in.  d as the 32x32 map of the bf16 form.
+__device__ __forceinline__ i32x16 mmi_mfma_i8_32x32x32(u32x4 a, u32x4 b, i32x16 c) {
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+}
+// D(16x16) += A(16x64) * B(64x16) (v_mfma_i32_16x16x64_i8); d[r] = D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ i32x4 mmi_mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+}
+// round-half-even to the nearest integer (v_rndne_f32), the rounding of bitsandbytes' int8_vectorwise_quant
+__device__ __forceinline__ float mmi_rint(float x) { return __builtin_rintf(x); }
 
 // streamed-once weights: non-temporal so they do not evict the activations / KV the other kernels reuse
 __device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }

@@ -52,13 +52,30 @@ def _np(t):
 
 
 class QWeight:
-    """Row-wise int8 weight: W ~= q * scb / 127 (utils/quantize.py:17-22 storage; weight-only dequantisation - the engine
-    keeps activations bf16, unlike bitsandbytes' int8 x int8 matmul, which is absent here: parity with the reference's
-    quantised path is UNPINNED)."""
+    """Row-wise int8 weight as `QLinear.__init__` stores it (utils/quantize.py:14-22): `weight` = CB int8 [N, K], `weight_scb` =
+    SCB fp32 [N] (the row absmax), W ~= CB * SCB / 127.
+
+    Two forwards (`linear` below):
+    * act8 = True - `QLinear.forward` (utils/quantize.py:24-40): `bnb.matmul(x.half(), CB, state)` with a fresh `MatmulLtState`
+      (threshold 0: no outlier columns).  bitsandbytes (pinned >= 0.45, < 0.50 by moshi/pyproject.toml:9) is NOT in /root/reference
+      and not installed here, so its published algorithm is restated (`int8_vectorwise_quant`, `int8_linear_matmul`,
+      `int8_mm_dequant` of bitsandbytes/functional.py, "default" implementations of 0.46+, same arithmetic as the CUDA kernels
+      kInt8VectorQuant / kdequant_mm_int32_fp16):
+          SCA[b]  = max_k |x[b, k]|                                       (fp32)
+          CA[b,k] = int8(round_half_even(x[b, k] * (127 / SCA[b])))       (fp32 product)
+          out32   = CA @ CB^T                                             (exact int32)
+          y[b,n]  = out32[b, n] * (SCA[b] * SCB[n]) * (1 / (127 * 127))   (fp32)
+      PARITY UNPINNED AGAINST bitsandbytes: no reference test exercises QLinear and the library cannot run here; this is a
+      restatement of its documented rule, not a check against its output.  Two deliberate differences, both no-ops in range:
+      `x.half()` (bf16 -> fp16 is exact for |x| in [2^-14, 65504]; smaller values quantise to 0 either way) is skipped, and
+      the result is rounded to the engine's activation type bf16 where bnb returns fp16.
+    * act8 = False - weight-only dequantisation (activations stay bf16; the engine's `MMI_Q8_ACT=bf16` mode, rounds 1-3)."""
 
     def __init__(self, q: np.ndarray, scb: np.ndarray):
         self.q = q.astype(f32)
-        self.scale = (scb.astype(f32) / f32(127.0)).astype(f32)
+        self.scb = scb.astype(f32)
+        self.scale = (self.scb / f32(127.0)).astype(f32)
+        self.act8 = False
 
     @property
     def shape(self):
@@ -66,8 +83,30 @@ class QWeight:
 
     def rows(self, lo: int, hi: int) -> "QWeight":
         w = QWeight.__new__(QWeight)
-        w.q, w.scale = self.q[lo:hi], self.scale[lo:hi]
+        w.q, w.scale, w.scb, w.act8 = self.q[lo:hi], self.scale[lo:hi], self.scb[lo:hi], self.act8
         return w
+
+
+def int8_vectorwise_quant(x: np.ndarray):
+    """bitsandbytes.functional.int8_vectorwise_quant (threshold 0) restated: row absmax SCA and CA = round(x * (127 / SCA)),
+    half to even, as fp32 integers in [-127, 127]; an all-zero row quantises to zeros."""
+    x = np.ascontiguousarray(x, dtype=f32)
+    sca = np.abs(x).max(-1, keepdims=True).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ca = np.rint((x * (f32(127.0) / sca)).astype(f32))
+    return np.where(sca > 0, ca, f32(0)).astype(f32), sca
+
+
+def linear_int8(x: np.ndarray, w: "QWeight") -> np.ndarray:
+    """`bnb.matmul` on int8 operands restated (see QWeight): exact integer accumulation (fp32 chunks of <= 1024 products of
+    magnitude <= 127 * 127 are exact, summed in fp64), dequantised in fp32, rounded to bf16."""
+    ca, sca = int8_vectorwise_quant(x)
+    K = ca.shape[-1]
+    acc = np.zeros((ca.shape[0], w.q.shape[0]), np.float64)
+    for k0 in range(0, K, 1024):
+        acc += (ca[:, k0:k0 + 1024] @ w.q[:, k0:k0 + 1024].T).astype(np.float64)
+    out = acc.astype(f32) * (sca * w.scb[None, :]).astype(f32) * f32(1.0 / (127.0 * 127.0))
+    return bf16r(out.astype(f32))
 
 
 def e4m3r(x: np.ndarray) -> np.ndarray:
@@ -111,6 +150,8 @@ def linear(x: np.ndarray, w, acc64: bool = False) -> np.ndarray:
             acc = (acc * (1.0 + eps * rng.uniform(-1.0, 1.0, acc.shape))).astype(f32)
         return bf16r((acc * (w.scale * w.input_scale)[None, :]).astype(f32))
     if isinstance(w, QWeight):
+        if w.act8:
+            return linear_int8(x, w)
         return bf16r(((x @ w.q.T).astype(f32) * w.scale[None, :]).astype(f32))
     if isinstance(w, LazyWeight):
         w = w.numpy()
@@ -182,7 +223,8 @@ def sample_token(logits: np.ndarray, use_sampling: bool, temp: float, top_k: int
 
 
 class LMOracle:
-    def __init__(self, state_dict, cfg, fp8_accumulate_noise: float = 0.0, noise_seed: int = 0, accumulate64: bool = False):
+    def __init__(self, state_dict, cfg, fp8_accumulate_noise: float = 0.0, noise_seed: int = 0, accumulate64: bool = False,
+                 int8_activations: bool = True):
         """fp8_accumulate_noise: relative perturbation applied to every fp8 GEMM accumulator.  The gfx950 fp8 dot-product unit
         does not sum its 8-product groups exactly: products below ~2^-13 of the group's largest are shifted out (measured by
         scripts/fp8_probe.hip: up to 2.7e-4 of sum|products|).  The tests use this knob to measure how far such a perturbation
@@ -194,8 +236,11 @@ class LMOracle:
         self.acc64 = bool(accumulate64)
         self.cfg = cfg
         sd = {k: _np(v) for k, v in state_dict.items()}
+        # int8_activations: the int8 linears run bitsandbytes' int8 x int8 rule (the reference's QLinear.forward; default) or
+        # weight-only dequantisation (False).  Cross-attention linears of a conditioned model stay weight-only in the engine.
         for k in [k for k in sd if k.endswith("_scb")]:          # int8 linears: `weight` (int8) + `weight_scb`
             sd[k[:-4]] = QWeight(sd[k[:-4]], sd.pop(k))
+            sd[k[:-4]].act8 = bool(int8_activations) and ".cross_attention." not in k
         for k in [k for k in sd if k.endswith(".weight_scale")]:  # fp8 linears: `weight` (e4m3fn) + `weight_scale` [+ `input_scale`]
             stem = k[: -len(".weight_scale")]
             ins = sd.pop(stem + ".input_scale", None)

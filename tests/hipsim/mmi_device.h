@@ -12,6 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 #define __global__
 #define __device__
@@ -252,6 +254,74 @@ inline f32x4 mmi_mfma_fp8_16x16x32(u32x2 a, u32x2 b, f32x4 c) {
     hipsim::sync_wave();
     return d;
 }
+
+// int8 x int8 MFMA forms: lane l = (row / column l & (T-1), k-group l / T), 16 bytes per operand; A's byte e of group g meets
+// B's byte e of group g (any k order inside the instruction gives the same sum)
+namespace hipsim_detail { struct OpI8 { int8_t a[16], b[16]; }; }
+inline i32x16 mmi_mfma_i8_32x32x32(u32x4 a, u32x4 b, i32x16 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpI8 me;
+    memcpy(me.a, &a, 16);
+    memcpy(me.b, &b, 16);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    i32x16 d;
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        int acc = c[r];
+        for (int g = 0; g < 2; ++g) {
+            OpI8 oa, ob;
+            memcpy(&oa, s[i + 32 * g].b, sizeof(oa));
+            memcpy(&ob, s[j + 32 * g].b, sizeof(ob));
+            for (int e = 0; e < 16; ++e) acc += (int)oa.a[e] * (int)ob.b[e];
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+inline i32x4 mmi_mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
+    using namespace hipsim_detail;
+    hipsim::Slot* s = hipsim::wave_slots();
+    const int l = hipsim::lane_id();
+    OpI8 me;
+    memcpy(me.a, &a, 16);
+    memcpy(me.b, &b, 16);
+    memcpy(s[l].b, &me, sizeof(me));
+    hipsim::sync_wave();
+    i32x4 d;
+    const int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        int acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            OpI8 oa, ob;
+            memcpy(&oa, s[i + 16 * g].b, sizeof(oa));
+            memcpy(&ob, s[j + 16 * g].b, sizeof(ob));
+            for (int e = 0; e < 16; ++e) acc += (int)oa.a[e] * (int)ob.b[e];
+        }
+        d[r] = acc;
+    }
+    hipsim::sync_wave();
+    return d;
+}
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+
+// sum over groups of W consecutive lanes, every lane receiving the total (the gfx950 build: DPP row operations)
+template <int W>
+inline float mmi_group_sum(float x) {
+    for (int m = 1; m < W; m <<= 1) x += mmi_shfl_xor(x, m);
+    return x;
+}
+inline float mmi_fma(float a, float b, float c) { return fmaf(a, b, c); }
+inline float mmi_rint(float x) { return nearbyintf(x); }
 
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }

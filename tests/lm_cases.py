@@ -35,6 +35,14 @@ def logits_close(a: np.ndarray, ref: np.ndarray, widen: float = 1.0) -> bool:
 GUIDED_WIDEN = 1.5
 
 
+# int8 x int8 linears (bitsandbytes' rule): every linear re-quantises its input row to 8 bits, a DISCONTINUOUS map - where the
+# engine's bf16 activation differs from the checker's by one rounding flip (summation order), an int8 code moves by one step
+# (0.4 % of the row's absmax) and the difference is carried through the remaining layers instead of averaging out.  Measured on
+# the simulator over seeds: most (row, site) pairs are bit-identical to the oracle (median error 0), the worst at 5.8 % max /
+# 1.9 % mean of max|logit| (tiny model, 34 sessions, seed 88; same figures through k_gemm_xp and k_gemm_xlds) -> tolerance x 1.75.
+INT8_ACT_WIDEN = 1.75
+
+
 def near_tie(ref_logits: np.ndarray, tok_a: int, tok_b: int, widen: float = 1.0) -> bool:
     """Two implementations may pick different tokens only where the reference logits nearly tie."""
     scale = float(np.abs(ref_logits).max()) + 1e-6
@@ -294,7 +302,7 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
             prev_tt, prev_a0 = tt, toks[0]
 
 
-def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0, stats=None):
+def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0, stats=None, int8_activations=True):
     sd = random_lm_state_dict(cfg, seed=seed)
     if quantize == "fp8":   # e4m3fn linears on the fp8 MFMA (BASELINE configs[4]); engine and oracle get the same fp8 tensors
         from moshi_amd.weights import quantize_lm_state_dict_fp8
@@ -303,7 +311,8 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
         from moshi_amd.weights import quantize_lm_state_dict
         sd = quantize_lm_state_dict(sd)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
-    orc = LMOracle(sd, cfg)
+    orc = LMOracle(sd, cfg, int8_activations=int8_activations)      # int8 linears: bitsandbytes' int8 x int8 rule, or weight-only
+    widen = INT8_ACT_WIDEN if (quantize is True and int8_activations) else 1.0
     orc.streaming(B)
     rng = np.random.default_rng(seed)
     with gen.streaming(B):
@@ -326,11 +335,11 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
                 if not mask[b]:
                     continue
                 assert np.array_equal(out[b], oo[b]), f"step {s} row {b}: ring output differs"
-                assert logits_close(tl[b], otl[b]), f"step {s} row {b}: text logits {np.abs(tl[b]-otl[b]).max()}"
+                assert logits_close(tl[b], otl[b], widen), f"step {s} row {b}: text logits {np.abs(tl[b]-otl[b]).max()}"
                 for k in range(cfg.dep_q):
-                    assert logits_close(al[b, k], oal[b, k]), f"step {s} row {b} cb {k}: {np.abs(al[b,k]-oal[b,k]).max()}"
+                    assert logits_close(al[b, k], oal[b, k], widen), f"step {s} row {b} cb {k}: {np.abs(al[b,k]-oal[b,k]).max()}"
                     a_e, a_o = int(al[b, k].argmax()), int(oat[b, k])
-                    assert a_e == a_o or near_tie(oal[b, k], a_e, a_o)
+                    assert a_e == a_o or near_tie(oal[b, k], a_e, a_o, widen)
         if stats is not None:
             import collections
             stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))

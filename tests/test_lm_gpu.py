@@ -44,8 +44,16 @@ def test_tiny_matches_oracle_with_masks_and_reset(gpu_lib, B):
 
 @pytest.mark.parametrize("B", [2, 18, 40])
 def test_int8_weights_match_the_int8_oracle(gpu_lib, B):
-    """C5's weight format (`quantize=True`: row-wise int8 + `weight_scb`) on the tiny model, all three batch tilings."""
+    """C5's weight format (`quantize=True`: row-wise int8 + `weight_scb`) run the reference's way - int8 activations on
+    v_mfma_i32_{16x16x64,32x32x32}_i8, bitsandbytes' row-wise rule (utils/quantize.py:24-40, restated in oracle/lm_oracle.py;
+    unpinned against the library itself) - on the tiny model, all three batch tilings."""
     lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
+
+
+def test_int8_weight_only_mode_matches_its_oracle(gpu_lib, monkeypatch):
+    """MMI_Q8_ACT=bf16: the weight-only form of rounds 1-3 stays selectable (same-box A/Bs)."""
+    monkeypatch.setenv("MMI_Q8_ACT", "bf16")
+    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=98, B=18, S=3, quantize=True, int8_activations=False)
 
 
 def test_int8_full_width_layers_match_oracle(gpu_lib):

@@ -136,11 +136,59 @@ def test_depformer_in_per_step_launches(sim_lib, monkeypatch):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=92, B=2, S=3, quantize=True)
 
 
+@pytest.mark.parametrize("B", [2, 18, 34])
+def test_int8_linears_on_the_int8_matrix_core_match_the_bitsandbytes_restatement(sim_lib, B):
+    """`quantize=True` (BASELINE configs[4]): the reference's QLinear.forward is bitsandbytes' int8 x int8 matmul
+    (utils/quantize.py:24-40) - activations quantised row-wise (absmax / 127, round half even), int32 accumulation on
+    v_mfma_i32_*_i8, dequantised by SCA * SCB / 127^2.  Against the oracle's restatement of that published rule (bnb itself is
+    absent: unpinned against the library), same tolerance as the bf16 path; 2 sessions = the 16-row tile (16x16x64), 18 / 34
+    = one / two batch tiles of the 32-row tile (32x32x32)."""
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True, stats=st)
+    assert st["launch_sites"].get("L.out_proj", 0) >= 2      # (quantisation launch + GEMM per layer)
+
+
 @pytest.mark.parametrize("B", [2, 18])
-def test_int8_weights_match_the_int8_oracle(sim_lib, B):
-    """`quantize=True`: row-wise int8 linears (utils/quantize.py storage), widened to bf16 in registers.  Same tolerance as
-    the bf16 path against an oracle holding the same int8 tensors."""
-    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
+def test_int8_weight_only_mode_matches_its_oracle(sim_lib, monkeypatch, B):
+    """MMI_Q8_ACT=bf16: the weight-only form of rounds 1-3 (int8 weights widened to bf16 in registers, bf16 activations),
+    against the oracle in the same mode."""
+    monkeypatch.setenv("MMI_Q8_ACT", "bf16")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True, int8_activations=False)
+
+
+def test_int8_activations_without_norm_fusion_and_with_split_k(sim_lib, monkeypatch):
+    """The un-fused norm (its own launch stores the int8 row) and the K-split temporal GEMMs on int8 operands."""
+    monkeypatch.setenv("MMI_NO_NORM_FUSION", "1")
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=87, B=18, S=3, quantize=True)
+
+
+def test_int8_activations_on_the_lds_resident_gemm(sim_lib, monkeypatch):
+    monkeypatch.setenv("MMI_GEMM_LDS", "1")
+    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "8")
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=88, B=34, S=2, quantize=True, stats=st)
+    assert st["xlds_launches"] >= 2 * (2 * 2 + 1)
+
+
+def test_bitsandbytes_rule_restated_known_answers():
+    """The oracle's restatement of bitsandbytes' int8 rule on hand-computed cases: absmax scaling, round HALF TO EVEN, an
+    all-zero row, exact integer accumulation beyond 2^24, the dequantisation constant."""
+    import numpy as np
+    from oracle.lm_oracle import QWeight, int8_vectorwise_quant, linear_int8
+    x = np.array([[127.0, 63.5, -0.5, 1.5, 2.5, -2.5], [0, 0, 0, 0, 0, 0], [1.0, -2.0, 0.25, 0.5, -0.5, 0.75]], np.float32)
+    ca, sca = int8_vectorwise_quant(x)
+    assert sca.ravel().tolist() == [127.0, 0.0, 2.0]
+    assert ca[0].tolist() == [127, 64, 0, 2, 2, -2]                 # 63.5 -> 64 (even), -0.5 -> -0, 1.5 -> 2, 2.5 -> 2, -2.5 -> -2
+    assert ca[1].tolist() == [0] * 6
+    assert ca[2].tolist() == [64, -127, 16, 32, -32, 48]            # x * 63.5: 63.5 -> 64, 15.875 -> 16, 31.75 -> 32, 47.625 -> 48
+    K = 4096
+    q = np.full((2, K), 127, np.float32); q[1] = -127
+    w = QWeight(q, np.array([2.0, 4.0], np.float32))
+    w.act8 = True
+    y = linear_int8(np.full((1, K), 3.0, np.float32), w)            # CA = 127 everywhere: out32 = +-127 * 127 * 4096 = 66 064 384 > 2^24
+    exact = np.array([[K * 3.0 * 2.0, -K * 3.0 * 4.0]])
+    assert np.allclose(y, exact, rtol=4e-3) and abs(float(y[0, 0]) - exact[0, 0]) <= 2 ** -8 * exact[0, 0]      # only the bf16 rounding of y
 
 
 @pytest.mark.parametrize("B,input_scale", [(2, 1.0), (18, 0.25), (34, 1.0)])
