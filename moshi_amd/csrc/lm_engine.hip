@@ -5,6 +5,10 @@
 #include "lm_kernels.h"
 #include "mmi_graph.h"
 
+#ifndef MMI_DEP_PERSIST_DEFAULT
+#define MMI_DEP_PERSIST_DEFAULT 0      // k_dep_layer: opt-in (MMI_DEP_PERSIST=1) until its same-box A/B says otherwise
+#endif
+
 #include <math.h>
 
 namespace {
@@ -99,6 +103,13 @@ struct mmi_lm {
     float *sx_xn = nullptr, *sx_tout = nullptr, *sx_dxn = nullptr;
     float* amax_pool = nullptr;
     int amax_slots = 0, amax_used = 0, amax_rows = 0;
+    // persistent depth-transformer layers (k_dep_layer, lm_kernels.h): MMI_DEP_PERSIST = "0" off, "1" on; default: see dep_persist_default()
+    bool dep_persist = false;
+    int dep_grid = 256;             // workgroups of a persistent layer launch: one per CU (test hook MMI_DEP_PERSIST_GRID)
+    unsigned* dep_sync = nullptr;   // [dep_q * dep_layers][32] edge counters + [1] fault word, zeroed at the head of every step
+    DepLayerArgs* dep_args = nullptr;        // [dep_q * dep_layers] launch arguments, in device memory (see k_dep_layer)
+    std::vector<DepLayerArgs> dep_args_host;
+    size_t dep_sync_words = 0;
     bool hidden_taps = false;                       // mmi_lm_set_hidden_taps: the next streaming_start adds the two copies below
     uint16_t* htap = nullptr;                       // [2][B][dim] residual stream after the first / the last temporal layer
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
@@ -251,6 +262,7 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     }
     const int ks = g.KSTEPS / p.ksplit;
     p.waves = ks >= 32 ? 8 : 4;
+    if (getenv("MMI_GEMM_WAVES8")) p.waves = 8;      // test hook: the 8-wave split on short K (what k_dep_layer's bodies always use)
     // fragments in flight per register buffer: 2 for the widest GEMM (the temporal FFN linear_in, 704 n-tiles: fewer
     // registers -> 3 workgroups per CU -> all 704 resident at once; 36.8 vs 39.3 us in the microbenchmark), else 4
     p.u = (g.gate && g.NT >= 512 && p.waves == 8) ? 2 : 4;
@@ -692,6 +704,28 @@ TokArgs tok_args(mmi_lm* lm) {
     return t;
 }
 
+// k_dep_layer on by default?  (decided by the same-box A/B of round 4; MMI_DEP_PERSIST overrides)
+bool dep_persist_default(const mmi_lm*) { return MMI_DEP_PERSIST_DEFAULT != 0; }
+
+// the GemmArgs launch_gemm / add_norm_gemm would hand the kernel, for a linear of the persistent depth-transformer layer
+GemmArgs dep_gemm_args(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
+                       const uint16_t* resid, const uint16_t* alpha, int D, const DepKv* kv) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
+    a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid;
+    a.tok_rows = lm->gen_batch; a.B = lm->batch;
+    a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
+    a.out_ld = out_features;
+    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.alpha = alpha; a.D = D; a.eps = 1e-8f;
+    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wq = g.wq; a.xinv = g.xinv;
+    a.osplit = alpha ? 1 : plan_osplit(g, plan_gemm(g, false), epi, lm->T);
+    return a;
+}
+
 int build_program(mmi_lm* lm) {
     const mmi_lm_cfg& c = lm->cfg;
     const int B = lm->batch, d = c.dim, H = c.num_heads, Dh = d / H;
@@ -700,8 +734,13 @@ int build_program(mmi_lm* lm) {
     MmiProgram& P = lm->prog;
     const bool a8 = lm->act8;
     lm->amax_used = 0;
+    lm->dep_args_host.clear();
     // ---- token ring in, embeddings
     P.site("prepare");
+    if (lm->dep_persist) {   // the arrival counters of every persistent layer launch of the step (and the fault word) start at 0
+        unsigned* w = lm->dep_sync; const size_t nb = lm->dep_sync_words * sizeof(unsigned);
+        P.add([=](hipStream_t s) { MMI_HIP_CHECK(hipMemsetAsync(w, 0, nb, s)); return (int)MMI_OK; });
+    }
     if (a8) {   // the step's absmax slots start at 0 (|x| >= 0: the identity of the atomic max)
         float* pool = lm->amax_pool; const size_t nb = (size_t)lm->amax_slots * lm->amax_rows * sizeof(float);
         P.add([=](hipStream_t s) { MMI_HIP_CHECK(hipMemsetAsync(pool, 0, nb, s)); return (int)MMI_OK; });
@@ -853,6 +892,40 @@ int build_program(mmi_lm* lm) {
             // the last layer's residual epilogue for the logits head
             float* s_att = new_amax_slot(lm);
             float* s_hb = new_amax_slot(lm);
+            if (lm->dep_persist) {       // the layer's five stages in ONE launch (k_dep_layer); same bodies, same bits
+                DepLayerArgs dl;
+                memset(&dl, 0, sizeof(dl));
+                DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
+                dl.skip_attn = skip_attn0 ? 1 : 0;
+                dl.in_proj = skip_attn0 ? dep_gemm_args(lm, L.in_proj[k], lm->dx, lm->datt, dd, true, MMI_EPI_DEP_QKV0, nullptr, L.n1, dd, &kv)
+                                        : dep_gemm_args(lm, L.in_proj[k], lm->dx, lm->dqkv, 3 * dd, false, MMI_EPI_STORE, nullptr, L.n1, dd, nullptr);
+                dl.att.qkv = lm->dqkv; dl.att.kc = kv.kc; dl.att.vc = kv.vc; dl.att.out = lm->datt;
+                dl.att.B = B; dl.att.H = Hd; dl.att.Dh = Dhd; dl.att.steps = c.dep_q; dl.att.k = k;
+                dl.att.T = lm->T; dl.att.out_ksteps = packed_ksteps(lm, dd); dl.att.amax = nullptr;
+                dl.out_proj = dep_gemm_args(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, 0, nullptr);
+                dl.ffn_in = dep_gemm_args(lm, L.ffn_in[k], lm->dx, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr, L.n2, dd, nullptr);
+                dl.ffn_out = dep_gemm_args(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, 0, nullptr);
+                dl.n_in = dl.in_proj.NT; dl.n_att = mmi_cdiv(B * Hd, 8);
+                dl.n_out = dl.out_proj.NT * (dl.out_proj.osplit > 1 ? dl.out_proj.osplit : 1);
+                dl.n_fin = dl.ffn_in.NT;
+                dl.n_fout = dl.ffn_out.NT * (dl.ffn_out.osplit > 1 ? dl.ffn_out.osplit : 1);
+                dl.sync = lm->dep_sync + ((size_t)k * c.depformer_num_layers + l) * 32;
+                dl.fault = lm->dep_sync + lm->dep_sync_words - 8;
+                const int T = lm->T, mt = mmi_cdiv(B, lm->T), grid = lm->dep_grid;
+                const long wbytes = (long)(L.in_proj[k].bytes + L.out_proj[k].bytes + L.ffn_in[k].bytes + L.ffn_out[k].bytes);
+                const DepLayerArgs* dla = lm->dep_args + lm->dep_args_host.size();
+                lm->dep_args_host.push_back(dl);
+                P.site("dep.layer");
+                P.add([=](hipStream_t s) {
+                    mmi_record_bytes(wbytes);
+                    if (T == 32 && mt == 1) MMI_LAUNCH((k_dep_layer<32, 1>), grid, 512, 0, s, dla);
+                    else if (T == 32) MMI_LAUNCH((k_dep_layer<32, 2>), grid, 512, 0, s, dla);
+                    else MMI_LAUNCH((k_dep_layer<16, 1>), grid, 512, 0, s, dla);
+                    MMI_CHECK_LAUNCH();
+                    return (int)MMI_OK;
+                }, wbytes);
+                continue;
+            }
             if (skip_attn0) {
                 DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
                 add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv, s_att);
@@ -901,6 +974,8 @@ int build_program(mmi_lm* lm) {
             return (int)MMI_OK;
         });
     }
+    if (!lm->dep_args_host.empty())
+        MMI_HIP_CHECK(hipMemcpy(lm->dep_args, lm->dep_args_host.data(), lm->dep_args_host.size() * sizeof(DepLayerArgs), hipMemcpyHostToDevice));
     return MMI_OK;
 }
 
@@ -1211,6 +1286,25 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     lm->htap = nullptr;
     if (lm->hidden_taps) ok &= hipSuccess == A.alloc(&lm->htap, (size_t)2 * B * d);
+    {   // persistent depth-transformer layers: bf16 linears, heads of whole 16-byte chunks, <= 8 positions, rows of <= 64 k-steps
+        const char* ep = getenv("MMI_DEP_PERSIST");
+        const bool want = ep && ep[0] ? ep[0] != '0' : dep_persist_default(lm);
+        const int ks_dd = mmi_cdiv(dd, mmi_kstep(lm->T));
+        // (two batch tiles - 33..64 sessions - keep the launch list: the fused kernel's register budget does not hold the second tile)
+        lm->dep_persist = want && c.dep_q > 0 && lm->q8 == 0 && Dhd % 8 == 0 && Dhd <= 64 && c.dep_q <= 8 && ks_dd <= 64 && B <= lm->T &&
+                          !getenv("MMI_NO_NORM_FUSION") && !getenv("MMI_DEP_ATTN0_LAUNCH");
+        lm->dep_sync = nullptr;
+        lm->dep_sync_words = 0;
+        if (lm->dep_persist) {
+            int cus = 256;
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, lm->device);
+            lm->dep_grid = cus > 0 ? cus : 256;
+            if (const char* eg = getenv("MMI_DEP_PERSIST_GRID")) { const int v = atoi(eg); if (v >= 1) lm->dep_grid = v; }
+            lm->dep_sync_words = (size_t)c.dep_q * c.depformer_num_layers * 32 + 8;
+            ok &= hipSuccess == A.alloc(&lm->dep_sync, lm->dep_sync_words);
+            ok &= hipSuccess == A.alloc(&lm->dep_args, (size_t)c.dep_q * c.depformer_num_layers);
+        }
+    }
     {   // int8 activations (see mmi_lm::act8)
         const char* e8 = getenv("MMI_Q8_ACT");
         lm->act8 = lm->q8 == 1 && !c.cross_attention && !(e8 && e8[0] == 'b');
@@ -1523,6 +1617,14 @@ extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream
 }
 
 extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
+    if (lm && which == 1) {          // edges of the persistent depth-transformer layers that gave up since the last step began (0 = none)
+        if (!lm->dep_sync) return 0;
+        MmiDeviceGuard dev_guard_(lm->device);
+        unsigned f = 0;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, lm->dep_sync + lm->dep_sync_words - 8, sizeof(f), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return (int64_t)f;
+    }
+    if (lm && which == 2) return lm->dep_persist ? 1 : 0;
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return -1;
     return which == 0 ? (int64_t)lm->xlds_launches : -1;

@@ -142,10 +142,7 @@ __device__ __forceinline__ float mmi_absmax_bf16x8(u32x4 v) {
     }
     return m;
 }
-// row absmax -> atomic slot (non-negative floats order like their bit patterns)
-__device__ __forceinline__ void mmi_amax_fold(float* slot, float v) {
-    atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
-}
+// (mmi_amax_fold - row absmax -> atomic slot - lives in mmi_device.h)
 // CA = int8(round_half_even(x * (127 / SCA))): 8 bf16 values -> 8 bytes (scale = 127 / SCA, 0 for an all-zero row)
 __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     u32x2 r;
@@ -164,6 +161,21 @@ __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     return r;
 }
 __device__ __forceinline__ float mmi_i8_scale(float sca) { return sca > 0.f ? 127.0f / sca : 0.f; }
+
+// ---- tensors handed from one workgroup to another INSIDE a launch (k_dep_layer) -------------------------------------------------
+// COH = true: 16 bytes as two 8-byte agent-scope relaxed atomics (global_load/store_dwordx2 sc1: served by / written through to
+// the L2, never the CU's L1) - with the hand-off counters of mmi_edge_sync the "8-byte agent atomics on both sides" form of
+// the guide's cross-workgroup visibility rules: no fence, no L2 write-back / invalidate.  COH = false: plain vector access.
+template <bool COH>
+__device__ __forceinline__ u32x4 mmi_ldx(const u32x4* p) {
+    if constexpr (COH) return mmi_ld_coh16(p);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void mmi_stx(u32x4* p, u32x4 v) {
+    if constexpr (COH) mmi_st_coh16(p, v);
+    else *p = v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
@@ -225,7 +237,7 @@ struct GemmArgs {
 
 // The residual (or embedding) vector the thread's FIRST epilogue task will add, requested before the weight stream starts
 // so that its latency is hidden behind the main loop instead of extending the epilogue.
-template <int TN, int MT, int NTW>
+template <int TN, int MT, int NTW, bool COH = false>
 __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int nt0) {
     u32x4 pre = {0u, 0u, 0u, 0u};
     if (a.epi != MMI_EPI_RESID && a.epi != MMI_EPI_EMB) return pre;
@@ -241,7 +253,7 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
     if (nt >= a.NT || b >= a.B || n0 >= a.N) return pre;
     if (a.epi == MMI_EPI_RESID) {
         const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.resid + (long)b * a.out_ld + n0;
-        pre = *reinterpret_cast<const u32x4*>(rs);
+        pre = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(rs));
     } else {
         const int tk = a.tok[(long)(b % a.tok_rows) * a.tok_stride];
         if (tk != -1) pre = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
@@ -255,7 +267,7 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 // kernels that own all of the LDS themselves (k_gemm_xlds).
 // g_lo / g_hi: only the tile's 8-feature groups [g_lo, g_hi) are written (k_gemm_xlds hands a tile's row octets to two
 // workgroups when that balances the chip: 384 in_proj tiles over 256 CUs = 6 octets each); default = the whole tile.
-template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
+template <int TN, int MT, int NTW, int WAVES, bool EXT = false, bool COH = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
                                                   int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4,
                                                   const float* sx_local = nullptr) {
@@ -362,9 +374,9 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(s[2 * e], s[2 * e + 1]);      // nn.Linear output in bf16
             uint16_t* cache = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap) * a.Dh + d0;
-            *reinterpret_cast<u32x4*>(cache) = ov;
+            mmi_stx<COH>(reinterpret_cast<u32x4*>(cache), ov);
             if (sec == 2) {
-                *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)) = ov;
+                mmi_stx<COH>(reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)), ov);
                 if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
             }
             continue;
@@ -418,7 +430,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         } else if (a.epi == MMI_EPI_RESID) {
             const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps)
                                                               : a.resid + (long)b * a.out_ld + n0;
-            const u32x4 rv = q == (int)threadIdx.x ? pre : *reinterpret_cast<const u32x4*>(rs);
+            const u32x4 rv = q == (int)threadIdx.x ? pre : mmi_ldx<COH>(reinterpret_cast<const u32x4*>(rs));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint16_t h = (uint16_t)((e & 1) ? (rv[e >> 1] >> 16) : (rv[e >> 1] & 0xffffu));
@@ -443,7 +455,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         u32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e], o[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(dst) = ov;
+        mmi_stx<COH>(reinterpret_cast<u32x4*>(dst), ov);
         if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
     }
 }
@@ -452,8 +464,11 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 // (a.KSTEPS then counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
 // WQ = 3: int8 weight entries x int8 activation entries (a.xp = Xq, one 16-byte entry per weight entry, a.sx = row absmax) on
 // v_mfma_i32_{32x32x32,16x16x64}_i8; the int32 sums are converted to fp32 once per wave and go through the common epilogue.
-template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
+// The kernel's body as a function of a VIRTUAL block index (vbx, vby of vgy): k_gemm_xp passes its own, the persistent
+// depth-transformer layer (k_dep_layer) walks its work items through it.  COH: activations / residual / outputs are tensors
+// handed over inside the launch (mmi_ldx / mmi_stx).
+template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0, bool COH = false>
+__device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vbx, const int vby, const int vgy) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
     constexpr int XS = (WQ == 1 || WQ == 2 || WQ == 4) ? 2 : 1;   // activation fragments per weight entry
@@ -472,18 +487,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     // octet sharing (a.osplit > 1, NTW == 1): workgroup = (n-tile, part); part owns the 8-feature groups [g_lo, g_hi)
     const int os = (NTW == 1 && a.osplit > 1) ? a.osplit : 1;
-    const int bx = (int)blockIdx.x / os, part = (int)blockIdx.x - bx * os;
+    const int bx = vbx / os, part = vbx - bx * os;
     const int nt0 = bx * NTW;
     const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
     // weight fragments are stored [k-step][lane], lane = (k-group, row): rows of octets the workgroup does not own are read
     // from the first owned octet instead
     const int ro = (lane >> 3) & (TN / 8 - 1);
     const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
-    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW>(a, nt0);
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW, COH>(a, nt0);
 
     // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
-    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
+    const int kb_per = (a.KSTEPS + vgy - 1) / vgy;
+    const int kb0 = min(a.KSTEPS, vby * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
     const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;
     const int ks0 = min(kb1, kb0 + wave * kper);
     const int nks = min(kb1, ks0 + kper) - ks0;
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
-            _Pragma("unroll") for (int x = 0; x < XS; ++x) X_[u][m][x] = xp[m][(((base) + u) * XS + x) * 64]; \
+            _Pragma("unroll") for (int x = 0; x < XS; ++x) X_[u][m][x] = mmi_ldx<COH>(xp[m] + (((base) + u) * XS + x) * 64); \
     }
 #define MMI_G_MFMA(WF, XF, ACC)                                                               \
     if constexpr (TN == 32) ACC = mmi_mfma_bf16_32x32x16(WF, XF, ACC);                        \
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int x = 0; x < XS; ++x) xA[u][m][x] = xp[m][(ks * XS + x) * 64];
+                for (int x = 0; x < XS; ++x) xA[u][m][x] = mmi_ldx<COH>(xp[m] + (ks * XS + x) * 64);
         }
 #pragma unroll
         for (int u = 0; u < U - 1; ++u)
@@ -618,7 +633,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
                 if constexpr (WQ == 3 || WQ == 4) accv[t][m][r] = (float)__builtin_bit_cast(iacc_t, acc[t][m])[r];   // the wave's int32 sum
                 else accv[t][m][r] = acc[t][m][r];
             }
-    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
+    mmi_gemm_epilogue<TN, MT, NTW, WAVES, false, COH>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
+}
+
+template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
+    mmi_gemm_xp_body<TN, MT, NTW, WAVES, U, WQ>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
@@ -630,8 +650,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // WQ = 3: int8 weights x int8 activations - the normalised row (a bf16 tensor, held in registers) is quantised row-wise like
 // bitsandbytes' int8_vectorwise_quant: the workgroup reduces its absmax through LDS next to the sum of squares, every lane
 // converts its own fragments, and the int32 sums are scaled by SCA[b] * SCB[n] / 127^2 in the epilogue.
-template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
+template <int TN, int MT, int WAVES, int KMAX, int WQ = 0, bool COH = false>
+__device__ __forceinline__ void mmi_gemm_xp_norm_body(const GemmArgs& a, const int vbx) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = (int)blockIdx.x;                          // one n-tile per workgroup (octet sharing of these GEMMs measured
+    const int nt0 = vbx;                          // one n-tile per workgroup (octet sharing of these GEMMs measured
     const int g_lo = 0, g_hi = TN / 8, wlane = lane;          // neutral, profiles/r02_logs/ab_osplit_norm*: not built in)
     const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
     const int ks0 = min(a.KSTEPS, wave * kper);
@@ -662,7 +682,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
             const int k = ((ksl + uu) * XS + x) * KS + 8 * kq;
             al[u * XS + x] = *reinterpret_cast<const u32x4*>(a.alpha + min(k, dmax));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xv[m][u * XS + x] = a.xp[(((long)m * a.KSTEPS + ksl + uu) * XS + x) * 64 + lane];
+            for (int m = 0; m < MT; ++m) xv[m][u * XS + x] = mmi_ldx<COH>(a.xp + (((long)m * a.KSTEPS + ksl + uu) * XS + x) * 64 + lane);
         }
     }
 #pragma unroll
@@ -788,7 +808,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
             if constexpr (WQ == 3) accv[0][m][r] = (float)__builtin_bit_cast(iacc_t, acc[m])[r];
             else accv[0][m][r] = acc[m][r];
         }
-    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi, WQ == 3 ? sxl : nullptr);
+    mmi_gemm_epilogue<TN, MT, 1, WAVES, false, COH>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi, WQ == 3 ? sxl : nullptr);
+}
+
+template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
+    mmi_gemm_xp_norm_body<TN, MT, WAVES, KMAX, WQ>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1730,10 +1755,10 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
 // chunk of q, of key row j and of value row j once (the newest row straight from the in_proj output, which the lanes of
 // position k also copy into the frame's cache), reduces the score over the 8 chunk lanes, the softmax and P.V over the 8
 // position groups (3 butterfly steps each), and the lanes of position 0 store 8 output features as one 16-byte vector.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
+template <int NW, bool COH = false>
+__device__ __forceinline__ void mmi_dep_attn8_body(const DepAttnArgs& a, const int vbx) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int bh = (int)blockIdx.x * NW + wave;
+    const int bh = vbx * NW + wave;
     if (bh >= a.B * a.H) return;
     const int b = bh / a.H, h = bh - b * a.H;
     const int Dh = a.Dh, HD = a.H * Dh, NC = Dh >> 3;
@@ -1743,9 +1768,11 @@ __global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
     uint16_t* kcb = a.kc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     uint16_t* vcb = a.vc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     const bool newest = jc == a.k;
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(row);
-    const u32x4 kv = *reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh);
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh);
+    // (COH: q / k / v of this position and the output are handed over inside the launch; the cache rows of earlier positions
+    // come from earlier launches and take the same load flavour - one unconditional load from a selected address)
+    const u32x4 qv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(row));
+    const u32x4 kv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh));
+    const u32x4 vv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh));
     if (j == a.k && c < NC) {                                       // this frame's cache, position k (transformer.py:243-253)
         *reinterpret_cast<u32x4*>(kcb + (long)a.k * Dh) = kv;
         *reinterpret_cast<u32x4*>(vcb + (long)a.k * Dh) = vv;
@@ -1779,8 +1806,65 @@ __global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
         u32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
-        *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
+        mmi_stx<COH>(reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)), ov);
         if (a.amax) mmi_amax_fold(a.amax + b, mmi_absmax_bf16x8(ov));
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
+    mmi_dep_attn8_body<NW>(a, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one depth-transformer layer of one micro-step as ONE persistent launch (round 4)
+// ------------------------------------------------------------------------------------------------
+// The depth transformer (lm.py:450-493; transformer.py:609-802 with per-step weights) is dep_q x depformer_num_layers layers of
+// five dependent stages - norm1 + in_proj, attention over <= dep_q positions, out_proj + residual, norm2 + gated linear_in,
+// linear_out + residual - each a 2-11 MB launch that takes 4.5-8 us of which ~1.5 us is the kernel boundary and ~1.5 us the
+// ramp (arguments, first loads) before any of its bytes move: 264 boundaries per frame, 1.65 ms at 0.10 of the HBM roofline
+// (DESIGN.md).  Here the five stages of a layer share one launch of one workgroup per CU: every stage is the body of the kernel it
+// replaces (mmi_gemm_xp_norm_body / mmi_dep_attn8_body / mmi_gemm_xp_body, same tile partitions, same arithmetic, so the
+// results are bit-identical), walked over its work items by the resident workgroups, and between two stages the workgroups meet
+// at an edge (mmi_edge_sync): payload through L2-coherent 8-byte atomics, arrival counters sharded by XCD, no L2 write-back or
+// invalidate - where a kernel boundary flushes and refills every cache the codec running beside the depth transformer is using.
+struct DepLayerArgs {
+    GemmArgs in_proj, out_proj, ffn_in, ffn_out;      // as the launch list builds them (in_proj / ffn_in with the fused RMSNorm)
+    DepAttnArgs att;
+    int skip_attn;                // micro-step 0: in_proj's epilogue (MMI_EPI_DEP_QKV0) already wrote the attention output
+    int n_in, n_att, n_out, n_fin, n_fout;            // work items (virtual workgroups of the replaced kernels) per stage
+    unsigned* sync;               // [4][8] arrival counters of this launch's edges, zero at the head of the step
+    unsigned* fault;              // raised if an edge gave up (bounded spin)
+};
+
+// The arguments live in device memory (written once when the stream starts): by value, the four GemmArgs would all sit in scalar
+// registers for the whole launch and spill (158 SGPR / 31-351 VGPR spills measured); by reference each stage loads its own.
+template <int TN, int MT>
+__global__ __launch_bounds__(512) void k_dep_layer(const DepLayerArgs* __restrict__ pp) {
+    const DepLayerArgs& p = *pp;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    for (int it = bid; it < p.n_in; it += G) {
+        mmi_gemm_xp_norm_body<TN, MT, 8, 8, 0, true>(p.in_proj, it);
+        __syncthreads();                               // the epilogue's reduction scratch is reused by the next item / stage
+    }
+    mmi_edge_sync(p.sync, G, bid, p.fault);
+    if (!p.skip_attn) {
+        for (int it = bid; it < p.n_att; it += G) mmi_dep_attn8_body<8, true>(p.att, it);
+        mmi_edge_sync(p.sync + 8, G, bid, p.fault);
+    }
+    for (int it = bid; it < p.n_out; it += G) {
+        mmi_gemm_xp_body<TN, MT, 1, 8, 4, 0, true>(p.out_proj, it, 0, 1);
+        __syncthreads();
+    }
+    mmi_edge_sync(p.sync + 16, G, bid, p.fault);
+    for (int it = bid; it < p.n_fin; it += G) {
+        mmi_gemm_xp_norm_body<TN, MT, 8, 8, 0, true>(p.ffn_in, it);
+        __syncthreads();
+    }
+    mmi_edge_sync(p.sync + 24, G, bid, p.fault);
+    for (int it = bid; it < p.n_fout; it += G) {
+        mmi_gemm_xp_body<TN, MT, 1, 8, 4, 0, true>(p.ffn_out, it, 0, 1);
+        __syncthreads();
     }
 }
 
