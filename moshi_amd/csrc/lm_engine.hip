@@ -5,10 +5,6 @@
 #include "lm_kernels.h"
 #include "mmi_graph.h"
 
-#ifndef MMI_DEP_PERSIST_DEFAULT
-#define MMI_DEP_PERSIST_DEFAULT 0      // k_dep_layer: opt-in (MMI_DEP_PERSIST=1) until its same-box A/B says otherwise
-#endif
-
 #include <math.h>
 
 namespace {
@@ -94,22 +90,15 @@ struct mmi_lm {
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
     // int8 activations (BASELINE configs[4], the reference's own arithmetic: QLinear.forward -> bitsandbytes' int8 x int8 matmul,
     // utils/quantize.py:24-40): on for int8 linears unless MMI_Q8_ACT=bf16 (weight-only, rounds 1-3) or the model has
-    // cross-attention layers.  xnq / attq / hbq / toutq: the int8 operand Xq[mt][kp][lane][16] next to its bf16 tensor;
-    // sx_*: the rows' absmax (SCA) where ONE workgroup sees the whole row (the norm kernel); amax_pool: one slot [rows] per
-    // producing site of the step whose row is spread over workgroups (attention, gated epilogue, ...), folded with atomic max
-    // and zeroed by one memset at the head of the step.
+    // cross-attention layers.  xnq / attq / hbq / toutq: the int8 operand Xq[mt][kp][lane][16] next to its bf16 tensor, sx_*: its
+    // rows' absmax (bitsandbytes' SCA).  Who quantises: the norm kernel for its own output (one workgroup per row); a
+    // k_quant_rows_i8 launch for the temporal attention output and the gated FFN tensor (rows written by many workgroups); the
+    // depth transformer's GEMMs themselves (k_gemm_q8: every workgroup holds the whole short row).  No atomics: absmax slots
+    // folded by the producing epilogues were built first and measured - 704 gated tiles x 64 rows hammering 2 cache lines took
+    // linear_in from 50 to 94 us (58 with test-then-max), profiles/r04_logs/call_b_summary.txt.
     bool act8 = false;
     uint8_t *xnq = nullptr, *attq = nullptr, *hbq = nullptr, *toutq = nullptr, *dxnq = nullptr;
-    float *sx_xn = nullptr, *sx_tout = nullptr, *sx_dxn = nullptr;
-    float* amax_pool = nullptr;
-    int amax_slots = 0, amax_used = 0, amax_rows = 0;
-    // persistent depth-transformer layers (k_dep_layer, lm_kernels.h): MMI_DEP_PERSIST = "0" off, "1" on; default: see dep_persist_default()
-    bool dep_persist = false;
-    int dep_grid = 256;             // workgroups of a persistent layer launch: one per CU (test hook MMI_DEP_PERSIST_GRID)
-    unsigned* dep_sync = nullptr;   // [dep_q * dep_layers][32] edge counters + [1] fault word, zeroed at the head of every step
-    DepLayerArgs* dep_args = nullptr;        // [dep_q * dep_layers] launch arguments, in device memory (see k_dep_layer)
-    std::vector<DepLayerArgs> dep_args_host;
-    size_t dep_sync_words = 0;
+    float *sx_xn = nullptr, *sx_tout = nullptr, *sx_dxn = nullptr, *sx_att = nullptr, *sx_hb = nullptr;
     bool hidden_taps = false;                       // mmi_lm_set_hidden_taps: the next streaming_start adds the two copies below
     uint16_t* htap = nullptr;                       // [2][B][dim] residual stream after the first / the last temporal layer
     uint16_t *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dhb = nullptr, *dlogits = nullptr;
@@ -262,7 +251,6 @@ GemmPlan plan_gemm(const GemmW& g, bool may_split) {
     }
     const int ks = g.KSTEPS / p.ksplit;
     p.waves = ks >= 32 ? 8 : 4;
-    if (getenv("MMI_GEMM_WAVES8")) p.waves = 8;      // test hook: the 8-wave split on short K (what k_dep_layer's bodies always use)
     // fragments in flight per register buffer: 2 for the widest GEMM (the temporal FFN linear_in, 704 n-tiles: fewer
     // registers -> 3 workgroups per CU -> all 704 resident at once; 36.8 vs 39.3 us in the microbenchmark), else 4
     p.u = (g.gate && g.NT >= 512 && p.waves == 8) ? 2 : 4;
@@ -310,7 +298,6 @@ int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, int wq, const Ge
     if (wq == 1) return launch_gemm_q<TN, MT, NTW, 1>(s, groups, waves, a);
     if (wq == 2) return launch_gemm_q<TN, MT, NTW, 2>(s, groups, waves, a);
     if (wq == 3) return launch_gemm_q<TN, MT, NTW, 3>(s, groups, waves, a);
-    if (wq == 4) return launch_gemm_q<TN, MT, NTW, 4>(s, groups, waves, a);
     if (waves == 8 && u == 2 && MT * NTW == 1) {
         if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
         MMI_CHECK_LAUNCH();
@@ -346,7 +333,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
     const char mode = en && en[0] ? en[0] : (g.wq == 0 ? '2' : '0');
-    if (mode == '0' || lm->T != 32 || mt > 2 || a.wq == 4) return p;
+    if (mode == '0' || lm->T != 32 || mt > 2) return p;
     if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
@@ -450,15 +437,8 @@ size_t packed_elems(const mmi_lm* lm, int features) {
 // x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
 // MMI_EPI_DEP_QKV0 (the depth transformer's in_proj at micro-step 0): where its epilogue writes k / v (frame cache, position 0)
 struct DepKv { uint16_t* kc; uint16_t* vc; int H, Dh, steps; };
-// int8 activations of one GEMM (lm->act8): wq 3 = `x` is the int8 operand Xq and sx its rows' absmax; wq 4 = `x` is the bf16
-// tensor, quantised inside the GEMM with the absmax sx the producer left behind; amax_out = fold the absmax of THIS GEMM's output
-struct Q8 { int wq = 0; const float* sx = nullptr; float* amax_out = nullptr; };
-
-// a fresh absmax slot [rows] of the step's pool (zeroed by the memset at the head of the program)
-float* new_amax_slot(mmi_lm* lm) {
-    if (!lm->act8 || lm->amax_used >= lm->amax_slots) return nullptr;
-    return lm->amax_pool + (size_t)(lm->amax_used++) * lm->amax_rows;
-}
+// int8 activations of one GEMM (lm->act8): `x` is the int8 operand Xq and sx its rows' absmax (wq 3)
+struct Q8 { int wq = 0; const float* sx = nullptr; };
 
 void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
               const uint16_t* resid, const uint16_t* emb = nullptr, const int* tok = nullptr, int tok_stride = 0,
@@ -466,7 +446,7 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
-    if (q8) { a.wq = q8->wq; a.sx = q8->sx; a.amax_out = q8->amax_out; }
+    if (q8) { a.wq = q8->wq; a.sx = q8->sx; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.emb = emb; a.tok = tok;
     a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
@@ -486,7 +466,7 @@ int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, 
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    if (q8) { a.wq = q8->wq; a.sx = q8->sx; }                  // (no absmax of a split-K partial: the norm that folds it has the row)
+    if (q8) { a.wq = q8->wq; a.sx = q8->sx; }
     a.xp = reinterpret_cast<const u32x4*>(in); a.epi = MMI_EPI_PARTIAL; a.partial = lm->partial; a.B = lm->batch;
     GemmW gw = g;
     lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); }, (long)g.bytes);
@@ -522,17 +502,16 @@ void add_hidden_tap(mmi_lm* lm, int which) {
 
 // RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
-// amax_out (lm->act8): fold the absmax of the GEMM's OUTPUT rows into that slot; the input is quantised inside (fused: the
-// workgroup holds the whole normalised row) or by the norm launch
+// lm->act8: the normalised row is quantised inside the GEMM (k_gemm_q8, fused) or by the norm launch
 void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alpha, uint16_t* xn_scratch, int D, uint16_t* out,
-                   int out_features, bool out_packed, int epi, const DepKv* kv = nullptr, float* amax_out = nullptr) {
+                   int out_features, bool out_packed, int epi, const DepKv* kv = nullptr) {
     const bool a8 = lm->act8 && g.wq == 1;
     const int wq = a8 ? 3 : g.wq;
     const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         if (a8) {
             add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn);
-            Q8 q{3, lm->sx_dxn, amax_out};
+            Q8 q{3, lm->sx_dxn};
             add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->dxnq), out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv, &q);
             return;
         }
@@ -542,7 +521,6 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.amax_out = amax_out;
     if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
@@ -562,9 +540,9 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
             else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
         } else if (wq == 3) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 3>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 3>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 3>), NT, 512, 0, s, a);
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, true>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, true>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, true>), NT, 512, 0, s, a);
         } else if (wq == 2) {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 2>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 2>), NT, 512, 0, s, a);
@@ -579,15 +557,56 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     }, gbytes);
 }
 
-// bf16 packed tensor + its rows' absmax -> the int8 operand (lm->act8; one small chip-wide launch)
-void add_quant_apply(mmi_lm* lm, const uint16_t* xp, const float* sx, uint8_t* xq, int features) {
-    const int B = lm->batch, T = lm->T, MT = mmi_cdiv(B, T), kp = packed_ksteps(lm, features) / 2;
+// bf16 packed tensor -> its row-wise int8 copy + the rows' absmax (lm->act8): one workgroup per row
+void add_quant_rows(mmi_lm* lm, const uint16_t* xp, uint8_t* xq, float* sx, int features) {
+    const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, features);
     lm->prog.add([=](hipStream_t s) {
-        MMI_LAUNCH(k_quant_apply_i8, mmi_cdiv(MT * kp * 64, 256), 256, 0, s, reinterpret_cast<const u32x4*>(xp), sx,
-                   reinterpret_cast<u32x4*>(xq), B, T, kp, MT);
+        int nth = mmi_cdiv(features / 8, 64) * 64;
+        if (nth > 1024) nth = 1024;
+        MMI_LAUNCH(k_quant_rows_i8, B, nth, 0, s, xp, B, features, T, ksteps, xq, sx);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
+}
+
+// An int8 linear of the depth transformer on a bf16 input WITHOUT a norm in front (out_proj, linear_out, the logits heads) under
+// lm->act8: the row quantisation fused into the GEMM (k_gemm_q8, rows of <= 8 * 11 entries); longer rows: quantisation launch
+// (into the gated tensor's scratch) + the plain int8 x int8 GEMM.
+void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features, uint16_t* out, int out_features, bool out_packed, int epi,
+                 const uint16_t* resid) {
+    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T);
+    const int kmax = g.KSTEPS <= 32 ? 4 : (g.KSTEPS <= 88 ? 11 : 0);
+    if (!kmax || getenv("MMI_NO_NORM_FUSION")) {
+        add_quant_rows(lm, x, lm->hbq, lm->sx_hb, in_features);
+        Q8 q{3, lm->sx_hb};
+        add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->hbq), out, out_features, out_packed, epi, resid, nullptr, nullptr, 0, false, nullptr, &q);
+        return;
+    }
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.B = lm->batch; a.tok_rows = lm->gen_batch;
+    a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
+    a.out_ld = out_features;
+    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
+    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wq = 3; a.xinv = g.xinv; a.osplit = 1;
+    const int NT = g.NT;
+    const long gbytes = (long)g.bytes;
+    lm->prog.add([=](hipStream_t s) {
+        mmi_record_bytes(gbytes);
+        if (kmax == 4) {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, false>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, false>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, false>), NT, 512, 0, s, a);
+        } else {
+            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 11, false>), NT, 512, 0, s, a);
+            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 11, false>), NT, 512, 0, s, a);
+            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 11, false>), NT, 512, 0, s, a);
+        }
+        MMI_CHECK_LAUNCH();
+        return (int)MMI_OK;
+    }, gbytes);
 }
 
 // next_k >= 0: the sampled token opens depth-transformer micro-step next_k, whose input row the sampler writes itself
@@ -704,28 +723,6 @@ TokArgs tok_args(mmi_lm* lm) {
     return t;
 }
 
-// k_dep_layer on by default?  (decided by the same-box A/B of round 4; MMI_DEP_PERSIST overrides)
-bool dep_persist_default(const mmi_lm*) { return MMI_DEP_PERSIST_DEFAULT != 0; }
-
-// the GemmArgs launch_gemm / add_norm_gemm would hand the kernel, for a linear of the persistent depth-transformer layer
-GemmArgs dep_gemm_args(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int out_features, bool out_packed, int epi,
-                       const uint16_t* resid, const uint16_t* alpha, int D, const DepKv* kv) {
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
-    if (kv) { a.kc = kv->kc; a.vc = kv->vc; a.H = kv->H; a.Dh = kv->Dh; a.cap = kv->steps; }
-    a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid;
-    a.tok_rows = lm->gen_batch; a.B = lm->batch;
-    a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
-    a.out_ld = out_features;
-    a.out_ksteps = packed_ksteps(lm, out_features);
-    a.alpha = alpha; a.D = D; a.eps = 1e-8f;
-    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
-    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
-    a.wq = g.wq; a.xinv = g.xinv;
-    a.osplit = alpha ? 1 : plan_osplit(g, plan_gemm(g, false), epi, lm->T);
-    return a;
-}
-
 int build_program(mmi_lm* lm) {
     const mmi_lm_cfg& c = lm->cfg;
     const int B = lm->batch, d = c.dim, H = c.num_heads, Dh = d / H;
@@ -733,18 +730,8 @@ int build_program(mmi_lm* lm) {
     const int n_user = c.n_q - c.dep_q;
     MmiProgram& P = lm->prog;
     const bool a8 = lm->act8;
-    lm->amax_used = 0;
-    lm->dep_args_host.clear();
     // ---- token ring in, embeddings
     P.site("prepare");
-    if (lm->dep_persist) {   // the arrival counters of every persistent layer launch of the step (and the fault word) start at 0
-        unsigned* w = lm->dep_sync; const size_t nb = lm->dep_sync_words * sizeof(unsigned);
-        P.add([=](hipStream_t s) { MMI_HIP_CHECK(hipMemsetAsync(w, 0, nb, s)); return (int)MMI_OK; });
-    }
-    if (a8) {   // the step's absmax slots start at 0 (|x| >= 0: the identity of the atomic max)
-        float* pool = lm->amax_pool; const size_t nb = (size_t)lm->amax_slots * lm->amax_rows * sizeof(float);
-        P.add([=](hipStream_t s) { MMI_HIP_CHECK(hipMemsetAsync(pool, 0, nb, s)); return (int)MMI_OK; });
-    }
     {
         TokArgs t = tok_args(lm);
         const int* user = lm->user_i32; int* tokens = lm->tokens;
@@ -779,7 +766,6 @@ int build_program(mmi_lm* lm) {
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
-        a.amax = new_amax_slot(lm);             // int8 activations: the attention output's row absmax, for out_proj (null otherwise)
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
@@ -801,8 +787,8 @@ int build_program(mmi_lm* lm) {
         });
         P.site("L.out_proj");
         if (a8) {
-            add_quant_apply(lm, lm->att, a.amax, lm->attq, d);
-            Q8 q{3, a.amax, nullptr};
+            add_quant_rows(lm, lm->att, lm->attq, lm->sx_att, d);
+            Q8 q{3, lm->sx_att};
             pending = add_gemm_resid(lm, L.out_proj, reinterpret_cast<const uint16_t*>(lm->attq), lm->x, d, &q);
         } else
         pending = add_gemm_resid(lm, L.out_proj, lm->att, lm->x, d);
@@ -840,13 +826,12 @@ int build_program(mmi_lm* lm) {
         add_resid_rmsnorm(lm, lm->x, pending, L.n2, lm->xn, d, a8 ? lm->xnq : nullptr, a8 ? lm->sx_xn : nullptr);
         P.site("L.ffn_in");
         if (a8) {
-            float* shb = new_amax_slot(lm);       // the gated tensor's row absmax, folded by linear_in's epilogue, read by linear_out
-            Q8 qi{3, lm->sx_xn, shb};
+            Q8 qi{3, lm->sx_xn};
             add_gemm(lm, L.ffn_in, reinterpret_cast<const uint16_t*>(lm->xnq), lm->hb, c.ffn_hidden, true, MMI_EPI_GATE, nullptr, nullptr, nullptr, 0,
                      /*dominant=*/true, nullptr, &qi);
             P.site("L.ffn_out");
-            add_quant_apply(lm, lm->hb, shb, lm->hbq, c.ffn_hidden);
-            Q8 qo{3, shb, nullptr};
+            add_quant_rows(lm, lm->hb, lm->hbq, lm->sx_hb, c.ffn_hidden);
+            Q8 qo{3, lm->sx_hb};
             pending = add_gemm_resid(lm, L.ffn_out, reinterpret_cast<const uint16_t*>(lm->hbq), lm->x, d, &qo);
             continue;
         }
@@ -860,7 +845,7 @@ int build_program(mmi_lm* lm) {
     add_hidden_tap(lm, 1);
     // the int8 linears that read transformer_out (text head, depformer_in) take its int8 copy
     const uint16_t* tout_in = a8 ? reinterpret_cast<const uint16_t*>(lm->toutq) : lm->tout;
-    const Q8 q_tout{3, lm->sx_tout, nullptr};
+    const Q8 q_tout{3, lm->sx_tout};
     const Q8* qt = a8 ? &q_tout : nullptr;
     P.site("text_linear");
     add_gemm(lm, lm->text_linear, tout_in, lm->text_logits, c.text_card_out, false, MMI_EPI_STORE, nullptr, nullptr, nullptr, 0, false, nullptr, qt);
@@ -877,7 +862,6 @@ int build_program(mmi_lm* lm) {
     for (int k = 0; k < c.dep_q; ++k) {
         const int* prev = k == 0 ? lm->text_tok : lm->audio_tok + (k - 1);
         const int prev_stride = k == 0 ? 1 : c.dep_q;
-        float* s_lin = nullptr;          // absmax of the micro-step's final residual stream, for the logits head (int8 activations)
         P.site("dep.in");
         if (!grouped) add_gemm(lm, lm->dep_in[k], tout_in, lm->dx, dd, true, MMI_EPI_EMB, nullptr, lm->dep_emb[k], prev, prev_stride, false, nullptr, qt);
         for (int l = 0; l < c.depformer_num_layers; ++l) {
@@ -887,55 +871,15 @@ int build_program(mmi_lm* lm) {
             // epilogue writes k / v into the frame's cache and v as out_proj's operand, and the attention launch is dropped
             // (bit-identical: 1 * v / 1; MMI_DEP_ATTN0_LAUNCH=1 keeps the launch)
             const bool skip_attn0 = k == 0 && Dhd % 8 == 0 && !getenv("MMI_DEP_ATTN0_LAUNCH");
-            // int8 activations: the small linears of the chain quantise their bf16 input themselves (wq 4) with the row absmax
-            // their producer folded into a slot - the attention (or in_proj's epilogue at micro-step 0), the gated epilogue, and
-            // the last layer's residual epilogue for the logits head
-            float* s_att = new_amax_slot(lm);
-            float* s_hb = new_amax_slot(lm);
-            if (lm->dep_persist) {       // the layer's five stages in ONE launch (k_dep_layer); same bodies, same bits
-                DepLayerArgs dl;
-                memset(&dl, 0, sizeof(dl));
-                DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
-                dl.skip_attn = skip_attn0 ? 1 : 0;
-                dl.in_proj = skip_attn0 ? dep_gemm_args(lm, L.in_proj[k], lm->dx, lm->datt, dd, true, MMI_EPI_DEP_QKV0, nullptr, L.n1, dd, &kv)
-                                        : dep_gemm_args(lm, L.in_proj[k], lm->dx, lm->dqkv, 3 * dd, false, MMI_EPI_STORE, nullptr, L.n1, dd, nullptr);
-                dl.att.qkv = lm->dqkv; dl.att.kc = kv.kc; dl.att.vc = kv.vc; dl.att.out = lm->datt;
-                dl.att.B = B; dl.att.H = Hd; dl.att.Dh = Dhd; dl.att.steps = c.dep_q; dl.att.k = k;
-                dl.att.T = lm->T; dl.att.out_ksteps = packed_ksteps(lm, dd); dl.att.amax = nullptr;
-                dl.out_proj = dep_gemm_args(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, 0, nullptr);
-                dl.ffn_in = dep_gemm_args(lm, L.ffn_in[k], lm->dx, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr, L.n2, dd, nullptr);
-                dl.ffn_out = dep_gemm_args(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, 0, nullptr);
-                dl.n_in = dl.in_proj.NT; dl.n_att = mmi_cdiv(B * Hd, 8);
-                dl.n_out = dl.out_proj.NT * (dl.out_proj.osplit > 1 ? dl.out_proj.osplit : 1);
-                dl.n_fin = dl.ffn_in.NT;
-                dl.n_fout = dl.ffn_out.NT * (dl.ffn_out.osplit > 1 ? dl.ffn_out.osplit : 1);
-                dl.sync = lm->dep_sync + ((size_t)k * c.depformer_num_layers + l) * 32;
-                dl.fault = lm->dep_sync + lm->dep_sync_words - 8;
-                const int T = lm->T, mt = mmi_cdiv(B, lm->T), grid = lm->dep_grid;
-                const long wbytes = (long)(L.in_proj[k].bytes + L.out_proj[k].bytes + L.ffn_in[k].bytes + L.ffn_out[k].bytes);
-                const DepLayerArgs* dla = lm->dep_args + lm->dep_args_host.size();
-                lm->dep_args_host.push_back(dl);
-                P.site("dep.layer");
-                P.add([=](hipStream_t s) {
-                    mmi_record_bytes(wbytes);
-                    if (T == 32 && mt == 1) MMI_LAUNCH((k_dep_layer<32, 1>), grid, 512, 0, s, dla);
-                    else if (T == 32) MMI_LAUNCH((k_dep_layer<32, 2>), grid, 512, 0, s, dla);
-                    else MMI_LAUNCH((k_dep_layer<16, 1>), grid, 512, 0, s, dla);
-                    MMI_CHECK_LAUNCH();
-                    return (int)MMI_OK;
-                }, wbytes);
-                continue;
-            }
             if (skip_attn0) {
                 DepKv kv{lm->dkc + l * dkv_layer, lm->dvc + l * dkv_layer, Hd, Dhd, c.dep_q};
-                add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv, s_att);
+                add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->datt, dd, true, MMI_EPI_DEP_QKV0, &kv);
             } else
             add_norm_gemm(lm, L.in_proj[k], lm->dx, L.n1, lm->dxn, dd, lm->dqkv, 3 * dd, false, MMI_EPI_STORE);
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
-            da.amax = s_att;
             P.site("dep.attn");
             const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8;        // else the general one-wave-per-(session, head) kernel
             if (!skip_attn0)
@@ -945,20 +889,20 @@ int build_program(mmi_lm* lm) {
                 MMI_CHECK_LAUNCH();
                 return (int)MMI_OK;
             });
-            const bool last = l + 1 == c.depformer_num_layers;
-            if (a8 && last) s_lin = new_amax_slot(lm);
-            const Q8 q_att{4, s_att, nullptr}, q_hb{4, s_hb, last ? s_lin : nullptr};
+            // int8 activations: the chain's linears quantise their own input row inside the GEMM (k_gemm_q8)
             P.site("dep.out_proj");
-            add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, nullptr, 0, false, nullptr, a8 ? &q_att : nullptr);
+            if (a8) add_q8_gemm(lm, L.out_proj[k], lm->datt, dd, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            else add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
             P.site("dep.ffn_in");
-            add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE, nullptr, s_hb);
+            add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE);
             P.site("dep.ffn_out");
-            add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx, nullptr, nullptr, 0, false, nullptr, a8 ? &q_hb : nullptr);
+            if (a8) add_q8_gemm(lm, L.ffn_out[k], lm->dhb, c.depformer_ffn_hidden, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            else add_gemm(lm, L.ffn_out[k], lm->dhb, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
         }
         uint16_t* lg = lm->dlogits + (size_t)k * B * c.card;
-        const Q8 q_lin{4, s_lin, nullptr};
         P.site("dep.lin");
-        add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr, nullptr, nullptr, 0, false, nullptr, a8 ? &q_lin : nullptr);
+        if (a8) add_q8_gemm(lm, lm->dep_lin[k], lm->dx, dd, lg, c.card, false, MMI_EPI_STORE, nullptr);
+        else add_gemm(lm, lm->dep_lin[k], lm->dx, lg, c.card, false, MMI_EPI_STORE, nullptr);
         P.site("dep.sample");
         add_sample(lm, lg, c.card, c.card, false, 1 + k, lm->audio_tok + k, c.dep_q, grouped && k + 1 < c.dep_q ? k + 1 : -1);
     }
@@ -974,8 +918,6 @@ int build_program(mmi_lm* lm) {
             return (int)MMI_OK;
         });
     }
-    if (!lm->dep_args_host.empty())
-        MMI_HIP_CHECK(hipMemcpy(lm->dep_args, lm->dep_args_host.data(), lm->dep_args_host.size() * sizeof(DepLayerArgs), hipMemcpyHostToDevice));
     return MMI_OK;
 }
 
@@ -1286,45 +1228,25 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     lm->htap = nullptr;
     if (lm->hidden_taps) ok &= hipSuccess == A.alloc(&lm->htap, (size_t)2 * B * d);
-    {   // persistent depth-transformer layers: bf16 linears, heads of whole 16-byte chunks, <= 8 positions, rows of <= 64 k-steps
-        const char* ep = getenv("MMI_DEP_PERSIST");
-        const bool want = ep && ep[0] ? ep[0] != '0' : dep_persist_default(lm);
-        const int ks_dd = mmi_cdiv(dd, mmi_kstep(lm->T));
-        // (two batch tiles - 33..64 sessions - keep the launch list: the fused kernel's register budget does not hold the second tile)
-        lm->dep_persist = want && c.dep_q > 0 && lm->q8 == 0 && Dhd % 8 == 0 && Dhd <= 64 && c.dep_q <= 8 && ks_dd <= 64 && B <= lm->T &&
-                          !getenv("MMI_NO_NORM_FUSION") && !getenv("MMI_DEP_ATTN0_LAUNCH");
-        lm->dep_sync = nullptr;
-        lm->dep_sync_words = 0;
-        if (lm->dep_persist) {
-            int cus = 256;
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, lm->device);
-            lm->dep_grid = cus > 0 ? cus : 256;
-            if (const char* eg = getenv("MMI_DEP_PERSIST_GRID")) { const int v = atoi(eg); if (v >= 1) lm->dep_grid = v; }
-            lm->dep_sync_words = (size_t)c.dep_q * c.depformer_num_layers * 32 + 8;
-            ok &= hipSuccess == A.alloc(&lm->dep_sync, lm->dep_sync_words);
-            ok &= hipSuccess == A.alloc(&lm->dep_args, (size_t)c.dep_q * c.depformer_num_layers);
-        }
-    }
     {   // int8 activations (see mmi_lm::act8)
         const char* e8 = getenv("MMI_Q8_ACT");
         lm->act8 = lm->q8 == 1 && !c.cross_attention && !(e8 && e8[0] == 'b');
         lm->xnq = lm->attq = lm->hbq = lm->toutq = lm->dxnq = nullptr;
-        lm->sx_xn = lm->sx_tout = lm->sx_dxn = lm->amax_pool = nullptr;
-        lm->amax_slots = lm->amax_used = 0;
+        lm->sx_xn = lm->sx_tout = lm->sx_dxn = lm->sx_att = lm->sx_hb = nullptr;
         if (lm->act8) {
             const size_t mtiles = (size_t)mmi_cdiv(B, lm->T);
             auto qbytes = [&](int features) { return mtiles * (size_t)(packed_ksteps(lm, features) / 2) * 1024; };
-            lm->amax_rows = (int)mtiles * lm->T;
-            lm->amax_slots = c.num_layers * 2 + c.dep_q * (c.depformer_num_layers * 2 + 1) + 4;
+            const size_t rows = mtiles * lm->T;
             ok &= hipSuccess == A.alloc(&lm->xnq, qbytes(d));
             ok &= hipSuccess == A.alloc(&lm->attq, qbytes(d));
-            ok &= hipSuccess == A.alloc(&lm->hbq, qbytes(c.ffn_hidden));
+            ok &= hipSuccess == A.alloc(&lm->hbq, qbytes(c.ffn_hidden > c.depformer_ffn_hidden ? c.ffn_hidden : c.depformer_ffn_hidden));
             ok &= hipSuccess == A.alloc(&lm->toutq, qbytes(d));
             ok &= hipSuccess == A.alloc(&lm->dxnq, qbytes(dd > 0 ? dd : 8));
-            ok &= hipSuccess == A.alloc(&lm->sx_xn, (size_t)lm->amax_rows);
-            ok &= hipSuccess == A.alloc(&lm->sx_tout, (size_t)lm->amax_rows);
-            ok &= hipSuccess == A.alloc(&lm->sx_dxn, (size_t)lm->amax_rows);
-            ok &= hipSuccess == A.alloc(&lm->amax_pool, (size_t)lm->amax_slots * lm->amax_rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_xn, rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_tout, rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_dxn, rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_att, rows);
+            ok &= hipSuccess == A.alloc(&lm->sx_hb, rows);
         }
     }
     ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
@@ -1617,14 +1539,6 @@ extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream
 }
 
 extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
-    if (lm && which == 1) {          // edges of the persistent depth-transformer layers that gave up since the last step began (0 = none)
-        if (!lm->dep_sync) return 0;
-        MmiDeviceGuard dev_guard_(lm->device);
-        unsigned f = 0;
-        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, lm->dep_sync + lm->dep_sync_words - 8, sizeof(f), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        return (int64_t)f;
-    }
-    if (lm && which == 2) return lm->dep_persist ? 1 : 0;
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return -1;
     return which == 0 ? (int64_t)lm->xlds_launches : -1;

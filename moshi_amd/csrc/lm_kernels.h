@@ -142,7 +142,6 @@ __device__ __forceinline__ float mmi_absmax_bf16x8(u32x4 v) {
     }
     return m;
 }
-// (mmi_amax_fold - row absmax -> atomic slot - lives in mmi_device.h)
 // CA = int8(round_half_even(x * (127 / SCA))): 8 bf16 values -> 8 bytes (scale = 127 / SCA, 0 for an all-zero row)
 __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     u32x2 r;
@@ -161,21 +160,6 @@ __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     return r;
 }
 __device__ __forceinline__ float mmi_i8_scale(float sca) { return sca > 0.f ? 127.0f / sca : 0.f; }
-
-// ---- tensors handed from one workgroup to another INSIDE a launch (k_dep_layer) -------------------------------------------------
-// COH = true: 16 bytes as two 8-byte agent-scope relaxed atomics (global_load/store_dwordx2 sc1: served by / written through to
-// the L2, never the CU's L1) - with the hand-off counters of mmi_edge_sync the "8-byte agent atomics on both sides" form of
-// the guide's cross-workgroup visibility rules: no fence, no L2 write-back / invalidate.  COH = false: plain vector access.
-template <bool COH>
-__device__ __forceinline__ u32x4 mmi_ldx(const u32x4* p) {
-    if constexpr (COH) return mmi_ld_coh16(p);
-    else return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void mmi_stx(u32x4* p, u32x4 v) {
-    if constexpr (COH) mmi_st_coh16(p, v);
-    else *p = v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
@@ -204,9 +188,6 @@ struct GemmArgs {
     const float* wscale;    // int8 / fp8 weights: dequantisation factor per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
     float xinv;             // fp8: 1 / input_scale, applied to the activations before the e4m3 conversion
     int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights, 3 int8 weights x int8 activations
-    float* amax_out;        // int8 activations: the epilogue folds max |y| of the bf16 values it writes into amax_out[b] (atomic max of the
-                            // bit patterns of non-negative floats: order-independent, so deterministic) - the row absmax (bitsandbytes'
-                            // SCA) the NEXT linear quantises this tensor with; the slots are zeroed once per step
     const float* sx;        // WQ = 3 with pre-quantised activations: xp holds int8 entries Xq[mt][kp][lane][16] (k_quant_rows_i8 / the
                             // norm kernel) and sx[b] the row absmax they were scaled by (bitsandbytes' SCA); the epilogue multiplies
                             // the int32 sum by SCA[b] / 127 * SCB[n] / 127.  k_gemm_q8: written here for the epilogue (LDS)
@@ -237,7 +218,7 @@ struct GemmArgs {
 
 // The residual (or embedding) vector the thread's FIRST epilogue task will add, requested before the weight stream starts
 // so that its latency is hidden behind the main loop instead of extending the epilogue.
-template <int TN, int MT, int NTW, bool COH = false>
+template <int TN, int MT, int NTW>
 __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int nt0) {
     u32x4 pre = {0u, 0u, 0u, 0u};
     if (a.epi != MMI_EPI_RESID && a.epi != MMI_EPI_EMB) return pre;
@@ -253,7 +234,7 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
     if (nt >= a.NT || b >= a.B || n0 >= a.N) return pre;
     if (a.epi == MMI_EPI_RESID) {
         const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps) : a.resid + (long)b * a.out_ld + n0;
-        pre = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(rs));
+        pre = *reinterpret_cast<const u32x4*>(rs);
     } else {
         const int tk = a.tok[(long)(b % a.tok_rows) * a.tok_stride];
         if (tk != -1) pre = *reinterpret_cast<const u32x4*>(a.emb + (long)(tk < 0 ? 0 : tk) * a.N + n0);   // lm_utils.py:102-124
@@ -267,7 +248,7 @@ __device__ __forceinline__ u32x4 mmi_gemm_prefetch_addend(const GemmArgs& a, int
 // kernels that own all of the LDS themselves (k_gemm_xlds).
 // g_lo / g_hi: only the tile's 8-feature groups [g_lo, g_hi) are written (k_gemm_xlds hands a tile's row octets to two
 // workgroups when that balances the chip: 384 in_proj tiles over 256 CUs = 6 octets each); default = the whole tile.
-template <int TN, int MT, int NTW, int WAVES, bool EXT = false, bool COH = false>
+template <int TN, int MT, int NTW, int WAVES, bool EXT = false>
 __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&accv)[NTW][MT][TN == 32 ? 16 : 4], int wave, int lane,
                                                   int nt0, u32x4 pre, float* red_ext = nullptr, int g_lo = 0, int g_hi = 4,
                                                   const float* sx_local = nullptr) {
@@ -374,11 +355,8 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(s[2 * e], s[2 * e + 1]);      // nn.Linear output in bf16
             uint16_t* cache = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap) * a.Dh + d0;
-            mmi_stx<COH>(reinterpret_cast<u32x4*>(cache), ov);
-            if (sec == 2) {
-                mmi_stx<COH>(reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)), ov);
-                if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
-            }
+            *reinterpret_cast<u32x4*>(cache) = ov;
+            if (sec == 2) *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(TN, b, hn, a.out_ksteps)) = ov;
             continue;
         }
         if (a.epi == MMI_EPI_ROPE_KV) {
@@ -430,7 +408,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         } else if (a.epi == MMI_EPI_RESID) {
             const uint16_t* rs = a.out_mode == MMI_OUT_PACKED ? a.resid + mmi_xp_index(TN, b, n0, a.out_ksteps)
                                                               : a.resid + (long)b * a.out_ld + n0;
-            const u32x4 rv = q == (int)threadIdx.x ? pre : mmi_ldx<COH>(reinterpret_cast<const u32x4*>(rs));
+            const u32x4 rv = q == (int)threadIdx.x ? pre : *reinterpret_cast<const u32x4*>(rs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint16_t h = (uint16_t)((e & 1) ? (rv[e >> 1] >> 16) : (rv[e >> 1] & 0xffffu));
@@ -455,8 +433,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         u32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e], o[2 * e + 1]);
-        mmi_stx<COH>(reinterpret_cast<u32x4*>(dst), ov);
-        if (a.amax_out) mmi_amax_fold(a.amax_out + b, mmi_absmax_bf16x8(ov));
+        *reinterpret_cast<u32x4*>(dst) = ov;
     }
 }
 
@@ -464,41 +441,28 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 // (a.KSTEPS then counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
 // WQ = 3: int8 weight entries x int8 activation entries (a.xp = Xq, one 16-byte entry per weight entry, a.sx = row absmax) on
 // v_mfma_i32_{32x32x32,16x16x64}_i8; the int32 sums are converted to fp32 once per wave and go through the common epilogue.
-// The kernel's body as a function of a VIRTUAL block index (vbx, vby of vgy): k_gemm_xp passes its own, the persistent
-// depth-transformer layer (k_dep_layer) walks its work items through it.  COH: activations / residual / outputs are tensors
-// handed over inside the launch (mmi_ldx / mmi_stx).
-template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0, bool COH = false>
-__device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vbx, const int vby, const int vgy) {
+template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
-    constexpr int XS = (WQ == 1 || WQ == 2 || WQ == 4) ? 2 : 1;   // activation fragments per weight entry
+    constexpr int XS = (WQ == 1 || WQ == 2) ? 2 : 1;   // activation fragments per weight entry
     typedef int iacc_t __attribute__((ext_vector_type(R)));
-    // WQ = 4: int8 weights x bf16 activations that are quantised HERE, entry by entry, with the row absmax a.sx[b] the producer
-    // left behind (the depth transformer's small linears: no separate quantisation launch on their dependent chain)
-    float qs4[MT];
-    if constexpr (WQ == 4) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int bq = m * TN + ((int)threadIdx.x & (TN - 1));
-            qs4[m] = mmi_i8_scale(a.sx[bq < a.B ? bq : a.B - 1]);
-        }
-    }
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     // octet sharing (a.osplit > 1, NTW == 1): workgroup = (n-tile, part); part owns the 8-feature groups [g_lo, g_hi)
     const int os = (NTW == 1 && a.osplit > 1) ? a.osplit : 1;
-    const int bx = vbx / os, part = vbx - bx * os;
+    const int bx = (int)blockIdx.x / os, part = (int)blockIdx.x - bx * os;
     const int nt0 = bx * NTW;
     const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
     // weight fragments are stored [k-step][lane], lane = (k-group, row): rows of octets the workgroup does not own are read
     // from the first owned octet instead
     const int ro = (lane >> 3) & (TN / 8 - 1);
     const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
-    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW, COH>(a, nt0);
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, NTW>(a, nt0);
 
     // K range of this workgroup (gridDim.y > 1: split-K over workgroups), then of this wave
-    const int kb_per = (a.KSTEPS + vgy - 1) / vgy;
-    const int kb0 = min(a.KSTEPS, vby * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
+    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
     const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;
     const int ks0 = min(kb1, kb0 + wave * kper);
     const int nks = min(kb1, ks0 + kper) - ks0;
@@ -523,7 +487,7 @@ __device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vb
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) W_[u][t] = mmi_load_nt(wp[t] + ((base) + u) * 64); \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
-            _Pragma("unroll") for (int x = 0; x < XS; ++x) X_[u][m][x] = mmi_ldx<COH>(xp[m] + (((base) + u) * XS + x) * 64); \
+            _Pragma("unroll") for (int x = 0; x < XS; ++x) X_[u][m][x] = xp[m][(((base) + u) * XS + x) * 64]; \
     }
 #define MMI_G_MFMA(WF, XF, ACC)                                                               \
     if constexpr (TN == 32) ACC = mmi_mfma_bf16_32x32x16(WF, XF, ACC);                        \
@@ -548,16 +512,7 @@ __device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vb
     }
 #define MMI_G_MMA1(W_, X_, u)                                                                 \
         if constexpr (WQ == 2) MMI_G_MMA8(W_, X_, u)                                          \
-        else if constexpr (WQ == 4) {                                                         \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                  \
-                const u32x2 qlo_ = mmi_quant_i8x8(X_[u][m][0], qs4[m]), qhi_ = mmi_quant_i8x8(X_[u][m][1], qs4[m]); \
-                const u32x4 xq_ = {qlo_[0], qlo_[1], qhi_[0], qhi_[1]};                       \
-                _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                             \
-                    if constexpr (TN == 32) acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(W_[u][t], xq_, __builtin_bit_cast(iacc_t, acc[t][m]))); \
-                    else acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_16x16x64(W_[u][t], xq_, __builtin_bit_cast(iacc_t, acc[t][m]))); \
-                }                                                                             \
-            }                                                                                 \
-        } else if constexpr (WQ == 3) {                                                       \
+        else if constexpr (WQ == 3) {                                                       \
             _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                   \
                 _Pragma("unroll") for (int m = 0; m < MT; ++m) {                              \
                     if constexpr (TN == 32) acc[t][m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(W_[u][t], X_[u][m][0], __builtin_bit_cast(iacc_t, acc[t][m]))); \
@@ -611,7 +566,7 @@ __device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vb
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int x = 0; x < XS; ++x) xA[u][m][x] = mmi_ldx<COH>(xp[m] + (ks * XS + x) * 64);
+                for (int x = 0; x < XS; ++x) xA[u][m][x] = xp[m][(ks * XS + x) * 64];
         }
 #pragma unroll
         for (int u = 0; u < U - 1; ++u)
@@ -630,15 +585,10 @@ __device__ __forceinline__ void mmi_gemm_xp_body(const GemmArgs& a, const int vb
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if constexpr (WQ == 3 || WQ == 4) accv[t][m][r] = (float)__builtin_bit_cast(iacc_t, acc[t][m])[r];   // the wave's int32 sum
+                if constexpr (WQ == 3) accv[t][m][r] = (float)__builtin_bit_cast(iacc_t, acc[t][m])[r];   // the wave's int32 sum
                 else accv[t][m][r] = acc[t][m][r];
             }
-    mmi_gemm_epilogue<TN, MT, NTW, WAVES, false, COH>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
-}
-
-template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
-    mmi_gemm_xp_body<TN, MT, NTW, WAVES, U, WQ>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
 
 // RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
@@ -647,20 +597,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // everything in flight at once, these GEMMs are latency bound - the waves combine their sums of squares through
 // LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
 // WQ = 1 / 2: int8 / fp8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
-// WQ = 3: int8 weights x int8 activations - the normalised row (a bf16 tensor, held in registers) is quantised row-wise like
-// bitsandbytes' int8_vectorwise_quant: the workgroup reduces its absmax through LDS next to the sum of squares, every lane
-// converts its own fragments, and the int32 sums are scaled by SCA[b] * SCB[n] / 127^2 in the epilogue.
-template <int TN, int MT, int WAVES, int KMAX, int WQ = 0, bool COH = false>
-__device__ __forceinline__ void mmi_gemm_xp_norm_body(const GemmArgs& a, const int vbx) {
+template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
     constexpr int XS = WQ ? 2 : 1;
-    typedef int iacc_t __attribute__((ext_vector_type(R)));
     constexpr int XMAX = KMAX * XS;                           // activation fragments per wave
     typedef float acc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = vbx;                          // one n-tile per workgroup (octet sharing of these GEMMs measured
+    const int nt0 = (int)blockIdx.x;                          // one n-tile per workgroup (octet sharing of these GEMMs measured
     const int g_lo = 0, g_hi = TN / 8, wlane = lane;          // neutral, profiles/r02_logs/ab_osplit_norm*: not built in)
     const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
     const int ks0 = min(a.KSTEPS, wave * kper);
@@ -682,7 +628,7 @@ __device__ __forceinline__ void mmi_gemm_xp_norm_body(const GemmArgs& a, const i
             const int k = ((ksl + uu) * XS + x) * KS + 8 * kq;
             al[u * XS + x] = *reinterpret_cast<const u32x4*>(a.alpha + min(k, dmax));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xv[m][u * XS + x] = mmi_ldx<COH>(a.xp + (((long)m * a.KSTEPS + ksl + uu) * XS + x) * 64 + lane);
+            for (int m = 0; m < MT; ++m) xv[m][u * XS + x] = a.xp[(((long)m * a.KSTEPS + ksl + uu) * XS + x) * 64 + lane];
         }
     }
 #pragma unroll
@@ -728,50 +674,6 @@ __device__ __forceinline__ void mmi_gemm_xp_norm_body(const GemmArgs& a, const i
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-    MMI_SHARED float sxl[MT * TN];                     // WQ = 3: the rows' absmax, for the epilogue
-    if constexpr (WQ == 3) {
-        MMI_SHARED float amx[WAVES][MT][TN];
-        float scl[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float am = 0.f;
-#pragma unroll
-            for (int u = 0; u < XMAX; ++u) {
-                u32x4 xn;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4& xr = xv[m][u];
-                    const u32x4& ar = al[u];
-                    const float lo = mmi_bf16_to_f32((uint16_t)(xr[q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xr[q] >> 16));
-                    const float alo = mmi_bf16_to_f32((uint16_t)(ar[q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(ar[q] >> 16));
-                    xn[q] = mmi_pack_bf16x2(lo * (alo * rs[m]), hi * (ahi * rs[m]));
-                }
-                xv[m][u] = xn;                          // the norm's output, a bf16 tensor: what the linear quantises
-                am = fmaxf(am, mmi_absmax_bf16x8(xn));
-            }
-            if constexpr (TN == 32) am = fmaxf(am, mmi_shfl_xor(am, 32));
-            else { am = fmaxf(am, mmi_shfl_xor(am, 16)); am = fmaxf(am, mmi_shfl_xor(am, 32)); }
-            if (lane < TN) amx[wave][m][lane] = am;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot = fmaxf(tot, amx[w][m][lane & (TN - 1)]);
-            scl[m] = mmi_i8_scale(tot);
-            if (wave == 0 && lane < TN) sxl[m * TN + lane] = tot;
-        }
-#pragma unroll
-        for (int u = 0; u < KMAX; ++u)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x2 qlo = mmi_quant_i8x8(xv[m][2 * u], scl[m]), qhi = mmi_quant_i8x8(xv[m][2 * u + 1], scl[m]);
-                const u32x4 xq = {qlo[0], qlo[1], qhi[0], qhi[1]};
-                if constexpr (TN == 32) acc[m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_32x32x32(wv[u], xq, __builtin_bit_cast(iacc_t, acc[m])));
-                else acc[m] = __builtin_bit_cast(acc_t, mmi_mfma_i8_16x16x64(wv[u], xq, __builtin_bit_cast(iacc_t, acc[m])));
-            }
-    } else
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         u32x4 wf[XS];
@@ -805,15 +707,123 @@ __device__ __forceinline__ void mmi_gemm_xp_norm_body(const GemmArgs& a, const i
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if constexpr (WQ == 3) accv[0][m][r] = (float)__builtin_bit_cast(iacc_t, acc[m])[r];
-            else accv[0][m][r] = acc[m][r];
+            accv[0][m][r] = acc[m][r];
         }
-    mmi_gemm_epilogue<TN, MT, 1, WAVES, false, COH>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi, WQ == 3 ? sxl : nullptr);
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, u32x4{0u, 0u, 0u, 0u}, nullptr, g_lo, g_hi);
 }
 
-template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
-    mmi_gemm_xp_norm_body<TN, MT, WAVES, KMAX, WQ>(a, (int)blockIdx.x);
+// int8 weights x int8 activations with the row quantisation INSIDE the GEMM (the depth transformer's linears, whose rows are
+// short enough - <= 8 * KMAX entries of 32 / 64 k - for one workgroup to hold): bitsandbytes' int8_vectorwise_quant needs the
+// absmax of the WHOLE input row, and every workgroup of these N-split GEMMs reads the whole row anyway, so each derives it
+// itself - no extra launch on the depth transformer's dependent chain, no cross-workgroup traffic.  Per batch tile: the wave's
+// bf16 fragments are loaded in one go, (NORM: RMSNorm'ed in registers exactly as k_gemm_xp_norm does - the norm's output is the
+// bf16 tensor the linear quantises,) the block reduces the rows' absmax through LDS, every lane converts its own fragments
+// (round half even) and feeds v_mfma_i32_{32x32x32,16x16x64}_i8; the epilogue scales the int32 sums by SCA[b] * SCB[n] / 127^2.
+// a.KSTEPS counts weight entries (two bf16 k-steps each).
+template <int TN, int MT, int WAVES, int KMAX, bool NORM>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
+    constexpr int R = TN == 32 ? 16 : 4;
+    constexpr int KS = TN == 32 ? 16 : 32;
+    constexpr int XMAX = 2 * KMAX;
+    typedef int iacc_t __attribute__((ext_vector_type(R)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int nt0 = (int)blockIdx.x;
+    const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
+    const int ks0 = min(a.KSTEPS, wave * kper);
+    const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
+    const int kq = TN == 32 ? (lane >> 5) : (lane >> 4);
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, 1>(a, nt0);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const int ksl = min(ks0, a.KSTEPS - 1);
+    u32x4 wv[KMAX];
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        const int uu = min(u, nks > 0 ? nks - 1 : 0);
+        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + lane);
+    }
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) if (u >= nks) wv[u] = zero;
+    MMI_SHARED float sxl[MT * TN];                       // the rows' absmax, for the epilogue
+    MMI_SHARED float redl[2][WAVES][TN];                 // [0] sums of squares, [1] absmax, per wave
+    iacc_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        // unconditional loads from clamped (valid) addresses, masked afterwards (a load under a branch would be serialised)
+        u32x4 xv[XMAX], al[NORM ? XMAX : 1];
+        const int dmax = (a.D - 8) > 0 ? (a.D - 8) : 0;
+#pragma unroll
+        for (int u = 0; u < XMAX; ++u) {
+            const int uu = min(u >> 1, nks > 0 ? nks - 1 : 0);
+            xv[u] = a.xp[(((long)m * a.KSTEPS + ksl + uu) * 2 + (u & 1)) * 64 + lane];
+            if constexpr (NORM) al[u] = *reinterpret_cast<const u32x4*>(a.alpha + min(((ksl + uu) * 2 + (u & 1)) * KS + 8 * kq, dmax));
+        }
+#pragma unroll
+        for (int u = 0; u < XMAX; ++u) {
+            const bool on = (u >> 1) < nks;
+            if (!on) xv[u] = zero;
+            if constexpr (NORM) { if (!on || ((ks0 + (u >> 1)) * 2 + (u & 1)) * KS + 8 * kq >= a.D) al[u] = zero; }
+        }
+        if constexpr (NORM) {       // y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16)   (transformer.py:45-58)
+            float ss = 0.f;
+#pragma unroll
+            for (int u = 0; u < XMAX; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = mmi_bf16_to_f32((uint16_t)(xv[u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[u][q] >> 16));
+                    ss += lo * lo;
+                    ss += hi * hi;
+                }
+            if constexpr (TN == 32) ss += mmi_shfl_xor(ss, 32);
+            else { ss += mmi_shfl_xor(ss, 16); ss += mmi_shfl_xor(ss, 32); }
+            if (lane < TN) redl[0][wave][lane] = ss;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) tot += redl[0][w][lane & (TN - 1)];
+            const float rs = mmi_rsqrtf(a.eps + tot / (float)a.D);
+#pragma unroll
+            for (int u = 0; u < XMAX; ++u) {
+                u32x4 xn;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = mmi_bf16_to_f32((uint16_t)(xv[u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[u][q] >> 16));
+                    const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
+                    xn[q] = mmi_pack_bf16x2(lo * (alo * rs), hi * (ahi * rs));
+                }
+                xv[u] = xn;
+            }
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int u = 0; u < XMAX; ++u) am = fmaxf(am, mmi_absmax_bf16x8(xv[u]));
+        if constexpr (TN == 32) am = fmaxf(am, mmi_shfl_xor(am, 32));
+        else { am = fmaxf(am, mmi_shfl_xor(am, 16)); am = fmaxf(am, mmi_shfl_xor(am, 32)); }
+        if (lane < TN) redl[1][wave][lane] = am;
+        __syncthreads();
+        float sca = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sca = fmaxf(sca, redl[1][w][lane & (TN - 1)]);
+        if (wave == 0 && lane < TN) sxl[m * TN + lane] = sca;
+        const float scale = mmi_i8_scale(sca);
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            const u32x2 qlo = mmi_quant_i8x8(xv[2 * u], scale), qhi = mmi_quant_i8x8(xv[2 * u + 1], scale);
+            const u32x4 xq = {qlo[0], qlo[1], qhi[0], qhi[1]};
+            if constexpr (TN == 32) acc[m] = mmi_mfma_i8_32x32x32(wv[u], xq, acc[m]);
+            else acc[m] = mmi_mfma_i8_16x16x64(wv[u], xq, acc[m]);
+        }
+        __syncthreads();                                 // redl is rewritten by the next batch tile; sxl is read by the epilogue
+    }
+    float accv[1][MT][R];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) accv[0][m][r] = (float)acc[m][r];
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, 0, TN / 8, sxl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1099,20 +1109,41 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
     }
 }
 
-// packed bf16 activations + the rows' absmax sx[b] (left behind by the producing epilogues / attention kernels) -> the int8
-// operand Xq[mt][kp][lane][16] of the int8 x int8 linears; one thread per 16-byte entry (two bf16 fragments in, one out)
-__global__ void k_quant_apply_i8(const u32x4* __restrict__ xp, const float* __restrict__ sx, u32x4* __restrict__ xq, int B, int T,
-                                 int kp_total, int MT) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)MT * kp_total * 64) return;
-    const int lane = (int)(idx & 63);
-    const long rest = idx >> 6;
-    const int kp = (int)(rest % kp_total), mt = (int)(rest / kp_total);
-    const int b = mt * T + (lane & (T - 1));
-    const float scale = mmi_i8_scale(sx[b < B ? b : B - 1]);
-    const u32x4 lo = xp[(((long)mt * 2 * kp_total) + 2 * kp) * 64 + lane], hi = xp[(((long)mt * 2 * kp_total) + 2 * kp + 1) * 64 + lane];
-    const u32x2 qlo = mmi_quant_i8x8(lo, scale), qhi = mmi_quant_i8x8(hi, scale);
-    xq[idx] = u32x4{qlo[0], qlo[1], qhi[0], qhi[1]};
+// A packed bf16 tensor [B][D] -> its row-wise int8 copy Xq[mt][kp][lane][16] + the rows' absmax sx[b] (bitsandbytes'
+// int8_vectorwise_quant), for the int8 linears whose input is written by MANY workgroups (the temporal attention output, the
+// gated FFN tensor): one workgroup per row holds the row in registers (as the norm kernel does), reduces the absmax, converts.
+__global__ __launch_bounds__(1024) void k_quant_rows_i8(const uint16_t* __restrict__ x, int B, int D, int T, int ksteps,
+                                                        uint8_t* __restrict__ xq, float* __restrict__ sx) {
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    u32x4 v[MMI_NORM_MAXP];
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        v[j] = *reinterpret_cast<const u32x4*>(x + mmi_xp_index(T, b, i, ksteps));
+        am = fmaxf(am, mmi_absmax_bf16x8(v[j]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) am = fmaxf(am, mmi_shfl_xor(am, m));
+    MMI_SHARED float redm[16];
+    if ((tid & 63) == 0) redm[tid >> 6] = am;
+    __syncthreads();
+    float sca = 0.f;
+    for (int w = 0; w < (nth + 63) / 64; ++w) sca = fmaxf(sca, redm[w]);
+    if (tid == 0) sx[b] = sca;
+    const float scale = mmi_i8_scale(sca);
+#pragma unroll
+    for (int j = 0; j < MMI_NORM_MAXP; ++j) {
+        const int i = (tid + j * nth) * 8;
+        if (i >= D) break;
+        const long at = mmi_xp_index(T, b, i, ksteps);
+        const long frag = at >> 9;
+        const int ln = (int)((at >> 3) & 63);
+        const long mt = frag / ksteps;
+        const int ks = (int)(frag - mt * ksteps);
+        *reinterpret_cast<u32x2*>(xq + ((mt * (ksteps >> 1) + (ks >> 1)) * 64 + ln) * 16 + (ks & 1) * 8) = mmi_quant_i8x8(v[j], scale);
+    }
 }
 
 // The cross-attention block's norm (transformer.py:731-732, 779-783: `norm_cross` is always an nn.LayerNorm with weight and
@@ -1319,15 +1350,7 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
-    float* amax;           // int8 activations: row absmax slot of the output (folded atomically, see GemmArgs::amax_out), or null
 };
-
-// max |bf16(o)| of the calling wave's lanes (inactive lanes pass 0) -> the row's absmax slot
-__device__ __forceinline__ void mmi_amax_fold_wave(float* slot, float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, mmi_shfl_xor(v, m));
-    if (((int)threadIdx.x & 63) == 0) mmi_amax_fold(slot, v);
-}
 
 #define MMI_ATTN_CHUNK 256
 // Decode attention of the one new query per (session, head) over the VALID part of the ring only (the reference reads
@@ -1475,10 +1498,6 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
         for (int e = 0; e < EPL; ++e) ored[wave * DH + seg * EPL + e] = acc[e];
     }
     __syncthreads();
-    if (gridDim.y == 1 && a.amax && tid < ((DH + 63) & ~63)) {       // whole waves: the shuffle reduction needs every lane
-        const float o = tid < DH ? (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]) : 0.f;
-        mmi_amax_fold_wave(a.amax + b, tid < DH ? fabsf(mmi_round_bf16(o / l_run)) : 0.f);
-    }
     if (tid < DH) {
         const float o = (ored[tid] + ored[DH + tid]) + (ored[2 * DH + tid] + ored[3 * DH + tid]);
         if (gridDim.y == 1) {
@@ -1630,21 +1649,16 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
         if (seg == 0) { wm[wave] = m_run; wl[wave] = l_run; }
     }
     __syncthreads();
-    if (tid < ((DH + 63) & ~63)) {                       // whole waves (DH = 32: lanes 32..63 idle but present for the shuffles)
+    if (tid < DH) {
         const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        float num = 0.f, den = 1.f;
-        if (tid < DH) {
-            den = 0.f;
+        float num = 0.f, den = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float sw = wm[w] == -INFINITY ? 0.f : expf(wm[w] - M);
-                num += sw * wacc[w * DH + tid];
-                den += sw * wl[w];
-            }
+        for (int w = 0; w < 4; ++w) {
+            const float sw = wm[w] == -INFINITY ? 0.f : expf(wm[w] - M);
+            num += sw * wacc[w * DH + tid];
+            den += sw * wl[w];
         }
-        if (gridDim.y == 1 && a.amax) mmi_amax_fold_wave(a.amax + b, tid < DH ? fabsf(mmi_round_bf16(num / den)) : 0.f);
-        if (tid >= DH) {
-        } else if (gridDim.y == 1) {
+        if (gridDim.y == 1) {
             a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
         } else {
             a.opart[((long)bh * gridDim.y + blockIdx.y) * DH + tid] = num;
@@ -1664,7 +1678,6 @@ __global__ void k_lm_attn_combine(LmAttnArgs a) {
     const float* ml = a.ml + (long)bh * a.NS * 2;
     float M = -INFINITY;
     for (int c = 0; c < a.NS; ++c) M = fmaxf(M, ml[2 * c]);
-    float am = 0.f;
     for (int d = threadIdx.x; d < Dh; d += blockDim.x) {
         float num = 0.f, den = 0.f;
         for (int c = 0; c < a.NS; ++c) {
@@ -1675,9 +1688,7 @@ __global__ void k_lm_attn_combine(LmAttnArgs a) {
             den += w * ml[2 * c + 1];
         }
         a.out[mmi_xp_index(a.T, bh / a.H, (bh % a.H) * Dh + d, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
-        am = fmaxf(am, fabsf(mmi_round_bf16(num / den)));
     }
-    if (a.amax) mmi_amax_fold_wave(a.amax + bh / a.H, am);      // blockDim is a multiple of 64: whole waves
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1692,7 +1703,6 @@ struct DepAttnArgs {
     uint16_t* out;         // packed (T, out_ksteps), feature = h*Dh + lane
     int B, H, Dh, steps, k;
     int T, out_ksteps;
-    float* amax;           // int8 activations: row absmax slot of the output, or null
 };
 
 __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
@@ -1747,7 +1757,6 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
         }
     }
     if (on) a.out[mmi_xp_index(a.T, b, h * Dh + lane, a.out_ksteps)] = mmi_f32_to_bf16(o / den);
-    if (a.amax) mmi_amax_fold_wave(a.amax + b, on ? fabsf(mmi_round_bf16(o / den)) : 0.f);
 }
 
 // The same attention for Dh a multiple of 8 (<= 64) and <= 8 positions per frame - Moshi's depth transformer - with far fewer
@@ -1755,10 +1764,10 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
 // chunk of q, of key row j and of value row j once (the newest row straight from the in_proj output, which the lanes of
 // position k also copy into the frame's cache), reduces the score over the 8 chunk lanes, the softmax and P.V over the 8
 // position groups (3 butterfly steps each), and the lanes of position 0 store 8 output features as one 16-byte vector.
-template <int NW, bool COH = false>
-__device__ __forceinline__ void mmi_dep_attn8_body(const DepAttnArgs& a, const int vbx) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int bh = vbx * NW + wave;
+    const int bh = (int)blockIdx.x * NW + wave;
     if (bh >= a.B * a.H) return;
     const int b = bh / a.H, h = bh - b * a.H;
     const int Dh = a.Dh, HD = a.H * Dh, NC = Dh >> 3;
@@ -1768,11 +1777,9 @@ __device__ __forceinline__ void mmi_dep_attn8_body(const DepAttnArgs& a, const i
     uint16_t* kcb = a.kc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     uint16_t* vcb = a.vc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     const bool newest = jc == a.k;
-    // (COH: q / k / v of this position and the output are handed over inside the launch; the cache rows of earlier positions
-    // come from earlier launches and take the same load flavour - one unconditional load from a selected address)
-    const u32x4 qv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(row));
-    const u32x4 kv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh));
-    const u32x4 vv = mmi_ldx<COH>(reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh));
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(row);
+    const u32x4 kv = *reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh);
     if (j == a.k && c < NC) {                                       // this frame's cache, position k (transformer.py:243-253)
         *reinterpret_cast<u32x4*>(kcb + (long)a.k * Dh) = kv;
         *reinterpret_cast<u32x4*>(vcb + (long)a.k * Dh) = vv;
@@ -1806,65 +1813,7 @@ __device__ __forceinline__ void mmi_dep_attn8_body(const DepAttnArgs& a, const i
         u32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
-        mmi_stx<COH>(reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)), ov);
-        if (a.amax) mmi_amax_fold(a.amax + b, mmi_absmax_bf16x8(ov));
-    }
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
-    mmi_dep_attn8_body<NW>(a, (int)blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// one depth-transformer layer of one micro-step as ONE persistent launch (round 4)
-// ------------------------------------------------------------------------------------------------
-// The depth transformer (lm.py:450-493; transformer.py:609-802 with per-step weights) is dep_q x depformer_num_layers layers of
-// five dependent stages - norm1 + in_proj, attention over <= dep_q positions, out_proj + residual, norm2 + gated linear_in,
-// linear_out + residual - each a 2-11 MB launch that takes 4.5-8 us of which ~1.5 us is the kernel boundary and ~1.5 us the
-// ramp (arguments, first loads) before any of its bytes move: 264 boundaries per frame, 1.65 ms at 0.10 of the HBM roofline
-// (DESIGN.md).  Here the five stages of a layer share one launch of one workgroup per CU: every stage is the body of the kernel it
-// replaces (mmi_gemm_xp_norm_body / mmi_dep_attn8_body / mmi_gemm_xp_body, same tile partitions, same arithmetic, so the
-// results are bit-identical), walked over its work items by the resident workgroups, and between two stages the workgroups meet
-// at an edge (mmi_edge_sync): payload through L2-coherent 8-byte atomics, arrival counters sharded by XCD, no L2 write-back or
-// invalidate - where a kernel boundary flushes and refills every cache the codec running beside the depth transformer is using.
-struct DepLayerArgs {
-    GemmArgs in_proj, out_proj, ffn_in, ffn_out;      // as the launch list builds them (in_proj / ffn_in with the fused RMSNorm)
-    DepAttnArgs att;
-    int skip_attn;                // micro-step 0: in_proj's epilogue (MMI_EPI_DEP_QKV0) already wrote the attention output
-    int n_in, n_att, n_out, n_fin, n_fout;            // work items (virtual workgroups of the replaced kernels) per stage
-    unsigned* sync;               // [4][8] arrival counters of this launch's edges, zero at the head of the step
-    unsigned* fault;              // raised if an edge gave up (bounded spin)
-};
-
-// The arguments live in device memory (written once when the stream starts): by value, the four GemmArgs would all sit in scalar
-// registers for the whole launch and spill (158 SGPR / 31-351 VGPR spills measured); by reference each stage loads its own.
-template <int TN, int MT>
-__global__ __launch_bounds__(512) void k_dep_layer(const DepLayerArgs* __restrict__ pp) {
-    const DepLayerArgs& p = *pp;
-    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-    for (int it = bid; it < p.n_in; it += G) {
-        mmi_gemm_xp_norm_body<TN, MT, 8, 8, 0, true>(p.in_proj, it);
-        __syncthreads();                               // the epilogue's reduction scratch is reused by the next item / stage
-    }
-    mmi_edge_sync(p.sync, G, bid, p.fault);
-    if (!p.skip_attn) {
-        for (int it = bid; it < p.n_att; it += G) mmi_dep_attn8_body<8, true>(p.att, it);
-        mmi_edge_sync(p.sync + 8, G, bid, p.fault);
-    }
-    for (int it = bid; it < p.n_out; it += G) {
-        mmi_gemm_xp_body<TN, MT, 1, 8, 4, 0, true>(p.out_proj, it, 0, 1);
-        __syncthreads();
-    }
-    mmi_edge_sync(p.sync + 16, G, bid, p.fault);
-    for (int it = bid; it < p.n_fin; it += G) {
-        mmi_gemm_xp_norm_body<TN, MT, 8, 8, 0, true>(p.ffn_in, it);
-        __syncthreads();
-    }
-    mmi_edge_sync(p.sync + 24, G, bid, p.fault);
-    for (int it = bid; it < p.n_fout; it += G) {
-        mmi_gemm_xp_body<TN, MT, 1, 8, 4, 0, true>(p.ffn_out, it, 0, 1);
-        __syncthreads();
+        *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
     }
 }
 

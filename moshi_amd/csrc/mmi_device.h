@@ -133,53 +133,6 @@ __device__ __forceinline__ i32x4 mmi_mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c)
 // round-half-even to the nearest integer (v_rndne_f32), the rounding of bitsandbytes' int8_vectorwise_quant
 __device__ __forceinline__ float mmi_rint(float x) { return __builtin_rintf(x); }
 
-// Row absmax -> its slot: an atomic max on the bit patterns (non-negative floats order like their bit patterns; order-independent,
-// so the result is deterministic).  Test first, then max: thousands of workgroups fold into the same few dozen slots (704 gated
-// tiles x 64 rows), and unconditional atomics serialise on them - the gated linear_in took 94 us instead of 50 with one atomic
-// per epilogue task (profiles/r04_logs) - while a slot only ever rises, so a value that is not above what a relaxed
-// (L2-coherent) load sees can be dropped; after the first few arrivals almost every fold is just that load.
-__device__ __forceinline__ void mmi_amax_fold(float* slot, float v) {
-    if (!(v > 0.f)) return;
-    if (v > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
-}
-
-// ---- hand-offs between workgroups of ONE launch (k_dep_layer) ---------------------------------------------------------------------
-// Payload: 8-byte agent-scope relaxed atomics on both sides (see lm_kernels.h mmi_ldx / mmi_stx).
-__device__ __forceinline__ u32x4 mmi_ld_coh16(const u32x4* p) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-}
-__device__ __forceinline__ void mmi_st_coh16(u32x4* p, u32x4 v) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    __hip_atomic_store(q, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Edge: every workgroup of the launch arrives once (its payload stores drained first), then waits until all have.  The arrival
-// counter is sharded 8 ways by block index (blocks b, b + 8, ... land on one XCD: ~32 arrivals per word instead of 256 on
-// one, MI355X_MICROARCH.md "fanin"); one wave polls the 8 words with relaxed agent-scope loads and s_sleep.  `ctr`: 8 words,
-// zero at the start of the launch's step; want[i] = arrivals expected in shard i.  The spin is BOUNDED: after ~50 ms without
-// completion the workgroup raises *fault and goes on (wrong numbers, caught by the host, instead of a hung GPU).
-__device__ __forceinline__ void mmi_edge_sync(unsigned* ctr, int nblocks, int bid, unsigned* fault) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's payload stores have left (the compiler may not drop it)
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr + (bid & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 64) {
-        const int sh = (int)threadIdx.x & 7;
-        const unsigned want = (unsigned)((nblocks - sh + 7) >> 3);              // blocks with index = sh (mod 8)
-        long spins = 0;
-        for (;;) {
-            const unsigned have = __hip_atomic_load(ctr + sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(have >= want)) break;
-            if (++spins > 400000) { if (threadIdx.x == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-}
-
 // streamed-once weights: non-temporal so they do not evict the activations / KV the other kernels reuse
 __device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_nontemporal_load(p); }

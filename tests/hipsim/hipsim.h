@@ -87,11 +87,7 @@ hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphExecDestroy(hipGraphExec_t e);
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 10017, hipDeviceAttributeMultiprocessorCount = 63 };
-// "CUs" of the simulator = its worker threads: a persistent launch sized by this count has every block on a worker of its own
-inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
-    *v = a == hipDeviceAttributeMultiprocessorCount ? hipsim::num_workers() : 100000;
-    return hipSuccess;
-}
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 10017 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }
 hipError_t hipGetDevice(int* d);
 hipError_t hipSetDevice(int d);

@@ -4,7 +4,6 @@
 #pragma once
 #include "hipsim.h"
 #include <stdint.h>
-#include <sched.h>
 #include <cmath>
 #include <algorithm>
 
@@ -313,34 +312,6 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
-}
-
-// hand-offs inside one launch: the simulator's memory is coherent; the edge is the same counter protocol on host atomics, and the
-// launch must put every block on its own worker (grid <= HIPSIM_WORKERS) or the blocks that wait would starve the ones they wait for
-inline u32x4 mmi_ld_coh16(const u32x4* p) { return *p; }
-inline void mmi_st_coh16(u32x4* p, u32x4 v) { *p = v; }
-inline void mmi_edge_sync(unsigned* ctr, int nblocks, int bid, unsigned* fault) {
-    hipsim::sync_block();
-    if (hipsim::t_threadIdx.x == 0) {
-        if (nblocks > hipsim::num_workers()) { fprintf(stderr, "hipsim: persistent launch of %d blocks on %d workers\n", nblocks, hipsim::num_workers()); abort(); }
-        __atomic_fetch_add(ctr + (bid & 7), 1u, __ATOMIC_ACQ_REL);
-        long spins = 0;
-        for (;;) {
-            bool all = true;
-            for (int sh = 0; sh < 8; ++sh) all &= __atomic_load_n(ctr + sh, __ATOMIC_ACQUIRE) >= (unsigned)((nblocks - sh + 7) >> 3);
-            if (all) break;
-            if (++spins > 200000000L) { __atomic_store_n(fault, 1u, __ATOMIC_RELEASE); break; }
-            sched_yield();
-        }
-    }
-    hipsim::sync_block();
-}
-
-inline void mmi_amax_fold(float* slot, float v) {
-    if (!(v > 0.f)) return;
-    unsigned u;
-    memcpy(&u, &v, 4);
-    atomicMax(reinterpret_cast<unsigned*>(slot), u);
 }
 
 // sum over groups of W consecutive lanes, every lane receiving the total (the gfx950 build: DPP row operations)

@@ -294,36 +294,3 @@ def test_cross_attention_at_full_width_matches_oracle(gpu_lib, B, Tc):
     keys / values projected through the weight-streaming GEMM in batches) against the oracle, both batch tilings."""
     from dataclasses import replace
     lm_cases.cross_vs_oracle(DEV, None, replace(LMConfig(num_layers=2, context=64), cross_attention=True), B=B, S=2, Tc=Tc, seed=77 + B)
-
-
-@pytest.mark.parametrize("B", [2, 24])
-def test_persistent_depth_transformer_layers_are_bit_identical_to_the_launch_list(gpu_lib, monkeypatch, B):
-    """k_dep_layer (MMI_DEP_PERSIST=1) at the 7B widths (depformer 6 x 1024 x 8 micro-steps; one temporal layer): the five stages
-    of a depth-transformer layer in ONE launch of one workgroup per CU, hand-offs between workgroups inside the launch
-    (L2-coherent 8-byte atomics + sharded arrival counters) - every token and every logit bit-identical to the launch list it
-    replaces, greedy and sampled, on the 16-row (2 sessions) and the 32-row tile (24 sessions), and no edge gave up."""
-    import numpy as np
-    cfg = LMConfig(num_layers=1, context=16)
-    sd = random_lm_state_dict(cfg, seed=5, device=DEV)
-    rng = np.random.default_rng(B)
-    codes = [torch.from_numpy(rng.integers(0, cfg.card, (B, 8, 1))).to(DEV) for _ in range(5)]
-
-    def run(persist, sampling):
-        monkeypatch.setenv("MMI_DEP_PERSIST", "1" if persist else "0")
-        gen = lm_cases.make_engine(cfg, sd, DEV, None, B, use_sampling=sampling, seed=11, support_out_of_sync=True)
-        outs = []
-        with gen.streaming(B):
-            for s, c in enumerate(codes):
-                if s == 3 and B > 1:
-                    m = torch.ones(B, dtype=torch.bool, device=DEV); m[1] = False
-                    gen.set_exec_mask(m)
-                out, tl, al = gen.step_with_taps(c)
-                outs.append((out.cpu().numpy().copy(), tl.cpu().numpy().copy(), al.cpu().numpy().copy()))
-            sites = {site for site, _ in gen.launch_list()}
-            assert ("dep.layer" in sites) == persist
-            assert gen._lib.mmi_lm_stat(gen.lm_model._handle, 1) == 0
-        return outs
-    for sampling in (False, True):
-        for (o1, t1, a1), (o2, t2, a2) in zip(run(False, sampling), run(True, sampling)):
-            assert np.array_equal(o1, o2)
-            assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32)) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32))

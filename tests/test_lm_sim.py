@@ -397,41 +397,3 @@ def test_cross_attention_more_positions_than_slots(sim_lib):
     passes and the batched key / value projection at stream start."""
     from dataclasses import replace
     lm_cases.cross_vs_oracle("cpu", sim_lib, replace(tiny_lm_config(), cross_attention=True), B=18, S=2, Tc=41, seed=8)
-
-
-@pytest.mark.parametrize("B,grid", [(3, 4), (18, 8), (30, 3), (18, 1)])
-def test_persistent_depth_transformer_layers_are_bit_identical_to_the_launch_list(sim_lib, monkeypatch, B, grid):
-    """k_dep_layer (MMI_DEP_PERSIST=1): the five stages of a depth-transformer layer in ONE launch - the same kernel bodies walked
-    over their work items by `grid` resident workgroups, edges between the stages.  Against the launch list it replaces: every
-    token and every logit tap bit-identical (greedy and sampled), for the 16-row and the 32-row tile, fewer workgroups than work items (striding) and a single workgroup."""
-    import numpy as np
-    import torch
-    from moshi_amd.weights import random_lm_state_dict
-    cfg = tiny_lm_config()
-    sd = random_lm_state_dict(cfg, seed=300 + B)
-    rng = np.random.default_rng(B)
-    codes = [torch.from_numpy(rng.integers(0, cfg.card, (B, 8, 1))) for _ in range(4)]
-
-    monkeypatch.setenv("MMI_GEMM_WAVES8", "1")      # the launch list's short-K GEMMs on the 8-wave split the layer kernel's bodies use
-
-    def run(persist, sampling):
-        monkeypatch.setenv("MMI_DEP_PERSIST", "1" if persist else "0")
-        monkeypatch.setenv("MMI_DEP_PERSIST_GRID", str(grid))
-        gen = lm_cases.make_engine(cfg, sd, "cpu", sim_lib, B, use_sampling=sampling, temp=0.8, temp_text=0.7, top_k=5, top_k_text=5,
-                                   seed=11, support_out_of_sync=True)
-        outs = []
-        with gen.streaming(B):
-            for s, c in enumerate(codes):
-                if s == 2 and B > 1:
-                    m = torch.ones(B, dtype=torch.bool); m[1] = False
-                    gen.set_exec_mask(m)
-                out, tl, al = gen.step_with_taps(c)
-                outs.append((out.numpy().copy(), tl.numpy().copy(), al.numpy().copy()))
-            sites = {site for site, _ in gen.launch_list()}
-            assert ("dep.layer" in sites) == persist and ("dep.out_proj" in sites) != persist
-            assert sim_lib.mmi_lm_stat(gen.lm_model._handle, 1) == 0          # no edge gave up
-        return outs
-    for sampling in (False, True):
-        for (o1, t1, a1), (o2, t2, a2) in zip(run(False, sampling), run(True, sampling)):
-            assert np.array_equal(o1, o2)
-            assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32)) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32))
