@@ -490,6 +490,21 @@ def main():
             # the other figures SURVEY 8d asks of this model, measured in the same process after the headline
             from bench_lm import extra_full_context, extra_c3
             join()
+            if args.kv_depth == "mid":
+                # the same pipelined step at the ring depth rounds 1-3 quoted (sessions 8 b deep + warm-up): the figure comparable
+                # with BENCH_r01..r03 (6.19 ms in round 3), beside the mid-run headline
+                lm_gen.seek([args.stagger * b for b in range(B)])
+                for _ in range(3):
+                    step()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                join()
+                torch.cuda.synchronize(dev)
+                out["kv_depth_start"] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / args.steps, "steps": args.steps,
+                                         "kv_positions": [0, args.stagger * (B - 1)],
+                                         "note": "same pipelined step with the rings as shallow as rounds 1-3 measured them (depth 8 b); BENCH_r03: 6.19 ms"}
             out["full_context"] = extra_full_context(lm_gen, user_codes, B, dev)
             out["c3"] = extra_c3(dev, args)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the barrier)

@@ -590,8 +590,16 @@ void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features,
     a.out_ksteps = packed_ksteps(lm, out_features);
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
-    a.wq = 3; a.xinv = g.xinv; a.osplit = 1;
-    const int NT = g.NT;
+    a.wq = 3; a.xinv = g.xinv;
+    // few n-tiles (the N = 1024 linears: 32 tiles for 256 CUs): share a tile's row octets out over several workgroups, as
+    // plan_osplit does for the bf16 form of these GEMMs
+    a.osplit = 1;
+    if (epi != MMI_EPI_GATE && !getenv("MMI_GEMM_OSPLIT")) {
+        const int octs = T / 8;
+        while (a.osplit < octs && (long)g.NT * a.osplit < 128) a.osplit *= 2;
+        if (g.NT > 64) a.osplit = 1;
+    }
+    const int NT = g.NT * a.osplit;
     const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
         mmi_record_bytes(gbytes);

@@ -725,9 +725,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
     constexpr int XMAX = 2 * KMAX;
+    // batch tiles handled together: both while a lane's fragments of both fit its registers (short rows), else one after the other
+    constexpr int MG = (MT * XMAX <= 16) ? MT : 1;
     typedef int iacc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nt0 = (int)blockIdx.x;
+    // octet sharing as in k_gemm_xp (a.osplit > 1): N = 1024 linears have 32 n-tiles for 256 CUs; a workgroup = (tile, part) owns
+    // TN / 8 / osplit of the tile's 8-row groups, the lanes of the other groups repeat an owned lane's weight address
+    const int os = a.osplit > 1 ? a.osplit : 1;
+    const int nt0 = (int)blockIdx.x / os, part = (int)blockIdx.x - nt0 * os;
+    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
+    const int ro = (lane >> 3) & (TN / 8 - 1);
+    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
     const int kper = (a.KSTEPS + WAVES - 1) / WAVES;          // <= KMAX (checked by the launcher)
     const int ks0 = min(a.KSTEPS, wave * kper);
     const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
@@ -739,91 +747,114 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
         const int uu = min(u, nks > 0 ? nks - 1 : 0);
-        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + lane);
+        wv[u] = mmi_load_nt(a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl + uu) * 64 + wlane);
     }
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) if (u >= nks) wv[u] = zero;
     MMI_SHARED float sxl[MT * TN];                       // the rows' absmax, for the epilogue
-    MMI_SHARED float redl[2][WAVES][TN];                 // [0] sums of squares, [1] absmax, per wave
+    MMI_SHARED float redl[2][WAVES][MG][TN];             // [0] sums of squares, [1] absmax, per wave and tile of the group
     iacc_t acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[m][r] = 0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        // unconditional loads from clamped (valid) addresses, masked afterwards (a load under a branch would be serialised)
-        u32x4 xv[XMAX], al[NORM ? XMAX : 1];
-        const int dmax = (a.D - 8) > 0 ? (a.D - 8) : 0;
+    const int dmax = (a.D - 8) > 0 ? (a.D - 8) : 0;
+    u32x4 al[NORM ? XMAX : 1];
+    if constexpr (NORM) {
 #pragma unroll
         for (int u = 0; u < XMAX; ++u) {
             const int uu = min(u >> 1, nks > 0 ? nks - 1 : 0);
-            xv[u] = a.xp[(((long)m * a.KSTEPS + ksl + uu) * 2 + (u & 1)) * 64 + lane];
-            if constexpr (NORM) al[u] = *reinterpret_cast<const u32x4*>(a.alpha + min(((ksl + uu) * 2 + (u & 1)) * KS + 8 * kq, dmax));
+            al[u] = *reinterpret_cast<const u32x4*>(a.alpha + min(((ksl + uu) * 2 + (u & 1)) * KS + 8 * kq, dmax));
         }
 #pragma unroll
-        for (int u = 0; u < XMAX; ++u) {
-            const bool on = (u >> 1) < nks;
-            if (!on) xv[u] = zero;
-            if constexpr (NORM) { if (!on || ((ks0 + (u >> 1)) * 2 + (u & 1)) * KS + 8 * kq >= a.D) al[u] = zero; }
-        }
-        if constexpr (NORM) {       // y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16)   (transformer.py:45-58)
-            float ss = 0.f;
+        for (int u = 0; u < XMAX; ++u)
+            if ((u >> 1) >= nks || ((ks0 + (u >> 1)) * 2 + (u & 1)) * KS + 8 * kq >= a.D) al[u] = zero;
+    }
 #pragma unroll
-            for (int u = 0; u < XMAX; ++u)
+    for (int m0 = 0; m0 < MT; m0 += MG) {
+        // unconditional loads from clamped (valid) addresses, masked afterwards (a load under a branch would be serialised)
+        u32x4 xv[MG][XMAX];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = mmi_bf16_to_f32((uint16_t)(xv[u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[u][q] >> 16));
-                    ss += lo * lo;
-                    ss += hi * hi;
-                }
-            if constexpr (TN == 32) ss += mmi_shfl_xor(ss, 32);
-            else { ss += mmi_shfl_xor(ss, 16); ss += mmi_shfl_xor(ss, 32); }
-            if (lane < TN) redl[0][wave][lane] = ss;
-            __syncthreads();
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot += redl[0][w][lane & (TN - 1)];
-            const float rs = mmi_rsqrtf(a.eps + tot / (float)a.D);
+        for (int g = 0; g < MG; ++g)
 #pragma unroll
             for (int u = 0; u < XMAX; ++u) {
-                u32x4 xn;
+                const int uu = min(u >> 1, nks > 0 ? nks - 1 : 0);
+                xv[g][u] = a.xp[(((long)(m0 + g) * a.KSTEPS + ksl + uu) * 2 + (u & 1)) * 64 + lane];
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float lo = mmi_bf16_to_f32((uint16_t)(xv[u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[u][q] >> 16));
-                    const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
-                    xn[q] = mmi_pack_bf16x2(lo * (alo * rs), hi * (ahi * rs));
+        for (int g = 0; g < MG; ++g)
+#pragma unroll
+            for (int u = 0; u < XMAX; ++u)
+                if ((u >> 1) >= nks) xv[g][u] = zero;
+        if constexpr (NORM) {       // y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16)   (transformer.py:45-58)
+#pragma unroll
+            for (int g = 0; g < MG; ++g) {
+                float ss = 0.f;
+#pragma unroll
+                for (int u = 0; u < XMAX; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = mmi_bf16_to_f32((uint16_t)(xv[g][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[g][u][q] >> 16));
+                        ss += lo * lo;
+                        ss += hi * hi;
+                    }
+                if constexpr (TN == 32) ss += mmi_shfl_xor(ss, 32);
+                else { ss += mmi_shfl_xor(ss, 16); ss += mmi_shfl_xor(ss, 32); }
+                if (lane < TN) redl[0][wave][g][lane] = ss;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < MG; ++g) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) tot += redl[0][w][g][lane & (TN - 1)];
+                const float rs = mmi_rsqrtf(a.eps + tot / (float)a.D);
+#pragma unroll
+                for (int u = 0; u < XMAX; ++u) {
+                    u32x4 xn;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = mmi_bf16_to_f32((uint16_t)(xv[g][u][q] & 0xffffu)), hi = mmi_bf16_to_f32((uint16_t)(xv[g][u][q] >> 16));
+                        const float alo = mmi_bf16_to_f32((uint16_t)(al[u][q] & 0xffffu)), ahi = mmi_bf16_to_f32((uint16_t)(al[u][q] >> 16));
+                        xn[q] = mmi_pack_bf16x2(lo * (alo * rs), hi * (ahi * rs));
+                    }
+                    xv[g][u] = xn;
                 }
-                xv[u] = xn;
             }
         }
-        float am = 0.f;
 #pragma unroll
-        for (int u = 0; u < XMAX; ++u) am = fmaxf(am, mmi_absmax_bf16x8(xv[u]));
-        if constexpr (TN == 32) am = fmaxf(am, mmi_shfl_xor(am, 32));
-        else { am = fmaxf(am, mmi_shfl_xor(am, 16)); am = fmaxf(am, mmi_shfl_xor(am, 32)); }
-        if (lane < TN) redl[1][wave][lane] = am;
-        __syncthreads();
-        float sca = 0.f;
+        for (int g = 0; g < MG; ++g) {
+            float am = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) sca = fmaxf(sca, redl[1][w][lane & (TN - 1)]);
-        if (wave == 0 && lane < TN) sxl[m * TN + lane] = sca;
-        const float scale = mmi_i8_scale(sca);
-#pragma unroll
-        for (int u = 0; u < KMAX; ++u) {
-            const u32x2 qlo = mmi_quant_i8x8(xv[2 * u], scale), qhi = mmi_quant_i8x8(xv[2 * u + 1], scale);
-            const u32x4 xq = {qlo[0], qlo[1], qhi[0], qhi[1]};
-            if constexpr (TN == 32) acc[m] = mmi_mfma_i8_32x32x32(wv[u], xq, acc[m]);
-            else acc[m] = mmi_mfma_i8_16x16x64(wv[u], xq, acc[m]);
+            for (int u = 0; u < XMAX; ++u) am = fmaxf(am, mmi_absmax_bf16x8(xv[g][u]));
+            if constexpr (TN == 32) am = fmaxf(am, mmi_shfl_xor(am, 32));
+            else { am = fmaxf(am, mmi_shfl_xor(am, 16)); am = fmaxf(am, mmi_shfl_xor(am, 32)); }
+            if (lane < TN) redl[1][wave][g][lane] = am;
         }
-        __syncthreads();                                 // redl is rewritten by the next batch tile; sxl is read by the epilogue
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            float sca = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sca = fmaxf(sca, redl[1][w][g][lane & (TN - 1)]);
+            if (wave == 0 && lane < TN) sxl[(m0 + g) * TN + lane] = sca;
+            const float scale = mmi_i8_scale(sca);
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) {
+                const u32x2 qlo = mmi_quant_i8x8(xv[g][2 * u], scale), qhi = mmi_quant_i8x8(xv[g][2 * u + 1], scale);
+                const u32x4 xq = {qlo[0], qlo[1], qhi[0], qhi[1]};
+                if constexpr (TN == 32) acc[m0 + g] = mmi_mfma_i8_32x32x32(wv[u], xq, acc[m0 + g]);
+                else acc[m0 + g] = mmi_mfma_i8_16x16x64(wv[u], xq, acc[m0 + g]);
+            }
+        }
+        __syncthreads();                                 // redl is rewritten by the next group; sxl is read by the epilogue
     }
     float accv[1][MT][R];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) accv[0][m][r] = (float)acc[m][r];
-    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, 0, TN / 8, sxl);
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi, sxl);
 }
 
 // ------------------------------------------------------------------------------------------------
