@@ -297,7 +297,19 @@ template <int TN, int MT, int NTW>
 int launch_gemm_w(hipStream_t s, dim3 groups, int waves, int u, int wq, const GemmArgs& a) {
     if (wq == 1) return launch_gemm_q<TN, MT, NTW, 1>(s, groups, waves, a);
     if (wq == 2) return launch_gemm_q<TN, MT, NTW, 2>(s, groups, waves, a);
-    if (wq == 3) return launch_gemm_q<TN, MT, NTW, 3>(s, groups, waves, a);
+    if (wq == 3) {
+        // int8 x int8 has no conversion to hold in registers: four entries per register buffer instead of two (MMI_Q8_U=2: the
+        // weight-only depth, same-box A/B)
+        static const bool u4 = !(getenv("MMI_Q8_U") && getenv("MMI_Q8_U")[0] == '2');
+        if (u4 && waves == 8) {
+            if constexpr (MT * NTW <= 2) {
+                MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 4, 3>), groups, 512, 0, s, a);
+                MMI_CHECK_LAUNCH();
+                return MMI_OK;
+            }
+        }
+        return launch_gemm_q<TN, MT, NTW, 3>(s, groups, waves, a);
+    }
     if (waves == 8 && u == 2 && MT * NTW == 1) {
         if constexpr (MT * NTW == 1) MMI_LAUNCH((k_gemm_xp<TN, MT, NTW, 8, 2>), groups, 512, 0, s, a);
         MMI_CHECK_LAUNCH();
@@ -339,7 +351,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
     if (tg && atoi(tg) > 0) cus = atoi(tg);
     const int xs = (g.wq && a.wq != 3) ? 2 : 1;                // activation fragments per weight entry (int8 activations: one entry)
-    const int big = (g.wq ? 32 : 64) / mt;                     // 64 KiB of activations per chunk buffer
+    const int big = ((g.wq && a.wq != 3) ? 32 : 64) / mt;      // 64 KiB of activations per chunk buffer (int8 activations: 1 KiB per entry)
     if (g.KSTEPS % big == 0 && g.NT >= 128) p.kc = big;       // the large temporal GEMMs
     else if (tg && g.KSTEPS % 8 == 0) p.kc = 8;
     else if (tg && g.KSTEPS % 4 == 0) p.kc = 4;
@@ -374,7 +386,7 @@ int launch_xlds_v(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
 // production chunk (64 / MT k-steps, or 32 / MT two-step entries) or one of the short test chunks
 template <int MT, bool STAGGER, int WQ>
 int launch_xlds_kc(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
-    constexpr int BIG = (WQ ? 32 : 64) / MT;
+    constexpr int BIG = ((WQ == 1 || WQ == 2) ? 32 : 64) / MT;
     if (p.kc == BIG) return launch_xlds_v<MT, BIG, STAGGER, WQ>(s, p, a);
     if (p.kc == 8) return launch_xlds_v<MT, 8, STAGGER, WQ>(s, p, a);
     if (p.kc == 4) return launch_xlds_v<MT, 4, STAGGER, WQ>(s, p, a);

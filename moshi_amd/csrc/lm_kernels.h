@@ -1569,9 +1569,11 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
     const int L = (int)(end_new < (long)a.cap ? end_new : (long)a.cap);
     const int seg = lane % LPR, rsub = lane / LPR;
     float qv[EPL];
+    u32x4 qp = {0u, 0u, 0u, 0u};      // bf16 ring: the lane's 8 query elements stay packed (v_dot2c_f32_bf16 takes both operands packed)
 #pragma unroll
     for (int v = 0; v < EPL / 8; ++v) {
         u32x4 qq = *reinterpret_cast<const u32x4*>(a.qrot + (long)bh * DH + seg * EPL + v * 8);
+        if (v == 0) qp = qq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             qv[v * 8 + 2 * q] = mmi_bf16_to_f32((uint16_t)(qq[q] & 0xffffu));
@@ -1595,6 +1597,10 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
     const unsigned loff = (unsigned)(seg * EPL * ES);
     const float scale = 1.0f / sqrtf((float)DH);
+    // context >= capacity (the LM's ring: both 3000): every written slot is inside the window - slot s < L holds a position p with
+    // 0 <= offset - p < cap - so the mask (transformer.py:574-582) reduces to `slot < L` and the per-row position arithmetic is
+    // skipped (wave-uniform branch); a ring longer than its attention window keeps it
+    const bool windowed = a.context < a.cap;
     const int total = (int)gridDim.y * 4, wg = (int)blockIdx.y * 4 + wave;       // waves serving this pair, and which one this is
     const int ngroups = (L + RPW - 1) / RPW;
     const int nmine = wg < ngroups ? (ngroups - wg + total - 1) / total : 0;       // row groups wg, wg + total, ...
@@ -1620,16 +1626,20 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
             const int j_ = (j0) + i;                                                             \
             const int slot_ = (wg + j_ * total) * RPW + rsub;                                    \
             bool valid_ = j_ < nmine && slot_ < L;                                               \
-            if (valid_) {   /* absolute position of the slot (transformer.py:258-286), causal / context mask (:574-582) */ \
+            if (windowed && valid_) {   /* absolute position of the slot (transformer.py:258-286), causal / context mask (:574-582) */ \
                 const int delta_ = slot_ - end_index;                                            \
                 const long pos_ = delta_ <= 0 ? off + delta_ : off + delta_ - a.cap;             \
                 const long dq_ = off - pos_;                                                     \
                 valid_ = pos_ >= 0 && dq_ >= 0 && dq_ < a.context;                               \
             }                                                                                    \
-            float kf_[EPL];                                                                      \
-            widen(KK[i], kf_);                                                                   \
             float dot_ = 0.f;                                                                    \
-            _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot_ = mmi_fma(qv[e], kf_[e], dot_); \
+            if constexpr (KV8) {                                                                 \
+                float kf_[EPL];                                                                  \
+                widen(KK[i], kf_);                                                               \
+                _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot_ = mmi_fma(qv[e], kf_[e], dot_); \
+            } else {                    /* 4 packed-pair dot products instead of 8 unpacks + 8 FMAs */ \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) dot_ = mmi_dot2_bf16(KK[i][q], qp[q], dot_); \
+            }                                                                                    \
             dot_ = mmi_group_sum<LPR>(dot_);                /* DPP row operations, no trip through the LDS crossbar */ \
             s_[i] = valid_ ? dot_ * scale : -INFINITY;                                           \
             mx_ = fmaxf(mx_, s_[i]);                                                             \
@@ -1642,9 +1652,19 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
             _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                    \
                 const float p_ = expf(s_[i] - m_new_);        /* exp(-inf) = 0 for masked rows */ \
                 l_run += p_;                                                                     \
-                float vf_[EPL];                                                                  \
-                widen(VV[i], vf_);                                                               \
-                _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] = mmi_fma(p_, vf_[e], acc[e]); \
+                if constexpr (KV8) {                                                             \
+                    float vf_[EPL];                                                              \
+                    widen(VV[i], vf_);                                                           \
+                    _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] = mmi_fma(p_, vf_[e], acc[e]); \
+                } else {                /* packed FMAs: two accumulator elements per instruction */ \
+                    const f32x2 pp_ = {p_, p_};                                                  \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                             \
+                        const f32x2 v2_ = {__builtin_bit_cast(float, VV[i][q] << 16), __builtin_bit_cast(float, VV[i][q] & 0xffff0000u)}; \
+                        const f32x2 a2_ = mmi_pk_fma(pp_, v2_, f32x2{acc[2 * q], acc[2 * q + 1]}); \
+                        acc[2 * q] = a2_[0];                                                     \
+                        acc[2 * q + 1] = a2_[1];                                                 \
+                    }                                                                            \
+                }                                                                                \
             }                                                                                    \
             m_run = m_new_;                                                                      \
         }                                                                                        \

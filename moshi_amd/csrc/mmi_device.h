@@ -67,6 +67,13 @@ __device__ __forceinline__ float mmi_group_sum(float x) {
     return x;
 }
 __device__ __forceinline__ float mmi_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// c + a.lo * b.lo + a.hi * b.hi on two packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16): no unpacking of either operand
+typedef __bf16 mmi_bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float mmi_dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mmi_bf16x2v, a), __builtin_bit_cast(mmi_bf16x2v, b), c, false);
+}
+// two fp32 FMAs in one instruction (v_pk_fma_f32)
+__device__ __forceinline__ f32x2 mmi_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // D(32x32) += A(32x2) * B(2x32), exact fp32 fma chain.  lane l: a = A[l&31][l>>5], b = B[l>>5][l&31];
 // d[r] = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].

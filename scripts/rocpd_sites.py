@@ -5,7 +5,11 @@ transformer's linears), so a per-kernel summary cannot give per-GEMM roofline fr
 step issued which kernel (`mmi_lm_launch_list` / `mmi_mimi_launch_list`, one "site<TAB>kernel" line per launch, dumped by
 `bench.py --launch-lists DIR`); a step's launches appear in the trace in exactly that order, so the two are joined by position.
 
-    python scripts/rocpd_sites.py <results.db> <launch_list_dir> [--header "comment"] > profiles/<name>_sites.csv
+    python scripts/rocpd_sites.py <results.db> <launch_list_dir> [--header "comment"] [--last N] > profiles/<name>_sites.csv
+
+--last N: average the LAST N steps of the trace instead of its last half.  bench.py moves the sessions to their mid-run ring depth
+only after the staggered start (248 steps at 32 sessions), so "the last half" of a default run still holds shallow, partly masked
+steps; the steps after the seek are warm-up + timed + latency + profile passes (>= 120 with the default flags).
 
 Columns: program, site, launches per step, mean us per step, mean us per launch, algorithmic MB per launch (the packed weight
 bytes the engine recorded for the launch - third column of the launch list, right for bf16, int8 and fp8 weights alike; the
@@ -53,6 +57,7 @@ def load_list(path):
 def main():
     db, ldir = sys.argv[1], Path(sys.argv[2])
     header = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--header" else None
+    last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
@@ -86,7 +91,7 @@ def main():
                 nbytes[site] = max(nb, nbytes.get(site, 0)) if site in seen_bytes else nb
                 seen_bytes.add(site)
         # keep the graph-replayed steps of the timed region: the last half of the matches
-        starts = starts[len(starts) // 2:]
+        starts = starts[-last:] if last > 0 else starts[len(starts) // 2:]
         if not starts:
             print(f"# {prog}: no step of {n} launches found in the trace", file=sys.stderr)
             continue

@@ -321,6 +321,11 @@ inline float mmi_group_sum(float x) {
     return x;
 }
 inline float mmi_fma(float a, float b, float c) { return fmaf(a, b, c); }
+inline float mmi_dot2_bf16(uint32_t a, uint32_t b, float c) {
+    using hipsim_detail::bf;
+    return fmaf(bf((uint16_t)(a >> 16)), bf((uint16_t)(b >> 16)), fmaf(bf((uint16_t)a), bf((uint16_t)b), c));
+}
+inline f32x2 mmi_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 inline float mmi_rint(float x) { return nearbyintf(x); }
 
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
