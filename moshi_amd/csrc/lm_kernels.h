@@ -142,20 +142,22 @@ __device__ __forceinline__ float mmi_absmax_bf16x8(u32x4 v) {
     }
     return m;
 }
-// CA = int8(round_half_even(x * (127 / SCA))): 8 bf16 values -> 8 bytes (scale = 127 / SCA, 0 for an all-zero row)
+// CA = int8(round_half_even(x * (127 / SCA))): 8 bf16 values -> 8 bytes (scale = 127 / SCA, 0 for an all-zero row).
+// t = x * scale is rounded to fp32 like bitsandbytes' product, then t + 1.5 * 2^23 rounds it to the nearest integer, ties to
+// even - the fp32 adder IS round-half-even at that magnitude, |t| <= 127 - and leaves the two's-complement byte in the low 8 bits
+// of the sum: 3 instructions per element + a byte permute per pair instead of rint / convert / mask / shift / or (the
+// quantisation sits on the dependent chain of the depth transformer's GEMMs, where every workgroup converts its own copy)
 __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
+    const float magic = 12582912.0f;            // 1.5 * 2^23
     u32x2 r;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        unsigned w = 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned x = v[2 * h + q];
-            const int lo = (int)mmi_rint(__builtin_bit_cast(float, x << 16) * scale);
-            const int hi = (int)mmi_rint(__builtin_bit_cast(float, x & 0xffff0000u) * scale);
-            w |= ((unsigned)lo & 0xffu) << (16 * q) | ((unsigned)hi & 0xffu) << (16 * q + 8);
-        }
-        r[h] = w;
+        const unsigned x0 = v[2 * h], x1 = v[2 * h + 1];
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x0 << 16) * scale + magic);
+        const unsigned b = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x0 & 0xffff0000u) * scale + magic);
+        const unsigned c = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x1 << 16) * scale + magic);
+        const unsigned d = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x1 & 0xffff0000u) * scale + magic);
+        r[h] = mmi_pack_low_bytes(a, b, c, d);
     }
     return r;
 }

@@ -137,6 +137,12 @@ __device__ __forceinline__ i32x16 mmi_mfma_i8_32x32x32(u32x4 a, u32x4 b, i32x16 
 __device__ __forceinline__ i32x4 mmi_mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
 }
+// the low bytes of four words -> one word (byte i = low byte of argument i): two v_perm_b32 + one
+__device__ __forceinline__ uint32_t mmi_pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u);      // bytes: [a.0, b.0, 0, 0]  (selector bytes 0-3 index the second operand, 4-7 the first, 0x0c = zero)
+    const uint32_t cd = __builtin_amdgcn_perm(d, c, 0x04000c0cu);      // bytes: [0, 0, c.0, d.0]
+    return ab | cd;
+}
 // round-half-even to the nearest integer (v_rndne_f32), the rounding of bitsandbytes' int8_vectorwise_quant
 __device__ __forceinline__ float mmi_rint(float x) { return __builtin_rintf(x); }
 

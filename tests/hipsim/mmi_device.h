@@ -327,6 +327,9 @@ inline float mmi_dot2_bf16(uint32_t a, uint32_t b, float c) {
 }
 inline f32x2 mmi_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 inline float mmi_rint(float x) { return nearbyintf(x); }
+inline uint32_t mmi_pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return (a & 0xffu) | ((b & 0xffu) << 8) | ((c & 0xffu) << 16) | ((d & 0xffu) << 24);
+}
 
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
