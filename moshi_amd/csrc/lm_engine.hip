@@ -85,7 +85,6 @@ struct mmi_lm {
     uint16_t *x = nullptr, *xn = nullptr, *qrot = nullptr, *att = nullptr, *hb = nullptr;
     uint16_t *tout = nullptr, *text_logits = nullptr;
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
-    bool kv_interleave = false;                     // MMI_KV_INTERLEAVE: one ring [layers][B][H][cap][2][Dh] in kc
     float *opart = nullptr, *ml = nullptr;
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
@@ -775,12 +774,7 @@ int build_program(mmi_lm* lm) {
     // ---- temporal transformer
     const int NS = attn_splits(c, B);
     const bool kv8 = c.kv_cache_dtype == MMI_F8E4M3;
-    // MMI_KV_INTERLEAVE (A/B hook): keys and values of a position in ONE ring row (vc = kc + Dh elements, row stride 2 Dh) instead of
-    // two rings - the decode attention's key and value loads of a row group then fall into the same DRAM pages
-    const bool kvi = lm->kv_interleave;
-    const size_t kv_layer = (size_t)B * H * c.context * Dh / (kv8 ? 2 : 1) * (kvi ? 2 : 1);     // in uint16 units: an fp8 ring is half as large
-    const int kvs = kvi ? 2 * Dh : Dh;
-    const size_t v_off = kvi ? (size_t)Dh / (kv8 ? 2 : 1) : 0;                  // uint16 units from a key row to its value row
+    const size_t kv_layer = (size_t)B * H * c.context * Dh / (kv8 ? 2 : 1);     // in uint16 units: an fp8 ring is half as large
     int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
@@ -788,8 +782,7 @@ int build_program(mmi_lm* lm) {
         add_resid_rmsnorm(lm, lm->x, pending, L.n1, lm->xn, d, a8 ? lm->xnq : nullptr, a8 ? lm->sx_xn : nullptr);
         if (l == 1) add_hidden_tap(lm, 0);     // x is complete (the previous linear_out's partials folded in) right after this norm
         LmAttnArgs a;
-        a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = kvi ? a.kc + v_off : lm->vc + l * kv_layer;
-        a.kvs = kvs;
+        a.qrot = lm->qrot; a.kc = lm->kc + l * kv_layer; a.vc = lm->vc + l * kv_layer;
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
@@ -800,7 +793,7 @@ int build_program(mmi_lm* lm) {
             ga.xp = reinterpret_cast<const u32x4*>(lm->xn); ga.epi = MMI_EPI_ROPE_KV; ga.B = B;
             if (a8) { ga.xp = reinterpret_cast<const u32x4*>(lm->xnq); ga.sx = lm->sx_xn; ga.wq = 3; }
             ga.qrot = a.qrot; ga.kc = a.kc; ga.vc = a.vc; ga.offsets = lm->offsets_m; ga.H = H; ga.Dh = Dh; ga.cap = c.context; ga.kv8 = kv8 ? 1 : 0;
-            ga.max_period = c.max_period; ga.rope = lm->rope; ga.kvs = kvs;
+            ga.max_period = c.max_period; ga.rope = lm->rope;
             GemmW gw = L.in_proj;
             P.add([lm, gw, ga](hipStream_t s) { return launch_gemm(lm, s, gw, ga, false); }, (long)gw.bytes);
         }
@@ -1247,12 +1240,8 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->hb, packed_elems(lm, c.ffn_hidden));
     ok &= hipSuccess == A.alloc(&lm->tout, packed_elems(lm, d));
     ok &= hipSuccess == A.alloc(&lm->text_logits, (size_t)B * c.text_card_out);
-    {
-        const char* ei = getenv("MMI_KV_INTERLEAVE");
-        lm->kv_interleave = ei && ei[0] == '1';
-    }
-    ok &= hipSuccess == A.alloc(&lm->kc, lm->kv_interleave ? 2 * kvn : kvn);
-    ok &= hipSuccess == A.alloc(&lm->vc, lm->kv_interleave ? (size_t)8 : kvn);
+    ok &= hipSuccess == A.alloc(&lm->kc, kvn);
+    ok &= hipSuccess == A.alloc(&lm->vc, kvn);
     ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
     ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
@@ -1305,8 +1294,8 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     }
     if (lm->cond) MMI_HIP_CHECK(hipMemcpyAsync(lm->cond, guide->condition_sum, (size_t)B * d * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
     MMI_LAUNCH(k_fill_i32, mmi_cdiv(G * lm->NC * lm->CT, 256), 256, 0, s, lm->cache, -2, (long)G * lm->NC * lm->CT);   // lm.py:608-613
-    MMI_HIP_CHECK(hipMemsetAsync(lm->kc, 0, (lm->kv_interleave ? 2 : 1) * kvn * sizeof(uint16_t), s));
-    if (!lm->kv_interleave) MMI_HIP_CHECK(hipMemsetAsync(lm->vc, 0, kvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->kc, 0, kvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->vc, 0, kvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dkc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dvc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));

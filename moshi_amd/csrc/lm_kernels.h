@@ -207,8 +207,6 @@ struct GemmArgs {
     float max_period;
     const float* rope;      // [B][Dh/2][2]: (cos, sin) of the new position's angles, filled once per step by k_lm_prepare
     int kv8;                // the ring holds e4m3 bytes instead of bf16 (fp8 KV cache: half the attention stream)
-    int kvs;                // ring row stride in elements: Dh (keys and values in rings of their own) or 2 * Dh (interleaved: the value
-                            // row of a position directly behind its key row, vc = kc + Dh; MMI_KV_INTERLEAVE)
     // k_gemm_xp_norm: RMSNorm of the input rows fused in front of the GEMM (xp holds the un-normalised rows)
     const uint16_t* alpha;  // [D]
     int D;                  // features of a row (the mean is over D, not the padded K)
@@ -382,7 +380,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 }
             }
             if (sec != 0 && a.kv8) {   // fp8 ring: the bf16 k / v values (k after RoPE, as the bf16 ring would hold them) -> e4m3
-                uint8_t* d8 = reinterpret_cast<uint8_t*>(sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.kvs + d0;
+                uint8_t* d8 = reinterpret_cast<uint8_t*>(sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.Dh + d0;
                 u32x2 o8;
                 o8[0] = mmi_cvt_fp8x4(mmi_round_bf16(v8[0]), mmi_round_bf16(v8[1]), mmi_round_bf16(v8[2]), mmi_round_bf16(v8[3]));
                 o8[1] = mmi_cvt_fp8x4(mmi_round_bf16(v8[4]), mmi_round_bf16(v8[5]), mmi_round_bf16(v8[6]), mmi_round_bf16(v8[7]));
@@ -391,7 +389,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
             }
             uint16_t* dst;
             if (sec == 0) dst = a.qrot + (long)b * HD + hn;
-            else dst = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.kvs + d0;
+            else dst = (sec == 1 ? a.kc : a.vc) + (((long)b * a.H + h) * a.cap + (int)(off % a.cap)) * a.Dh + d0;
             u32x4 ov;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(v8[2 * e], v8[2 * e + 1]);
@@ -1385,7 +1383,6 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
-    int kvs;               // ring row stride in elements (GemmArgs::kvs)
 };
 
 #define MMI_ATTN_CHUNK 256
@@ -1439,8 +1436,8 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
             }
         }
     };
-    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * a.kvs * ES;
-    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * a.kvs * ES;
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * DH * ES;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr int PER_WAVE = CH / 4;
     float m_run = -INFINITY, l_run = 0.f;
@@ -1458,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
-                kk[i] = *reinterpret_cast<const u32x4*>(kbase + ((long)slot * a.kvs + seg * EPL) * ES);
+                kk[i] = *reinterpret_cast<const u32x4*>(kbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -1511,7 +1508,7 @@ __global__ __launch_bounds__(256) void k_lm_attn_split(LmAttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int slot = min(c0 + wave * PER_WAVE + (h0 + i) * RPW + rsub, L - 1);
-                vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * a.kvs + seg * EPL) * ES);
+                vv[i] = *reinterpret_cast<const u32x4*>(vbase + ((long)slot * DH + seg * EPL) * ES);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -1598,9 +1595,9 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
         }
     };
     // wave-uniform base (scalar registers) + a 32-bit lane offset: the loads take the saddr form, no 64-bit address per lane
-    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * a.kvs * ES;
-    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * a.kvs * ES;
-    const unsigned loff = (unsigned)(seg * EPL * ES), rstride = (unsigned)(a.kvs * ES);
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(a.kc) + (long)bh * a.cap * DH * ES;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
+    const unsigned loff = (unsigned)(seg * EPL * ES);
     const float scale = 1.0f / sqrtf((float)DH);
     // context >= capacity (the LM's ring: both 3000): every written slot is inside the window - slot s < L holds a position p with
     // 0 <= offset - p < cap - so the mask (transformer.py:574-582) reduces to `slot < L` and the per-row position arithmetic is
@@ -1619,7 +1616,7 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
 #define MMI_AW_LOAD(KK, VV, j0)                                                                  \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                            \
         const int slot_ = min((wg + ((j0) + i) * total) * RPW + rsub, L - 1);                   \
-        const unsigned o_ = (unsigned)slot_ * rstride + loff;                                   \
+        const unsigned o_ = (unsigned)slot_ * (unsigned)(DH * ES) + loff;                       \
         KK[i] = *reinterpret_cast<const u32x4*>(kbase + o_);                                    \
         VV[i] = *reinterpret_cast<const u32x4*>(vbase + o_);                                    \
     }

@@ -57,17 +57,6 @@ def test_attention_ring_split_over_several_workgroups(sim_lib, monkeypatch, kern
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=61, B=2, S=9)
 
 
-@pytest.mark.parametrize("kernel,quantize", [("wave", False), ("split", False), ("wave", "kv8")])
-def test_interleaved_kv_ring(sim_lib, monkeypatch, kernel, quantize):
-    """MMI_KV_INTERLEAVE=1 (A/B hook): keys and values of a position in one ring row (stride 2 Dh) - same numbers as two rings,
-    through the ring wrap (S > context), both attention kernels, the bf16 and the fp8 ring."""
-    from dataclasses import replace
-    monkeypatch.setenv("MMI_KV_INTERLEAVE", "1")
-    monkeypatch.setenv("MMI_ATTN", kernel)
-    cfg = tiny_lm_config() if not quantize else replace(tiny_lm_config(), kv_cache_dtype="fp8")
-    lm_cases.oracle_vs_engine("cpu", sim_lib, cfg, seed=71, B=3, S=15)
-
-
 def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     """The K-split GEMM path (fp32 partials folded into the residual stream by k_resid_rmsnorm) that the 4096-wide
     layers take at 17..64 sessions, forced onto the tiny shapes."""
