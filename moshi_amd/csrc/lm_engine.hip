@@ -86,6 +86,7 @@ struct mmi_lm {
     uint16_t *tout = nullptr, *text_logits = nullptr;
     uint16_t *kc = nullptr, *vc = nullptr;          // [layers][B][H][cap][Dh]
     float *opart = nullptr, *ml = nullptr;
+    unsigned* attn_done = nullptr;                  // [B][H] arrival counters of the split decode attention (k_lm_attn_wave), 0 between launches
     float* partial = nullptr;                       // [4][B][max(dim, depformer_dim)] split-K partial sums
     float* rope = nullptr;                          // [B][Dh/2][2] (cos, sin) of the step's new position
     // int8 activations (BASELINE configs[4], the reference's own arithmetic: QLinear.forward -> bitsandbytes' int8 x int8 matmul,
@@ -120,6 +121,9 @@ struct mmi_lm {
     void* phase_user = nullptr;
     SampleArgs text_sample_args;    // to rebuild the depth transformer's first input when a hook changed the text token
     long offset_cpu = 0;
+    int attn_ns = 1;                                // workgroups per (session, head) of the decode attention (attn_splits)
+    long depth_bound = 0;                           // no session's offset exceeds this (steps since streaming_start / the last seek; resets
+                                                    // only lower offsets): picks the step program's variant (attn_variant)
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
     bool dominant_xlds = false;     // the profiled (dominant) GEMM ran on k_gemm_xlds
     MmiProgram prog;
@@ -562,6 +566,10 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
         } else {
             if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
             else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
+            // 16-row tile: rows of <= 32 k-steps (the depth transformer's 1024 features) need 4 fragments per wave, not 8: the
+            // smaller register arrays let two workgroups share a CU, so the 352 gated tiles of linear_in are resident at once
+            // instead of running as 256 + 96 (same k partition per wave: bit-identical)
+            else if (a.KSTEPS <= 32) MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4>), NT, 512, 0, s, a);
             else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
         }
         MMI_CHECK_LAUNCH();
@@ -694,6 +702,27 @@ static bool attn_wave_kernel() {
     return !(e && e[0] == 's');
 }
 
+// k_lm_attn_wave, ring split over several workgroups: up to this many rows, workgroup 0 walks the ring alone and writes the output
+// itself (one wave covers 16 rows per iteration: 768 rows = 12 iterations, about what the release + arrival + acquire of the
+// merge costs).  MMI_ATTN_SOLO: test hook (0 = always merge, so the tiny models reach that path)
+static int attn_solo_rows() {
+    if (const char* e = getenv("MMI_ATTN_SOLO")) return atoi(e);
+    return 768;
+}
+
+// The ring split over NS > 1 workgroups (fewer than 32 sessions) has two step programs (MmiProgram::variant):
+//   0  while no ring can hold more than solo_rows rows (the host's bound on the offsets): k_lm_attn_wave alone - workgroup 0 of
+//      each (session, head) walks the ring and writes the output.  One launch per layer instead of two: 4.4 us x 32 layers of a
+//      4.7 ms single-session step.  (Should a ring be longer all the same, the kernel merges in its last-arriving workgroup:
+//      correct whatever the host believes, 8 us per layer slower than a launch - measured, profiles/r04_logs/call_j_summary.txt)
+//   1  deeper rings: partials from every workgroup + the k_lm_attn_combine launch, as in rounds 1-3.
+// MMI_ATTN_MERGE=kernel (test hook) stays on variant 0 whatever the depth.
+static int attn_variant(const mmi_lm* lm, int NS) {
+    if (NS <= 1 || !attn_wave_kernel()) return 0;
+    if (const char* e = getenv("MMI_ATTN_MERGE")) if (e[0] == 'k') return 0;
+    return lm->depth_bound + 1 > (long)attn_solo_rows() ? 1 : 0;
+}
+
 int launch_attn_split(hipStream_t s, const LmAttnArgs& a, bool kv8) {
     dim3 grid(a.B * a.H, a.NS);
     if (attn_wave_kernel()) {
@@ -773,6 +802,7 @@ int build_program(mmi_lm* lm) {
     }
     // ---- temporal transformer
     const int NS = attn_splits(c, B);
+    lm->attn_ns = NS;
     const bool kv8 = c.kv_cache_dtype == MMI_F8E4M3;
     const size_t kv_layer = (size_t)B * H * c.context * Dh / (kv8 ? 2 : 1);     // in uint16 units: an fp8 ring is half as large
     int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
@@ -786,6 +816,7 @@ int build_program(mmi_lm* lm) {
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
+        a.done = lm->attn_done; a.solo_rows = attn_solo_rows();
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
@@ -799,9 +830,12 @@ int build_program(mmi_lm* lm) {
         }
         P.site("L.attn");
         P.add([=](hipStream_t s) {
-            int rc = launch_attn_split(s, a, kv8);
+            LmAttnArgs aa = a;
+            const bool merge_launch = a.NS > 1 && (!attn_wave_kernel() || lm->prog.variant == 1);
+            if (merge_launch) { aa.solo_rows = -1; aa.done = nullptr; }     // every workgroup leaves its partial (m, l, O)
+            int rc = launch_attn_split(s, aa, kv8);
             if (rc) return rc;
-            if (a.NS > 1) MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, a);
+            if (merge_launch) MMI_LAUNCH(k_lm_attn_combine, B * H, Dh < 64 ? 64 : Dh, 0, s, aa);
             MMI_CHECK_LAUNCH();
             return (int)MMI_OK;
         });
@@ -1203,6 +1237,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     lm->kmax = sampling->top_k > sampling->top_k_text ? sampling->top_k : sampling->top_k_text;
     if (lm->kmax < 1) lm->kmax = 1;
     lm->offset_cpu = 0;
+    lm->depth_bound = 0;
     const int G = batch;
     const int B = rows, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
     const int NS = attn_splits(c, B);
@@ -1244,6 +1279,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     ok &= hipSuccess == A.alloc(&lm->vc, kvn);
     ok &= hipSuccess == A.alloc(&lm->opart, (size_t)B * H * NS * Dh);
     ok &= hipSuccess == A.alloc(&lm->ml, (size_t)B * H * NS * 2);
+    ok &= hipSuccess == A.alloc(&lm->attn_done, (size_t)B * H);
     ok &= hipSuccess == A.alloc(&lm->partial, (size_t)4 * B * (d > dd ? d : dd));
     ok &= hipSuccess == A.alloc(&lm->rope, (size_t)B * Dh);
     lm->htap = nullptr;
@@ -1296,6 +1332,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     MMI_LAUNCH(k_fill_i32, mmi_cdiv(G * lm->NC * lm->CT, 256), 256, 0, s, lm->cache, -2, (long)G * lm->NC * lm->CT);   // lm.py:608-613
     MMI_HIP_CHECK(hipMemsetAsync(lm->kc, 0, kvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->vc, 0, kvn * sizeof(uint16_t), s));
+    MMI_HIP_CHECK(hipMemsetAsync(lm->attn_done, 0, (size_t)B * H * sizeof(unsigned), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dkc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->dvc, 0, dkvn * sizeof(uint16_t), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_noise, 0, sizeof(int), s));
@@ -1379,6 +1416,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     }
     MMI_CHECK_LAUNCH();
     int rc;
+    lm->prog.variant = attn_variant(lm, lm->attn_ns);
     const bool hooked = lm->hooks.on_text_logits || lm->hooks.on_text_token || lm->hooks.on_audio_tokens;
     if (hooked) {
         rc = run_step_with_hooks(lm, s);
@@ -1410,6 +1448,7 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
         lm->forced_armed = false;
     }
     lm->offset_cpu += 1;
+    if (lm->depth_bound < (1L << 40)) lm->depth_bound += 1;
     if (valid) *valid = lm->offset_cpu > lm->max_delay ? 1 : 0;   // lm.py:774-776
     return MMI_OK;
 }
@@ -1508,6 +1547,7 @@ extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int
     if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch / guidance)");
     MMI_HIP_CHECK(lm->st.load(src, (hipStream_t)stream));
     lm->offset_cpu = (long)host_word;
+    lm->depth_bound = 1L << 40;        // the snapshot's offsets are not known here: take the program that is right at any depth
     lm->forced_armed = false;
     lm->noise_on = true;               // the snapshot carries its own use_noise word: the next step rewrites it
     return MMI_OK;
@@ -1533,8 +1573,8 @@ int64_t mmi_copy_launch_log(const std::vector<std::string>& log, char* buf, int6
 
 extern "C" int64_t mmi_lm_launch_list(const mmi_lm* lm, char* buf, int64_t cap) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
-    if (!lm || !lm->streaming || !lm->prog.logged) return 0;
-    return mmi_copy_launch_log(lm->prog.launch_log, buf, cap);
+    if (!lm || !lm->streaming || !lm->prog.logged()) return 0;
+    return mmi_copy_launch_log(lm->prog.launch_log(), buf, cap);
 }
 
 extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream) {
@@ -1555,6 +1595,7 @@ extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream
     MMI_HIP_CHECK(hipMemcpy(lm->offsets, off.data(), (size_t)G * sizeof(long), hipMemcpyHostToDevice));
     if (lm->offsets_m != lm->offsets) MMI_HIP_CHECK(hipMemcpy(lm->offsets_m, off.data(), (size_t)lm->batch * sizeof(long), hipMemcpyHostToDevice));
     lm->offset_cpu = mx;
+    lm->depth_bound = mx;
     return MMI_OK;
 }
 

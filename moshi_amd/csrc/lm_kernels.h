@@ -600,7 +600,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
 // LDS, normalise their own fragments in registers and only then run the MFMAs.  No split-K over workgroups here.
 // WQ = 1 / 2: int8 / fp8 weights, a.KSTEPS counts k-step pairs (see k_gemm_xp); KMAX = weight entries per wave.
 template <int TN, int MT, int WAVES, int KMAX, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_norm(GemmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (TN == 16 && KMAX == 4 && WQ == 0) ? 4 : 1) void k_gemm_xp_norm(GemmArgs a) {   // 16-row tile, short rows: two workgroups per CU
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
@@ -1383,6 +1383,9 @@ struct LmAttnArgs {
     int B, H, Dh, cap, context, NS;
     int T, out_ksteps;
     float max_period;
+    unsigned* done;        // k_lm_attn_wave with the ring split over NS workgroups: arrival counter per (session, head), 0 between launches
+                           // (the last workgroup to arrive merges); null = leave the partials to k_lm_attn_combine
+    int solo_rows;         // ... rings of at most this many rows are walked by workgroup y = 0 alone (the others exit at once); -1 = never
 };
 
 #define MMI_ATTN_CHUNK 256
@@ -1603,7 +1606,13 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
     // 0 <= offset - p < cap - so the mask (transformer.py:574-582) reduces to `slot < L` and the per-row position arithmetic is
     // skipped (wave-uniform branch); a ring longer than its attention window keeps it
     const bool windowed = a.context < a.cap;
-    const int total = (int)gridDim.y * 4, wg = (int)blockIdx.y * 4 + wave;       // waves serving this pair, and which one this is
+    // Fewer (session, head) pairs than it takes to fill the chip (one real-time session: 32): the ring is shared out over gridDim.y
+    // workgroups - but only where it is long enough to be worth the merge: a short ring is walked by workgroup y = 0 alone, which
+    // then writes the final output itself (no partials, no fence, and no combine launch either way: see the end of the kernel)
+    const bool solo = (int)gridDim.y > 1 && L <= a.solo_rows;
+    if (solo && blockIdx.y != 0) return;
+    const int nsplit = solo ? 1 : (int)gridDim.y;
+    const int total = nsplit * 4, wg = (solo ? 0 : (int)blockIdx.y * 4) + wave;  // waves serving this pair, and which one this is
     const int ngroups = (L + RPW - 1) / RPW;
     const int nmine = wg < ngroups ? (ngroups - wg + total - 1) / total : 0;       // row groups wg, wg + total, ...
     const int nrounds = (nmine + NB - 1) / NB;
@@ -1711,7 +1720,7 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
             num += sw * wacc[w * DH + tid];
             den += sw * wl[w];
         }
-        if (gridDim.y == 1) {
+        if (nsplit == 1) {
             a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
         } else {
             a.opart[((long)bh * gridDim.y + blockIdx.y) * DH + tid] = num;
@@ -1721,6 +1730,37 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
                 mlp[1] = den;
             }
         }
+    }
+    if (nsplit == 1 || a.done == nullptr) return;        // (no counter: k_lm_attn_combine follows in a launch of its own)
+    // ---- the workgroup that arrives LAST merges the partials: out = sum_c e^{m_c - M} O_c / sum_c e^{m_c - M} l_c.  The safety net
+    // of the engine's shallow-ring program (lm_engine.hip attn_variant), which has no merge launch: the release + arrival + acquire
+    // chain costs about 8 us per layer more than that launch would, so rings the host KNOWS may be deep take the other program
+    MMI_SHARED unsigned s_last;
+    __syncthreads();                                     // the partials of this workgroup are stored
+    if (tid == 0) {
+        const unsigned seen = mmi_arrive_release(a.done + bh);
+        s_last = seen == (unsigned)gridDim.y - 1u ? 1u : 0u;
+        if (s_last) {
+            mmi_store_relaxed_agent(a.done + bh, 0u);    // everyone has arrived: the counter is ready for the next launch
+            mmi_acquire_agent();
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < DH) {
+        const int NSg = (int)gridDim.y;
+        const float* ml = a.ml + (long)bh * NSg * 2;
+        float M = -INFINITY;
+        for (int c = 0; c < NSg; ++c) M = fmaxf(M, ml[2 * c]);
+        float num = 0.f, den = 0.f;
+        for (int c = 0; c < NSg; ++c) {
+            const float m = ml[2 * c];
+            if (m == -INFINITY) continue;
+            const float w = expf(m - M);
+            num += w * a.opart[((long)bh * NSg + c) * DH + tid];
+            den += w * ml[2 * c + 1];
+        }
+        a.out[mmi_xp_index(a.T, b, (bh % a.H) * DH + tid, a.out_ksteps)] = mmi_f32_to_bf16(num / den);
     }
 }
 

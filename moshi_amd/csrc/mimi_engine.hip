@@ -1146,8 +1146,8 @@ extern "C" int64_t mmi_mimi_launch_list(const mmi_mimi* m, int32_t which, char* 
     MmiDeviceGuard dev_guard_(m ? m->device : -1);
     if (!m || !m->streaming) return 0;
     const MmiProgram& p = which == 0 ? m->enc_prog : m->dec_prog;
-    if (!p.logged) return 0;
-    return mmi_copy_launch_log(p.launch_log, buf, cap);
+    if (!p.logged()) return 0;
+    return mmi_copy_launch_log(p.launch_log(), buf, cap);
 }
 
 extern "C" int mmi_mimi_get_cfg(const mmi_mimi* m, mmi_mimi_cfg* out) {

@@ -146,6 +146,20 @@ __device__ __forceinline__ uint32_t mmi_pack_low_bytes(uint32_t a, uint32_t b, u
 // round-half-even to the nearest integer (v_rndne_f32), the rounding of bitsandbytes' int8_vectorwise_quant
 __device__ __forceinline__ float mmi_rint(float x) { return __builtin_rintf(x); }
 
+// "Last arriver finishes" inside one launch (k_lm_attn_wave's ring split): a workgroup publishes its partial result with plain
+// stores, then ONE lane releases at agent scope (L2 write-back), drains, and bumps the arrival counter; the workgroup that sees
+// the final count acquires at agent scope (invalidates its CU's L1) and reads the others' partials with plain loads - the
+// producer / consumer forms MI355X_MICROARCH.md lists as valid across XCDs.  Call from ONE thread, between two __syncthreads().
+__device__ __forceinline__ unsigned mmi_arrive_release(unsigned* counter) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait: keep one it cannot see through)
+    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mmi_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void mmi_store_relaxed_agent(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // streamed-once weights: non-temporal so they do not evict the activations / KV the other kernels reuse
 __device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_nontemporal_load(p); }

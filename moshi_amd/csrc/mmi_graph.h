@@ -17,27 +17,35 @@ void mmi_record_bytes(long bytes);      // the NEXT launch streams this many wei
 void mmi_record_end();
 
 struct MmiProgram {
+    // A list may exist in up to NV variants: the op lambdas may read `variant` when they are launched / captured and issue
+    // different launches for it.  Each variant is captured into its own graph(s) the first time it runs; the caller picks one per
+    // step from what it knows on the HOST (lm_engine.hip: how deep the KV rings can be decides whether the decode attention
+    // needs its merge launch).  Programs that never touch `variant` have one.
+    static constexpr int NV = 2;
     std::vector<std::function<int(hipStream_t)>> ops;
     std::vector<std::string> sites;             // one label per op
     std::vector<long> op_bytes;                 // weight bytes the op streams (GEMMs), 0 otherwise
     std::function<void(size_t, bool, hipStream_t)> tap;   // profiling: called before (true) and after (false) every eagerly run op
-    std::vector<std::string> launch_log;        // "site\tkernel" per launch, in launch order (filled by the first run)
+    std::vector<std::string> launch_logs[NV];   // "site\tkernel" per launch, in launch order (filled by the variant's first run)
     std::string site_ = "-";                    // label given to the ops added from now on
-    bool logged = false;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    bool logged_[NV] = {false, false};
+    int variant = 0;
+    hipGraph_t graph[NV] = {nullptr, nullptr};
+    hipGraphExec_t exec[NV] = {nullptr, nullptr};
     // the same list captured as two graphs, ops [0, cut) and [cut, end), for callers that put something between the halves
     // (run_split: an event record that another stream waits on)
-    hipGraph_t graph_a = nullptr, graph_b = nullptr;
-    hipGraphExec_t exec_a = nullptr, exec_b = nullptr;
-    size_t cut_ = 0;
+    hipGraph_t graph_a[NV] = {nullptr, nullptr}, graph_b[NV] = {nullptr, nullptr};
+    hipGraphExec_t exec_a[NV] = {nullptr, nullptr}, exec_b[NV] = {nullptr, nullptr};
+    size_t cut_[NV] = {0, 0};
 
     void site(const std::string& label) { site_ = label; }
     void add(std::function<int(hipStream_t)> f, long bytes = 0) { ops.push_back(std::move(f)); sites.push_back(site_); op_bytes.push_back(bytes); }
+    bool logged() const { return logged_[variant]; }
+    const std::vector<std::string>& launch_log() const { return launch_logs[variant]; }
 
     int run_eager(hipStream_t s) {
-        const bool rec = !logged;
-        if (rec) mmi_record_begin(&launch_log);
+        const bool rec = !logged_[variant];
+        if (rec) mmi_record_begin(&launch_logs[variant]);
         int rc = MMI_OK;
         for (size_t i = 0; i < ops.size() && !rc; ++i) {
             if (rec) mmi_record_site(sites[i].c_str());
@@ -45,7 +53,7 @@ struct MmiProgram {
             rc = ops[i](s);
             if (tap) tap(i, false, s);
         }
-        if (rec) { mmi_record_end(); logged = true; }
+        if (rec) { mmi_record_end(); logged_[variant] = true; }
         return rc;
     }
 
@@ -58,15 +66,26 @@ struct MmiProgram {
 
     int run(hipStream_t s, bool use_graph, hipStream_t capture_stream) {
         if (!use_graph) return run_eager(s);
-        if (!exec) {
+        const int v = variant;
+        if (!exec[v]) {
             MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
             int rc = run_eager(capture_stream);
-            hipError_t e = hipStreamEndCapture(capture_stream, &graph);
-            if (rc) return rc;
-            if (e != hipSuccess) return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            MMI_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipError_t e = hipStreamEndCapture(capture_stream, &graph[v]);
+            if (rc || e != hipSuccess) {
+                if (e == hipSuccess && graph[v]) hipGraphDestroy(graph[v]);
+                graph[v] = nullptr;
+                if (rc) return rc;
+                return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            }
+            e = hipGraphInstantiate(&exec[v], graph[v], nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                hipGraphDestroy(graph[v]);
+                graph[v] = nullptr;
+                exec[v] = nullptr;
+                return mmi_fail(MMI_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            }
         }
-        MMI_HIP_CHECK(hipGraphLaunch(exec, s));
+        MMI_HIP_CHECK(hipGraphLaunch(exec[v], s));
         return MMI_OK;
     }
 
@@ -93,48 +112,55 @@ struct MmiProgram {
     // ops [0, cut) - between(s) - ops [cut, end): as two graph launches (or eagerly), `between` enqueued on s in the middle
     int run_split(hipStream_t s, bool use_graph, hipStream_t capture_stream, size_t cut, const std::function<int(hipStream_t)>& between) {
         int rc;
-        if (!use_graph || !logged) {            // the first run of a program is the eager one that records the launch list
-            const bool rec = !logged;
-            if (rec) mmi_record_begin(&launch_log);
+        const int v = variant;
+        if (!use_graph || !logged_[v]) {        // the first run of a variant is the eager one that records the launch list
+            const bool rec = !logged_[v];
+            if (rec) mmi_record_begin(&launch_logs[v]);
             rc = MMI_OK;
             for (size_t i = 0; i < ops.size() && !rc; ++i) {
                 if (i == cut && (rc = between(s))) break;
-                if (rec) mmi_record_site(sites[i].c_str());
+                    if (rec) mmi_record_site(sites[i].c_str());
                 if (tap) tap(i, true, s);
                 rc = ops[i](s);
                 if (tap) tap(i, false, s);
             }
-            if (rec) { mmi_record_end(); logged = true; }
+            if (rec) { mmi_record_end(); logged_[v] = true; }
             return rc;
         }
-        if (!exec_a || cut_ != cut) {
-            if (exec_a) { hipGraphExecDestroy(exec_a); hipGraphDestroy(graph_a); exec_a = nullptr; }
-            if (exec_b) { hipGraphExecDestroy(exec_b); hipGraphDestroy(graph_b); exec_b = nullptr; }
-            if ((rc = capture_range(capture_stream, 0, cut, &graph_a, &exec_a))) return rc;
-            if ((rc = capture_range(capture_stream, cut, ops.size(), &graph_b, &exec_b))) return rc;
-            cut_ = cut;
+        if (!exec_a[v] || cut_[v] != cut) {
+            drop_split(v);
+            if ((rc = capture_range(capture_stream, 0, cut, &graph_a[v], &exec_a[v]))) return rc;
+            if ((rc = capture_range(capture_stream, cut, ops.size(), &graph_b[v], &exec_b[v]))) return rc;
+            cut_[v] = cut;
         }
-        MMI_HIP_CHECK(hipGraphLaunch(exec_a, s));
+        MMI_HIP_CHECK(hipGraphLaunch(exec_a[v], s));
         if ((rc = between(s))) return rc;
-        MMI_HIP_CHECK(hipGraphLaunch(exec_b, s));
+        MMI_HIP_CHECK(hipGraphLaunch(exec_b[v], s));
         return MMI_OK;
     }
 
+    void drop_split(int v) {
+        if (exec_a[v]) { hipGraphExecDestroy(exec_a[v]); hipGraphDestroy(graph_a[v]); }
+        if (exec_b[v]) { hipGraphExecDestroy(exec_b[v]); hipGraphDestroy(graph_b[v]); }
+        exec_a[v] = exec_b[v] = nullptr;
+        graph_a[v] = graph_b[v] = nullptr;
+    }
+
     void clear() {
-        if (exec) hipGraphExecDestroy(exec);
-        if (graph) hipGraphDestroy(graph);
-        if (exec_a) { hipGraphExecDestroy(exec_a); hipGraphDestroy(graph_a); }
-        if (exec_b) { hipGraphExecDestroy(exec_b); hipGraphDestroy(graph_b); }
-        exec_a = exec_b = nullptr;
-        graph_a = graph_b = nullptr;
-        exec = nullptr;
-        graph = nullptr;
+        for (int v = 0; v < NV; ++v) {
+            if (exec[v]) hipGraphExecDestroy(exec[v]);
+            if (graph[v]) hipGraphDestroy(graph[v]);
+            exec[v] = nullptr;
+            graph[v] = nullptr;
+            drop_split(v);
+            launch_logs[v].clear();
+            logged_[v] = false;
+        }
+        variant = 0;
         ops.clear();
         sites.clear();
         op_bytes.clear();
         tap = nullptr;
-        launch_log.clear();
-        logged = false;
         site_ = "-";
     }
 };

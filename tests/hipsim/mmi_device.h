@@ -331,6 +331,10 @@ inline uint32_t mmi_pack_low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t 
     return (a & 0xffu) | ((b & 0xffu) << 8) | ((c & 0xffu) << 16) | ((d & 0xffu) << 24);
 }
 
+inline unsigned mmi_arrive_release(unsigned* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL); }
+inline void mmi_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+inline void mmi_store_relaxed_agent(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
 inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }

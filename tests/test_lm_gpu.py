@@ -70,12 +70,20 @@ def test_fp8_kv_ring_matches_the_oracle(gpu_lib, B, S):
     lm_cases.oracle_vs_engine(DEV, None, replace(tiny_lm_config(), kv_cache_dtype="fp8"), seed=120 + B, B=B, S=S)
 
 
-@pytest.mark.parametrize("kv", ["bf16", "fp8"])
-def test_long_ring_split_over_workgroups_matches_oracle(gpu_lib, kv):
-    """A ring longer than one 256-slot chunk with few (session, head) pairs: the decode attention splits the ring over
-    several workgroups and merges the partials (k_lm_attn_split NS > 1 + k_lm_attn_combine), 300 positions deep."""
+@pytest.mark.parametrize("kv,path", [("bf16", "launch"), ("bf16", "solo"), ("bf16", "switch"), ("bf16", "kernel"), ("fp8", "switch")])
+def test_long_ring_split_over_workgroups_matches_oracle(gpu_lib, monkeypatch, kv, path):
+    """A ring longer than one 256-slot chunk with few (session, head) pairs: the decode attention (k_lm_attn_wave) splits the
+    ring over several workgroups and k_lm_attn_combine merges their partials ("launch": MMI_ATTN_SOLO=0 takes that step program
+    from the first row) - or, while the ring is short ("solo": the default, up to 768 rows), workgroup 0 walks it alone and there
+    is no merge launch; "switch": the engine goes from the "solo" program (graph) to the "launch" one after 100 steps, as a real
+    session does after 768; "kernel": the shallow program's safety net, the merge done by the last workgroup to arrive inside the launch
+    (agent-scope release / acquire across XCDs).  300 positions deep."""
     from dataclasses import replace
     from oracle.lm_oracle import LMOracle
+    if path != "solo":
+        monkeypatch.setenv("MMI_ATTN_SOLO", "100" if path == "switch" else "0")
+    if path == "kernel":
+        monkeypatch.setenv("MMI_ATTN_MERGE", "kernel")
     cfg = replace(tiny_lm_config(), context=600, kv_cache_dtype=kv)
     sd = random_lm_state_dict(cfg, seed=44)
     gen = LMGen(LMModel(sd, cfg, device=DEV, max_batch=1), use_sampling=False, support_out_of_sync=True)

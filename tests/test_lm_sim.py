@@ -47,13 +47,20 @@ def test_wide_batch_tiles_match_oracle(sim_lib, B):
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=60 + B, B=B, S=3)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "split"])
+@pytest.mark.parametrize("kernel", ["wave", "wave-solo", "wave-switch", "wave-kernel", "split"])
 def test_attention_ring_split_over_several_workgroups(sim_lib, monkeypatch, kernel):
     """Fewer (session, head) pairs than CUs (one real-time session: 32 pairs): the ring is shared out over several workgroups
     per pair and their partial (max, sum, output) merged by k_lm_attn_combine - forced here on the tiny model, for the
-    barrier-free kernel of round 4 and the chunked one it replaces."""
+    barrier-free kernel of round 4 ("wave") and the chunked one it replaces ("split").  The wave kernel's other paths
+    (lm_engine.hip attn_variant): "wave-solo" = rings of up to MMI_ATTN_SOLO rows, workgroup 0 alone and no merge at all;
+    "wave-switch" = the engine changes from that step program to the one with the merge launch when its host-side bound on the
+    ring depth passes the threshold (here after 4 of the 9 steps); "wave-kernel" = the merge done by the last workgroup to
+    arrive, the shallow program's safety net."""
     monkeypatch.setenv("MMI_ATTN_NS", "3")
-    monkeypatch.setenv("MMI_ATTN", kernel)
+    monkeypatch.setenv("MMI_ATTN", kernel.split("-")[0])
+    monkeypatch.setenv("MMI_ATTN_SOLO", {"wave-solo": "768", "wave-switch": "4"}.get(kernel, "0"))
+    if kernel == "wave-kernel":
+        monkeypatch.setenv("MMI_ATTN_MERGE", "kernel")
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=61, B=2, S=9)
 
 
