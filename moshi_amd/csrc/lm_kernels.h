@@ -443,8 +443,12 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 // (a.KSTEPS then counts pairs; the activation buffers hold 2*KSTEPS k-steps, zero padded).
 // WQ = 3: int8 weight entries x int8 activation entries (a.xp = Xq, one 16-byte entry per weight entry, a.sx = row absmax) on
 // v_mfma_i32_{32x32x32,16x16x64}_i8; the int32 sums are converted to fp32 once per wave and go through the common epilogue.
+// The 16-row tile (<= 16 sessions) with bf16 weights is held to 128 registers: two 8-wave workgroups per CU, so that one's
+// reduction + epilogue runs under the other's weight stream (136 registers unbounded; 8 spill, outside the loop).  Same-box at
+// 1 / 8 / 16 sessions: -0.12 / -0.14 / -0.12 ms per step (in_proj 20.9 -> 19.4 us, linear_in 38.4 -> 35.5, text head 48.9 ->
+// 44.2; profiles/r04_logs/call_m_summary.txt).
 template <int TN, int MT, int NTW, int WAVES, int U, int WQ = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp(GemmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (TN == 16 && MT == 1 && NTW == 1 && WQ == 0 && WAVES == 8) ? 4 : 1) void k_gemm_xp(GemmArgs a) {
     constexpr bool W8 = WQ == 1;
     constexpr int R = TN == 32 ? 16 : 4;          // accumulator registers per MFMA tile
     constexpr int XS = (WQ == 1 || WQ == 2) ? 2 : 1;   // activation fragments per weight entry
