@@ -472,6 +472,42 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
     lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); }, (long)g.bytes);
 }
 
+// The depth transformer's attention inside its out_proj (k_dep_attn_out_proj): ONE session at the 16-row tile (the real-time
+// configuration), bf16 weights, a wave's K-slice = one or two whole heads.  Same-box at 1 / 2 / 4 sessions: -0.06 / +0.04 / +0.27 ms
+// per step (a wave works through its 2 B pairs one after the other; profiles/r04_logs/call_o2_summary.txt), hence one session only.
+// MMI_NO_DEP_ATTN_FUSION=1: the two launches (A/B and the bit-equality test)
+bool dep_attn_fusable(const mmi_lm* lm, const GemmW& g, int H, int Dh, int steps) {
+    if (lm->T != 16 || lm->batch != 1 || lm->act8 || g.wq != 0 || getenv("MMI_NO_DEP_ATTN_FUSION")) return false;
+    if (Dh % 8 || Dh > 64 || steps > 8 || g.KSTEPS * 32 != H * Dh) return false;
+    const GemmPlan p = plan_gemm(g, false);
+    const int kper = mmi_cdiv(g.KSTEPS, p.waves);
+    return kper <= 4 && (kper * 32) % Dh == 0 && kper * 32 / Dh <= 2;
+}
+
+template <int WAVES>
+int launch_dep_attn_out_proj(hipStream_t s, int groups, const GemmArgs& a, const DepAttnArgs& d) {
+    MMI_LAUNCH((k_dep_attn_out_proj<WAVES, 2, 1>), groups, WAVES * 64, 0, s, a, d);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
+// x += out_proj(attention(qkv, frame cache)) (dep_attn_fusable)
+void add_dep_attn_out_proj(mmi_lm* lm, const GemmW& g, const DepAttnArgs& da, uint16_t* x, int features) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = x; a.epi = MMI_EPI_RESID; a.resid = x; a.B = lm->batch; a.tok_rows = lm->gen_batch;
+    a.out_mode = MMI_OUT_PACKED; a.out_ld = features; a.out_ksteps = packed_ksteps(lm, features);
+    a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT; a.wscale = g.scale; a.xinv = g.xinv;
+    const GemmPlan p = plan_gemm(g, false);
+    a.osplit = plan_osplit(g, p, a.epi, lm->T);
+    const int groups = g.NT * (a.osplit > 1 ? a.osplit : 1), waves = p.waves;
+    const long bytes = (long)g.bytes;
+    lm->prog.add([=](hipStream_t s) {
+        mmi_record_bytes(bytes);
+        return waves == 8 ? launch_dep_attn_out_proj<8>(s, groups, a, da) : launch_dep_attn_out_proj<4>(s, groups, a, da);
+    }, bytes);
+}
+
 // K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
 // Returns the number of partials, 0 when the GEMM is not split (then it applied the residual itself, in place on x).
 int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features, const Q8* q8 = nullptr) {
@@ -936,7 +972,8 @@ int build_program(mmi_lm* lm) {
             da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
             P.site("dep.attn");
             const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8;        // else the general one-wave-per-(session, head) kernel
-            if (!skip_attn0)
+            const bool attn_in_gemm = !skip_attn0 && attn8 && dep_attn_fusable(lm, L.out_proj[k], Hd, Dhd, c.dep_q);
+            if (!skip_attn0 && !attn_in_gemm)
             P.add([=](hipStream_t s) {
                 if (attn8) MMI_LAUNCH((k_dep_attn8<4>), mmi_cdiv(B * Hd, 4), 256, 0, s, da);
                 else MMI_LAUNCH(k_dep_attn, B * Hd, 64, 0, s, da);
@@ -945,7 +982,8 @@ int build_program(mmi_lm* lm) {
             });
             // int8 activations: the chain's linears quantise their own input row inside the GEMM (k_gemm_q8)
             P.site("dep.out_proj");
-            if (a8) add_q8_gemm(lm, L.out_proj[k], lm->datt, dd, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
+            if (attn_in_gemm) add_dep_attn_out_proj(lm, L.out_proj[k], da, lm->dx, dd);
+            else if (a8) add_q8_gemm(lm, L.out_proj[k], lm->datt, dd, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
             else add_gemm(lm, L.out_proj[k], lm->datt, lm->dx, dd, true, MMI_EPI_RESID, lm->dx);
             P.site("dep.ffn_in");
             add_norm_gemm(lm, L.ffn_in[k], lm->dx, L.n2, lm->dxn, dd, lm->dhb, c.depformer_ffn_hidden, true, MMI_EPI_GATE);

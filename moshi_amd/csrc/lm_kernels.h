@@ -1861,12 +1861,13 @@ __global__ __launch_bounds__(64) void k_dep_attn(DepAttnArgs a) {
 // chunk of q, of key row j and of value row j once (the newest row straight from the in_proj output, which the lanes of
 // position k also copy into the frame's cache), reduces the score over the 8 chunk lanes, the softmax and P.V over the 8
 // position groups (3 butterfly steps each), and the lanes of position 0 store 8 output features as one 16-byte vector.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int bh = (int)blockIdx.x * NW + wave;
-    if (bh >= a.B * a.H) return;
-    const int b = bh / a.H, h = bh - b * a.H;
+// One (session, head) by the calling wave, in two parts so that a wave serving several pairs (k_dep_attn_out_proj) has all their
+// loads in flight before the first dependent instruction.  mmi_dep_attn8_load: the lane's 16-byte chunk of q, of key row j and of
+// value row j (write_cache: the lanes of position k also copy the newest key / value row into the frame's cache);
+// mmi_dep_attn8_reduce: on return the lanes of position 0 (j == 0, c < Dh / 8) hold output features 8 c .. 8 c + 7 of the head as
+// packed bf16.
+struct DepAttnOperands { u32x4 q, k, v; };
+__device__ __forceinline__ DepAttnOperands mmi_dep_attn8_load(const DepAttnArgs& a, int b, int h, int lane, bool write_cache) {
     const int Dh = a.Dh, HD = a.H * Dh, NC = Dh >> 3;
     const int j = lane >> 3, c = lane & 7;
     const int jc = j < a.k ? j : a.k, cc = c < NC ? c : 0;          // clamped: every lane loads from a valid address
@@ -1874,13 +1875,20 @@ __global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
     uint16_t* kcb = a.kc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     uint16_t* vcb = a.vc + ((long)b * a.H + h) * a.steps * Dh + 8 * cc;
     const bool newest = jc == a.k;
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(row);
-    const u32x4 kv = *reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh);
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh);
-    if (j == a.k && c < NC) {                                       // this frame's cache, position k (transformer.py:243-253)
-        *reinterpret_cast<u32x4*>(kcb + (long)a.k * Dh) = kv;
-        *reinterpret_cast<u32x4*>(vcb + (long)a.k * Dh) = vv;
+    DepAttnOperands o;
+    o.q = *reinterpret_cast<const u32x4*>(row);
+    o.k = *reinterpret_cast<const u32x4*>(newest ? row + HD : kcb + (long)jc * Dh);
+    o.v = *reinterpret_cast<const u32x4*>(newest ? row + 2 * HD : vcb + (long)jc * Dh);
+    if (write_cache && j == a.k && c < NC) {                        // this frame's cache, position k (transformer.py:243-253)
+        *reinterpret_cast<u32x4*>(kcb + (long)a.k * Dh) = o.k;
+        *reinterpret_cast<u32x4*>(vcb + (long)a.k * Dh) = o.v;
     }
+    return o;
+}
+__device__ __forceinline__ u32x4 mmi_dep_attn8_reduce(const DepAttnArgs& a, const DepAttnOperands& in, int lane) {
+    const int Dh = a.Dh, NC = Dh >> 3;
+    const int j = lane >> 3, c = lane & 7;
+    const u32x4 qv = in.q, kv = in.k, vv = in.v;
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1906,12 +1914,97 @@ __global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
     for (int e = 0; e < 8; ++e) {
         o[e] += mmi_shfl_xor(o[e], 8); o[e] += mmi_shfl_xor(o[e], 16); o[e] += mmi_shfl_xor(o[e], 32);
     }
-    if (j == 0 && c < NC) {
-        u32x4 ov;
+    u32x4 ov;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
-        *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * Dh + 8 * c, a.out_ksteps)) = ov;
+    for (int e = 0; e < 4; ++e) ov[e] = mmi_pack_bf16x2(o[2 * e] / den, o[2 * e + 1] / den);
+    return ov;
+}
+__device__ __forceinline__ u32x4 mmi_dep_attn8_wave(const DepAttnArgs& a, int b, int h, int lane, bool write_cache) {
+    return mmi_dep_attn8_reduce(a, mmi_dep_attn8_load(a, b, h, lane, write_cache), lane);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_dep_attn8(DepAttnArgs a) {
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int bh = (int)blockIdx.x * NW + wave;
+    if (bh >= a.B * a.H) return;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const u32x4 ov = mmi_dep_attn8_wave(a, b, h, lane, true);
+    const int j = lane >> 3, c = lane & 7;
+    if (j == 0 && c < (a.Dh >> 3)) *reinterpret_cast<u32x4*>(a.out + mmi_xp_index(a.T, b, h * a.Dh + 8 * c, a.out_ksteps)) = ov;
+}
+
+// The depth transformer's attention INSIDE its out_proj (one session - the engine instantiates BMAX = 1 - at the 16-row tile,
+// micro-steps >= 1): the GEMM's K axis is the attention output [head][Dh], a wave's K-slice is whole heads, so every workgroup's
+// wave computes the (session, head) pairs of its own slice itself - k_dep_attn8's arithmetic, straight after requesting its weight
+// fragments - and hands the 8-feature pieces to the lanes that hold them in the MFMA operand through LDS: two pairs per wave, a
+// few hundred bytes from L2.  What it removes is a 4.5 us launch on the depth transformer's dependent chain, 42 times per step
+// (the GEMM grows by 1.6 us).  The workgroups all compute the same thing; workgroup 0 also writes the newest key / value rows to
+// the frame's cache.  Bit-identical to the two launches (the same per-pair functions, the same operand values).
+template <int WAVES, int HPW, int BMAX>
+__global__ __launch_bounds__(WAVES * 64) void k_dep_attn_out_proj(GemmArgs a, DepAttnArgs d) {
+    constexpr int TN = 16, R = 4, KPWMAX = 4;
+    typedef float acc_t __attribute__((ext_vector_type(R)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int os = a.osplit > 1 ? a.osplit : 1;                     // octet sharing as in k_gemm_xp
+    const int bx = (int)blockIdx.x / os, part = (int)blockIdx.x - bx * os;
+    const int nt0 = bx;
+    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
+    const int ro = (lane >> 3) & (TN / 8 - 1);
+    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, 1, 1>(a, nt0);
+    const int kper = (a.KSTEPS + WAVES - 1) / WAVES;                // <= KPWMAX, kper * 32 a multiple of Dh (launcher)
+    const int ks0 = min(a.KSTEPS, wave * kper);
+    const int nks = min(a.KSTEPS, ks0 + kper) - ks0;
+    const int last = nks > 0 ? nks - 1 : 0;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4* wp = a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + min(ks0, a.KSTEPS - 1)) * 64 + wlane;
+    u32x4 wv[KPWMAX];
+#pragma unroll
+    for (int u = 0; u < KPWMAX; ++u) wv[u] = mmi_load_nt(wp + min(u, last) * 64);
+    // ---- the attention of this wave's heads
+    MMI_SHARED __attribute__((aligned(16))) u32x4 xs[WAVES][KPWMAX][64];
+    const int h0 = ks0 * 32 / d.Dh, nh = nks * 32 / d.Dh;
+    const int j = lane >> 3, c = lane & 7;
+    DepAttnOperands in[HPW][BMAX];                                   // every pair's loads first (clamped pairs repeat a live one)
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b)
+            in[hh][b] = mmi_dep_attn8_load(d, min(b, d.B - 1), min(h0 + hh, d.H - 1), lane, false);
+    if (blockIdx.x == 0) {                                           // the newest key / value rows into the frame's cache: one workgroup
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (!(hh < nh && b < d.B) || j != d.k || c >= (d.Dh >> 3)) continue;
+                const long at = (((long)b * d.H + h0 + hh) * d.steps + d.k) * d.Dh + 8 * c;
+                *reinterpret_cast<u32x4*>(d.kc + at) = in[hh][b].k;
+                *reinterpret_cast<u32x4*>(d.vc + at) = in[hh][b].v;
+            }
     }
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
+            const bool on = hh < nh && b < d.B;                      // wave-uniform
+            const u32x4 ov = mmi_dep_attn8_reduce(d, in[hh][b], lane);
+            const int kl = (h0 + hh) * d.Dh + 8 * c - ks0 * 32;      // feature offset inside the wave's slice
+            if (on && j == 0 && c < (d.Dh >> 3)) xs[wave][kl >> 5][((kl & 31) >> 3) * 16 + b] = ov;
+        }
+    __syncthreads();
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPWMAX; ++u) {
+        const u32x4 xv = (u < nks && (lane & 15) < d.B) ? xs[wave][u][lane] : zero;
+        if (u < nks) acc = mmi_mfma_bf16_16x16x32(wv[u], xv, acc);
+    }
+    float accv[1][1][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) accv[0][0][r] = acc[r];
+    mmi_gemm_epilogue<TN, 1, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -285,6 +285,20 @@ def test_batch_rows_independent_and_graph_equals_eager(gpu_lib, monkeypatch):
     assert torch.equal(oe, o32) and torch.equal(te, t32)
 
 
+def test_depformer_attention_inside_out_proj_is_bit_identical_to_its_own_launch(gpu_lib, monkeypatch, B=1):
+    """One session, bf16 weights: the depth transformer's attention runs inside its out_proj (k_dep_attn_out_proj: the same
+    per-(session, head) function, the same operand values).  Tokens and text logits equal those of the two-launch form
+    (MMI_NO_DEP_ATTN_FUSION=1) bit for bit, at the 7B layer shapes; the audio tokens are what the depth transformer produced."""
+    cfg = LMConfig(num_layers=2, context=64)
+    sd = random_lm_state_dict(cfg, seed=13, device=DEV)
+    steps = 5
+    codes = torch.randint(0, cfg.card, (steps, B, 8, 1), generator=torch.Generator().manual_seed(4)).to(DEV)
+    of, tf = _greedy_run(cfg, sd, B, codes, steps)
+    monkeypatch.setenv("MMI_NO_DEP_ATTN_FUSION", "1")
+    ou, tu = _greedy_run(cfg, sd, B, codes, steps)
+    assert torch.equal(of, ou) and torch.equal(tf, tu)
+
+
 def test_rng_sampling_statistics(gpu_lib):
     lm_cases.rng_sampling_statistics(DEV, None)
 

@@ -64,6 +64,20 @@ def test_attention_ring_split_over_several_workgroups(sim_lib, monkeypatch, kern
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=61, B=2, S=9)
 
 
+def test_depformer_attention_inside_out_proj_for_one_session(sim_lib, monkeypatch):
+    """One session, bf16 weights: the depth transformer's attention of micro-steps >= 1 runs inside its out_proj
+    (k_dep_attn_out_proj; no dep.attn site in the launch list); MMI_NO_DEP_ATTN_FUSION=1 and more sessions keep the launch."""
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=73, B=1, S=5, stats=st)
+    assert "dep.attn" not in st["launch_sites"]
+    monkeypatch.setenv("MMI_NO_DEP_ATTN_FUSION", "1")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=73, B=1, S=5, stats=st)
+    assert st["launch_sites"]["dep.attn"] == 7 * 2
+    monkeypatch.delenv("MMI_NO_DEP_ATTN_FUSION")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=77, B=2, S=2, stats=st)
+    assert st["launch_sites"]["dep.attn"] == 7 * 2
+
+
 def test_split_k_gemm_with_fused_residual_norm(sim_lib, monkeypatch):
     """The K-split GEMM path (fp32 partials folded into the residual stream by k_resid_rmsnorm) that the 4096-wide
     layers take at 17..64 sessions, forced onto the tiny shapes."""
