@@ -13,6 +13,15 @@ def test_pipelined_frames_equal_the_serial_loop(gpu_lib, use_sampling):
     duplex_cases.check_pipeline_is_bit_identical(DEV, None, B=5, steps=24, use_sampling=use_sampling, join_every=6)
 
 
+def test_pipeline_crosses_the_attention_program_switch(gpu_lib, monkeypatch):
+    """Fewer than 32 sessions: the LM keeps two step programs (decode attention with / without its merge launch, lm_engine.hip
+    attn_variant) and moves from one to the other when its host-side bound on the ring depth passes the threshold - here after 5 of
+    24 frames, with the ring split forced onto the tiny model - inside the pipeline's two-graph form of the step (run_split)."""
+    monkeypatch.setenv("MMI_ATTN_NS", "3")
+    monkeypatch.setenv("MMI_ATTN_SOLO", "5")
+    duplex_cases.check_pipeline_is_bit_identical(DEV, None, B=5, steps=24, use_sampling=True, join_every=6)
+
+
 def test_decode_reads_a_column_slice_in_place(gpu_lib):
     duplex_cases.check_strided_decode(DEV, None)
 
