@@ -79,8 +79,8 @@ def build_asan(out_dir: Path) -> Path:
         ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 MMI_SIM_LIB=/tmp/asan/libmoshi_sim_asan.so \
         python -m pytest tests/test_mimi_sim.py tests/test_lm_sim.py tests/test_batcher_sim.py tests/test_duplex_sim.py -m "not gpu"
 
-    (round 3: 81 passed, no report; the one failure is test_io_threads_push_and_pop..., whose 60 s deadline the 5x slower
-    instrumented build misses)."""
+    (round 4: 101 passed, no report; the one failure is test_io_threads_push_and_pop..., whose 60 s deadline the 5x slower
+    instrumented build misses - as in round 3)."""
     out_dir.mkdir(parents=True, exist_ok=True)
     flags = [_cxx(), "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value", "-Wno-psabi",
              "-fsanitize=address", "-fno-omit-frame-pointer", f"-I{HERE}", f"-I{CSRC}"]
