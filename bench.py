@@ -56,6 +56,8 @@ def parse():
                          "(SURVEY.md 8d: C4 = 500 steps, sessions 8 frames apart -> ring depth 250 + 8 b; C3 = 300 steps -> depth 150), so "
                          "the measured step does not depend on --steps; start: sessions start at depth 8 b (rounds 1-3); "
                          "full: every ring full (depth = context, 3000)")
+    ap.add_argument("--kv-seek", type=int, default=-1,
+                    help="debug / tuning: move every session to this ring depth instead (overrides --kv-depth; not a named configuration)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra figures of the default line: `full_context` (every session 3000 positions deep) and `c3` (one session)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank's host thread to its own block of cores")
@@ -367,6 +369,8 @@ def main():
             base_depth = [lm_gen.lm_model.config.context] * B
         else:
             base_depth = [250 + args.stagger * b for b in range(B)] if B > 1 else [150]
+        if args.kv_seek >= 0:
+            base_depth = [args.kv_seek] * B
         lm_gen.seek(base_depth)
     trace("staggered")
     for _ in range(args.warmup):

@@ -719,18 +719,6 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
     });
 }
 
-// workgroups per (session, head) of the decode attention: 1 once B*H alone fills the chip, else split the ring
-int attn_splits(const mmi_lm_cfg& c, int B) {
-    if (const char* e = getenv("MMI_ATTN_NS")) {          // test hook: the split + combine path on rings too short to need it
-        const int v = atoi(e);
-        if (v >= 1 && v <= 16) return v;
-    }
-    const int chunks = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
-    int want = 1024 / (B * c.num_heads);
-    if (want < 1) want = 1;
-    return want < chunks ? want : chunks;
-}
-
 // MMI_ATTN: "wave" (default since round 4) = k_lm_attn_wave, one online softmax per wave, no barrier in the loop; "split" = the
 // chunked kernel of rounds 1-3 (same-box A/Bs)
 static bool attn_wave_kernel() {
@@ -738,12 +726,28 @@ static bool attn_wave_kernel() {
     return !(e && e[0] == 's');
 }
 
+// workgroups per (session, head) of the decode attention.  k_lm_attn_wave: ONE from 128 pairs (4 sessions) on - one workgroup per
+// pair walking the whole ring beats ring split + merge launch at every depth there (4 / 8 / 16 sessions, 3000 rows: -0.03 / -0.16 /
+// -0.16 ms per step, profiles/r04_logs/call_v_summary.txt); below that the ring is split (and still walked by one workgroup while
+// it is short: attn_solo_rows).  The chunked kernel of rounds 1-3: 1 once B*H alone fills the chip.
+int attn_splits(const mmi_lm_cfg& c, int B) {
+    if (const char* e = getenv("MMI_ATTN_NS")) {          // test hook: the split + combine path on rings too short to need it
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) return v;
+    }
+    if (attn_wave_kernel() && B * c.num_heads >= 128) return 1;
+    const int chunks = mmi_cdiv(c.context, MMI_ATTN_CHUNK);
+    int want = 1024 / (B * c.num_heads);
+    if (want < 1) want = 1;
+    return want < chunks ? want : chunks;
+}
+
 // k_lm_attn_wave, ring split over several workgroups: up to this many rows, workgroup 0 walks the ring alone and writes the output
-// itself (one wave covers 16 rows per iteration: 768 rows = 12 iterations, about what the release + arrival + acquire of the
-// merge costs).  MMI_ATTN_SOLO: test hook (0 = always merge, so the tiny models reach that path)
-static int attn_solo_rows() {
+// itself.  Measured crossover against split + merge launch (profiles/r04_logs/call_u_summary.txt, call_v_summary.txt): one session
+// between 600 and 900 rows, two sessions between 600 and 1800.  MMI_ATTN_SOLO: test hook (0 = always the merge launch)
+static int attn_solo_rows(int pairs) {
     if (const char* e = getenv("MMI_ATTN_SOLO")) return atoi(e);
-    return 768;
+    return pairs <= 32 ? 768 : 1200;
 }
 
 // The ring split over NS > 1 workgroups (fewer than 32 sessions) has two step programs (MmiProgram::variant):
@@ -756,7 +760,7 @@ static int attn_solo_rows() {
 static int attn_variant(const mmi_lm* lm, int NS) {
     if (NS <= 1 || !attn_wave_kernel()) return 0;
     if (const char* e = getenv("MMI_ATTN_MERGE")) if (e[0] == 'k') return 0;
-    return lm->depth_bound + 1 > (long)attn_solo_rows() ? 1 : 0;
+    return lm->depth_bound + 1 > (long)attn_solo_rows(lm->batch * lm->cfg.num_heads) ? 1 : 0;
 }
 
 int launch_attn_split(hipStream_t s, const LmAttnArgs& a, bool kv8) {
@@ -852,7 +856,7 @@ int build_program(mmi_lm* lm) {
         a.offsets = lm->offsets_m; a.opart = lm->opart; a.ml = lm->ml; a.out = lm->att;
         a.B = B; a.H = H; a.Dh = Dh; a.cap = c.context; a.context = c.context; a.NS = NS; a.max_period = c.max_period;
         a.T = lm->T; a.out_ksteps = packed_ksteps(lm, d);
-        a.done = lm->attn_done; a.solo_rows = attn_solo_rows();
+        a.done = lm->attn_done; a.solo_rows = attn_solo_rows(B * H);
         P.site("L.in_proj");
         {   // in_proj with RoPE + ring-KV write in its epilogue
             GemmArgs ga;
