@@ -461,7 +461,9 @@ def main():
                    "kv_depth": ({"mid": "sessions moved (mmi_lm_seek) to the midpoint of the configuration's run before the warm-up: ring depth "
                                         "250 + 8 b of SURVEY 8d C4's 500-step run (150 for the single session of C3); skipped ring rows hold zeros",
                                  "start": "sessions start at depth 8 b (the stagger alone; rounds 1-3)",
-                                 "full": "every session moved (mmi_lm_seek) to position `context`: all 3000 slots of every ring are read"}[args.kv_depth] if lm_gen is not None else None),
+                                 "full": "every session moved (mmi_lm_seek) to position `context`: all 3000 slots of every ring are read"}[args.kv_depth]
+                                if lm_gen is not None and args.kv_seek < 0 else
+                                (f"--kv-seek {args.kv_seek}: every session moved to that ring depth (tuning run, not a named configuration)" if lm_gen is not None else None)),
                    "kv_positions_at_start": ([base_depth[0], base_depth[-1]] if lm_gen is not None else None),
                    "kv_positions_at_end": ([base_depth[b] + args.warmup + args.steps for b in (0, B - 1)] if lm_gen is not None else None)},
     }
