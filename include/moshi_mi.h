@@ -310,6 +310,30 @@ int mmi_lm_force_next_tokens(mmi_lm* lm, const int64_t* tokens, mmi_stream strea
 int mmi_lm_set_hidden_taps(mmi_lm* lm, int32_t on);
 int mmi_lm_get_hidden_taps(mmi_lm* lm, void* buf_bf16, int64_t nbytes, mmi_stream stream);
 
+/* Parity tap (test aid; no reference counterpart - it is `F.linear(x, weight)` / `QLinear.forward(x)` of ONE module,
+ * utils/quantize.py:24-40, on rows the caller supplies): runs the linear stored under the state-dict key `weight_name`
+ * ("transformer.layers.0.gating.linear_in.weight", "depformer.layers.2.self_attn.out_projs.5.weight", "linears.3.weight", ...)
+ * through the kernels the step uses for it and returns its bf16 output, so that a test can hold the engine's int8 x int8
+ * arithmetic to the oracle BIT FOR BIT, per linear, instead of through the logits of a whole network.
+ *   x         device bf16 [rows][in_features], row-major; rows <= max_batch
+ *   out       device bf16 [rows][out_features]; a gated linear_in returns [rows][hidden] = silu(gate) * value, what the step hands on
+ *   path      MMI_DBG_PLAIN       (int8 x int8 models: k_quant_rows_i8, then) the weight-streaming GEMM as planned for the
+ *                                 shape and batch (k_gemm_xp / k_gemm_xlds), store epilogue
+ *             MMI_DBG_SPLITK      the same operand through the split-K form + the fold of the next norm launch
+ *                                 (out = bf16(sum of the partials)); MMI_ERR_UNSUPPORTED if the engine does not split this GEMM
+ *             MMI_DBG_FUSED       k_gemm_q8: the row quantisation inside the GEMM (int8 x int8 models, rows of <= 88 entries)
+ *             MMI_DBG_NORM        RMSNorm with the vector stored under `alpha_name` first, as the step's norm launch does it
+ *                                 (k_resid_rmsnorm + its int8 copy), then the GEMM; norm_out (optional, bf16 [rows][in_features])
+ *                                 receives the normalised rows
+ *             MMI_DBG_NORM_FUSED  the norm inside the GEMM (k_gemm_xp_norm / k_gemm_q8<NORM>; rows of <= 1024 features)
+ *   codes, absmax (optional; int8 x int8 models, paths PLAIN / SPLITK / NORM): int8 [rows][in_features] and fp32 [rows] - the
+ *             row-wise quantisation the GEMM consumed (bitsandbytes' CA / SCA)
+ * Does not touch a running stream's state (own scratch); synchronises `stream`. */
+enum { MMI_DBG_PLAIN = 0, MMI_DBG_SPLITK = 1, MMI_DBG_FUSED = 2, MMI_DBG_NORM = 3, MMI_DBG_NORM_FUSED = 4 };
+int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const char* alpha_name_or_null, int32_t path, const void* x_bf16,
+                        int32_t rows, void* out_bf16, int8_t* codes_or_null, float* absmax_or_null, void* norm_out_or_null,
+                        mmi_stream stream);
+
 /* The launch list of one frame step, recorded while the step ran for the first time: one line "site<TAB>kernel[<TAB>weight bytes]" per kernel
  * launch in launch order (sites: "L.in_proj", "L.ffn_in", "dep.out_proj", "text_linear", ...).  scripts/rocpd_sites.py joins
  * it with a rocprofv3 kernel trace by position inside the step, which is how per-site durations of kernels that share one

@@ -144,6 +144,7 @@ SIGNATURES = {
     "mmi_batcher_step": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "mmi_batcher_pop": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]),
     "mmi_batcher_get_stats": (C.c_int, [_P, C.POINTER(BatcherStats)]),
+    "mmi_lm_debug_linear": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "mmi_lm_launch_list": (C.c_int64, [_P, _P, C.c_int64]),
     "mmi_mimi_launch_list": (C.c_int64, [_P, C.c_int32, _P, C.c_int64]),
     "mmi_lm_seek": (C.c_int, [_P, _P, _P]),

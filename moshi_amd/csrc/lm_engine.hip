@@ -6,6 +6,7 @@
 #include "mmi_graph.h"
 
 #include <math.h>
+#include <map>
 
 namespace {
 
@@ -13,6 +14,7 @@ struct GemmW {              // one packed nn.Linear
     u32x4* wp = nullptr;
     int N = 0, K = 0, NT = 0, KSTEPS = 0, gate = 0;   // gate: N = hidden, gate/value rows interleaved per tile
     float* scale = nullptr;   // int8 weights: SCB / 127 per original weight row; fp8: weight_scale * input_scale; KSTEPS then counts k-step PAIRS
+    float* scb = nullptr;     // int8 weights: the raw SCB (`weight_scb`), for the int8 x int8 dequantisation (mmi_i8_dequant)
     int wq = 0;               // 0 bf16, 1 int8, 2 fp8
     float xinv = 1.f;         // fp8: 1 / input_scale
     size_t bytes = 0;
@@ -56,6 +58,9 @@ struct mmi_lm {
     bool dep_in_grouped = false;
     std::vector<uint16_t*> dep_emb; // [0] = depformer_text_emb, [k>=1] = depformer_emb[k-1]
     std::vector<DepLayerW> dep_layers;
+    // parity tap (mmi_lm_debug_linear): every packed linear / every norm vector by its state-dict key
+    std::map<std::string, GemmW> linear_by_name;
+    std::map<std::string, const uint16_t*> vector_by_name;
     int* delays_dev = nullptr;
     size_t weight_bytes = 0;
     // streaming state
@@ -160,7 +165,7 @@ __global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict_
 
 // wp_dst / scale_dst: pack into a slice of a caller-owned allocation instead of a fresh one (see load_dep_in_group)
 int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g,
-                void* wp_dst = nullptr, float* scale_dst = nullptr) {
+                void* wp_dst = nullptr, float* scale_dst = nullptr, float* scb_dst = nullptr) {
     const mmi_tensor_desc* d = W.find(name);
     if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
     if (d->dtype != MMI_BF16 && d->dtype != MMI_I8 && d->dtype != MMI_F8E4M3)
@@ -213,6 +218,11 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
         g->wp = reinterpret_cast<u32x4*>(p);
         g->scale = scale_dst;
         if (!g->scale) MMI_HIP_CHECK(lm->wts.alloc(&g->scale, (size_t)N));
+        if (q8 == 1) {
+            g->scb = scb_dst;
+            if (!g->scb) MMI_HIP_CHECK(lm->wts.alloc(&g->scb, (size_t)N));
+            MMI_HIP_CHECK(hipMemcpy(g->scb, sc->data, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice));
+        }
         g->bytes = n + (size_t)N * sizeof(float);
         MMI_LAUNCH(k_pack_w_i8, (int)mmi_cdiv64((int64_t)n, 256), 256, 0, (hipStream_t)0, (const int8_t*)d->data, p, N, K, TN,
                    g->NT, g->KSTEPS, gate_hidden);
@@ -220,6 +230,7 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
                    q8 == 1 ? 1.f : in_scale, q8 == 1 ? 127.f : 1.f);
     }
     lm->weight_bytes += g->bytes;
+    lm->linear_by_name[name] = *g;
     MMI_CHECK_LAUNCH();
     return MMI_OK;
 }
@@ -235,6 +246,7 @@ int load_copy(mmi_lm* lm, const MmiWeights& W, const std::string& name, int ndim
     if (!dst) MMI_HIP_CHECK(lm->wts.alloc(&dst, n));
     MMI_HIP_CHECK(hipMemcpy(dst, d->data, n * sizeof(uint16_t), hipMemcpyDeviceToDevice));
     if (out) *out = dst;
+    lm->vector_by_name[name] = dst;
     return MMI_OK;
 }
 
@@ -406,7 +418,7 @@ int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
 
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
-    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = (g.wq == 1 && a.wq >= 3) ? a.wq : g.wq;             // int8 linears: 3 / 4 = int8 activations (set by the program builder)
     a.xinv = g.xinv;
     const int mt = mmi_cdiv(a.B, lm->T);
@@ -508,13 +520,17 @@ void add_dep_attn_out_proj(mmi_lm* lm, const GemmW& g, const DepAttnArgs& da, ui
     }, bytes);
 }
 
-// K-split GEMM whose fp32 partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
-// Returns the number of partials, 0 when the GEMM is not split (then it applied the residual itself, in place on x).
-int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features, const Q8* q8 = nullptr) {
+// The split-K partials a norm launch still has to fold into the residual stream: P of them; int8 x int8 GEMMs leave int32 sums
+// and the norm dequantises (sx = the absmax of the GEMM's input rows, scb = its SCB; k_resid_rmsnorm psx / pscb)
+struct Pending { int P = 0; const float* sx = nullptr; const float* scb = nullptr; };
+
+// K-split GEMM whose partial sums (lm->partial) the following add_resid_rmsnorm folds into the residual stream.
+// Returns the partials, P = 0 when the GEMM is not split (then it applied the residual itself, in place on x).
+Pending add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, int features, const Q8* q8 = nullptr) {
     const GemmPlan p = plan_gemm(g, true);
     if (p.ksplit <= 1) {
         add_gemm(lm, g, in, x, features, true, MMI_EPI_RESID, x, nullptr, nullptr, 0, false, nullptr, q8);
-        return 0;
+        return Pending{};
     }
     GemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -522,18 +538,23 @@ int add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t* x, 
     a.xp = reinterpret_cast<const u32x4*>(in); a.epi = MMI_EPI_PARTIAL; a.partial = lm->partial; a.B = lm->batch;
     GemmW gw = g;
     lm->prog.add([lm, gw, a](hipStream_t s) { return launch_gemm(lm, s, gw, a, false); }, (long)g.bytes);
-    return p.ksplit;
+    Pending pd;
+    pd.P = p.ksplit;
+    if (q8 && q8->wq == 3 && g.wq == 1) { pd.sx = q8->sx; pd.scb = g.scb; }
+    return pd;
 }
 
 // x (+= the P pending split-K partials), y = rms_norm(x) * alpha
 // yq / sx: also store the row quantised row-wise to int8 (+ its absmax) for the int8 linears that read it (lm->act8)
-void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, int P, const uint16_t* alpha, uint16_t* y, int D, uint8_t* yq = nullptr, float* sx = nullptr) {
+void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, Pending pd, const uint16_t* alpha, uint16_t* y, int D, uint8_t* yq = nullptr, float* sx = nullptr) {
     const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, D);
     const float* partial = lm->partial;
+    const int P = pd.P;
+    const float *psx = pd.sx, *pscb = pd.scb;
     lm->prog.add([=](hipStream_t s) {
         int nth = mmi_cdiv(D / 8, 64) * 64;            // one 16-byte piece per thread where the row allows it
         if (nth > 1024) nth = 1024;
-        MMI_LAUNCH(k_resid_rmsnorm, B, nth, 0, s, x, partial, P, B, alpha, y, D, T, ksteps, 1e-8f, yq, sx);
+        MMI_LAUNCH(k_resid_rmsnorm, B, nth, 0, s, x, partial, P, B, alpha, y, D, T, ksteps, 1e-8f, yq, sx, psx, pscb);
         MMI_CHECK_LAUNCH();
         return (int)MMI_OK;
     });
@@ -552,6 +573,58 @@ void add_hidden_tap(mmi_lm* lm, int which) {
     });
 }
 
+// RMSNorm fused in front of a short-row GEMM (k_gemm_xp_norm; int8 x int8: k_gemm_q8<NORM>): the launch by tile / batch tiles / weight format
+int launch_norm_fused(hipStream_t s, int T, int mt, int wq, int NT, const GemmArgs& a) {
+    if (wq == 1) {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
+    } else if (wq == 3) {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, true>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, true>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, true>), NT, 512, 0, s, a);
+    } else if (wq == 2) {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 2>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 2>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 2>), NT, 512, 0, s, a);
+    } else {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
+        // 16-row tile: rows of <= 32 k-steps (the depth transformer's 1024 features) need 4 fragments per wave, not 8: the
+        // smaller register arrays let two workgroups share a CU, so the 352 gated tiles of linear_in are resident at once
+        // instead of running as 256 + 96 (same k partition per wave: bit-identical)
+        else if (a.KSTEPS <= 32) MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
+    }
+    MMI_CHECK_LAUNCH();
+    return (int)MMI_OK;
+}
+
+// k_gemm_q8 without a norm: the row quantisation inside the GEMM (kmax = 4: rows of <= 32 entries, 11: <= 88)
+int launch_q8_fused(hipStream_t s, int T, int mt, int kmax, int NT, const GemmArgs& a) {
+    if (kmax == 4) {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, false>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, false>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, false>), NT, 512, 0, s, a);
+    } else {
+        if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 11, false>), NT, 512, 0, s, a);
+        else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 11, false>), NT, 512, 0, s, a);
+        else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 11, false>), NT, 512, 0, s, a);
+    }
+    MMI_CHECK_LAUNCH();
+    return (int)MMI_OK;
+}
+static int q8_fused_kmax(const GemmW& g) { return g.KSTEPS <= 32 ? 4 : (g.KSTEPS <= 88 ? 11 : 0); }
+static int q8_fused_osplit(const GemmW& g, int epi, int T) {
+    int os = 1;
+    if (epi != MMI_EPI_GATE && !getenv("MMI_GEMM_OSPLIT")) {
+        const int octs = T / 8;
+        while (os < octs && (long)g.NT * os < 128) os *= 2;
+        if (g.NT > 64) os = 1;
+    }
+    return os;
+}
+
 // RMSNorm(x) * alpha fused into the GEMM (k_gemm_xp_norm) when a workgroup's 8 waves can hold the whole row slice in
 // registers (rows of <= 1024 features at the 32-wide tile: the depth transformer); otherwise norm kernel + GEMM.
 // lm->act8: the normalised row is quantised inside the GEMM (k_gemm_q8, fused) or by the norm launch
@@ -562,12 +635,12 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         if (a8) {
-            add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn);
+            add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn);
             Q8 q{3, lm->sx_dxn};
             add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->dxnq), out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv, &q);
             return;
         }
-        add_resid_rmsnorm(lm, x, 0, alpha, xn_scratch, D);
+        add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D);
         add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv);
         return;
     }
@@ -580,36 +653,14 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.out_ksteps = packed_ksteps(lm, out_features);
     a.alpha = alpha; a.D = D; a.eps = 1e-8f;
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
-    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = wq; a.xinv = g.xinv;
     a.osplit = 1;
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
         mmi_record_bytes(gbytes);
-        if (wq == 1) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 1>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 1>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
-        } else if (wq == 3) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, true>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, true>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, true>), NT, 512, 0, s, a);
-        } else if (wq == 2) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 4, 2>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 4, 2>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 2>), NT, 512, 0, s, a);
-        } else {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_xp_norm<32, 1, 8, 8>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_xp_norm<32, 2, 8, 8>), NT, 512, 0, s, a);
-            // 16-row tile: rows of <= 32 k-steps (the depth transformer's 1024 features) need 4 fragments per wave, not 8: the
-            // smaller register arrays let two workgroups share a CU, so the 352 gated tiles of linear_in are resident at once
-            // instead of running as 256 + 96 (same k partition per wave: bit-identical)
-            else if (a.KSTEPS <= 32) MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
-        }
-        MMI_CHECK_LAUNCH();
-        return (int)MMI_OK;
+        return launch_norm_fused(s, T, mt, wq, NT, a);
     }, gbytes);
 }
 
@@ -631,7 +682,7 @@ void add_quant_rows(mmi_lm* lm, const uint16_t* xp, uint8_t* xq, float* sx, int 
 void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features, uint16_t* out, int out_features, bool out_packed, int epi,
                  const uint16_t* resid) {
     const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T);
-    const int kmax = g.KSTEPS <= 32 ? 4 : (g.KSTEPS <= 88 ? 11 : 0);
+    const int kmax = q8_fused_kmax(g);
     if (!kmax || getenv("MMI_NO_NORM_FUSION")) {
         add_quant_rows(lm, x, lm->hbq, lm->sx_hb, in_features);
         Q8 q{3, lm->sx_hb};
@@ -645,31 +696,16 @@ void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features,
     a.out_ld = out_features;
     a.out_ksteps = packed_ksteps(lm, out_features);
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
-    a.wscale = g.scale; a.gate_rows = g.gate ? g.N : 0;
+    a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = 3; a.xinv = g.xinv;
     // few n-tiles (the N = 1024 linears: 32 tiles for 256 CUs): share a tile's row octets out over several workgroups, as
     // plan_osplit does for the bf16 form of these GEMMs
-    a.osplit = 1;
-    if (epi != MMI_EPI_GATE && !getenv("MMI_GEMM_OSPLIT")) {
-        const int octs = T / 8;
-        while (a.osplit < octs && (long)g.NT * a.osplit < 128) a.osplit *= 2;
-        if (g.NT > 64) a.osplit = 1;
-    }
+    a.osplit = q8_fused_osplit(g, epi, T);
     const int NT = g.NT * a.osplit;
     const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
         mmi_record_bytes(gbytes);
-        if (kmax == 4) {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, false>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, false>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, false>), NT, 512, 0, s, a);
-        } else {
-            if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 11, false>), NT, 512, 0, s, a);
-            else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 11, false>), NT, 512, 0, s, a);
-            else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 11, false>), NT, 512, 0, s, a);
-        }
-        MMI_CHECK_LAUNCH();
-        return (int)MMI_OK;
+        return launch_q8_fused(s, T, mt, kmax, NT, a);
     }, gbytes);
 }
 
@@ -845,7 +881,7 @@ int build_program(mmi_lm* lm) {
     lm->attn_ns = NS;
     const bool kv8 = c.kv_cache_dtype == MMI_F8E4M3;
     const size_t kv_layer = (size_t)B * H * c.context * Dh / (kv8 ? 2 : 1);     // in uint16 units: an fp8 ring is half as large
-    int pending = 0;   // split-K partials of the previous linear_out still to be folded into x
+    Pending pending;   // split-K partials of the previous linear_out still to be folded into x
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& L = lm->layers[l];
         P.site("L.norm1");
@@ -889,7 +925,7 @@ int build_program(mmi_lm* lm) {
         if (c.cross_attention) {   // x = x + cross_attention(norm_cross(x), src, src) (transformer.py:779-786)
             P.site("L.norm_cross");
             {
-                const int T = lm->T, ksteps = packed_ksteps(lm, d), Pn = pending;
+                const int T = lm->T, ksteps = packed_ksteps(lm, d), Pn = pending.P;
                 uint16_t *x = lm->x, *y = lm->xn; const float* partial = lm->partial;
                 const uint16_t *w = L.nx_w, *bb = L.nx_b;
                 P.add([=](hipStream_t s) {
@@ -1183,7 +1219,7 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
         // dep_q * depformer_dim output features ahead of the micro-step loop (build_program).  Needs whole n-tiles per step.
         const bool group = c.dep_q > 0 && dd % lm->T == 0 && !getenv("MMI_NO_DEP_IN_GROUP");
         uint8_t* wp_all = nullptr;
-        float* scale_all = nullptr;
+        float *scale_all = nullptr, *scb_all = nullptr;
         size_t per = 0;
         if (group) {
             const int NT = dd / lm->T, ksteps = mmi_cdiv(d, mmi_kstep(lm->T));
@@ -1191,10 +1227,13 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
             if (lm->wts.alloc(&wp_all, per * c.dep_q) != hipSuccess) return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in)"));
             if (lm->q8 >= 1 && lm->wts.alloc(&scale_all, (size_t)dd * c.dep_q) != hipSuccess)
                 return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in scales)"));
+            if (lm->q8 == 1 && lm->wts.alloc(&scb_all, (size_t)dd * c.dep_q) != hipSuccess)
+                return fail(mmi_fail(MMI_ERR_HIP, "out of device memory (depformer_in scales)"));
         }
         for (int k = 0; k < c.dep_q; ++k) {
             if ((rc = load_linear(lm, W, "depformer_in." + std::to_string(k) + ".weight", dd, d, 0, &lm->dep_in[k],
-                                  group ? wp_all + per * k : nullptr, scale_all ? scale_all + (size_t)dd * k : nullptr)))
+                                  group ? wp_all + per * k : nullptr, scale_all ? scale_all + (size_t)dd * k : nullptr,
+                                  scb_all ? scb_all + (size_t)dd * k : nullptr)))
                 return fail(rc);
         }
         for (int k = 1; group && k < c.dep_q; ++k)
@@ -1385,6 +1424,14 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
         struct { uint16_t* p; int f; } pk[] = {{lm->x, d}, {lm->xn, d}, {lm->att, d}, {lm->hb, c.ffn_hidden}, {lm->tout, d},
                                                {lm->dx, dd}, {lm->dxn, dd}, {lm->datt, dd}, {lm->dhb, c.depformer_ffn_hidden}};
         for (auto& e : pk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, packed_elems(lm, e.f) * sizeof(uint16_t), s));
+    }
+    if (lm->act8) {   // the int8 operands: like their bf16 twins, padding rows / k-steps are never written and must read as zero
+        const size_t mtiles = (size_t)mmi_cdiv(B, lm->T), rows = mtiles * lm->T;
+        auto qbytes = [&](int features) { return mtiles * (size_t)(packed_ksteps(lm, features) / 2) * 1024; };
+        struct { uint8_t* p; int f; } qk[] = {{lm->xnq, d}, {lm->attq, d}, {lm->hbq, c.ffn_hidden > c.depformer_ffn_hidden ? c.ffn_hidden : c.depformer_ffn_hidden},
+                                              {lm->toutq, d}, {lm->dxnq, dd > 0 ? dd : 8}};
+        for (auto& e : qk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, qbytes(e.f), s));
+        for (float* p : {lm->sx_xn, lm->sx_tout, lm->sx_dxn, lm->sx_att, lm->sx_hb}) MMI_HIP_CHECK(hipMemsetAsync(p, 0, rows * sizeof(float), s));
     }
     MMI_HIP_CHECK(hipMemsetAsync(lm->text_tok, 0, G * sizeof(int), s));
     MMI_HIP_CHECK(hipMemsetAsync(lm->audio_tok, 0, (size_t)G * c.dep_q * sizeof(int), s));
@@ -1638,6 +1685,124 @@ extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream
     if (lm->offsets_m != lm->offsets) MMI_HIP_CHECK(hipMemcpy(lm->offsets_m, off.data(), (size_t)lm->batch * sizeof(long), hipMemcpyHostToDevice));
     lm->offset_cpu = mx;
     lm->depth_bound = mx;
+    return MMI_OK;
+}
+
+// Parity tap: ONE linear of the model on caller-supplied rows, through the kernels the step uses for it (include/moshi_mi.h).
+// Works on its own scratch (a streaming session is not disturbed) and synchronises.
+extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const char* alpha_name, int32_t path, const void* x_bf16,
+                                   int32_t rows, void* out_bf16, int8_t* codes, float* absmax, void* norm_out, mmi_stream stream) {
+    MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
+    if (!lm || !weight_name || !x_bf16 || !out_bf16) return mmi_fail(MMI_ERR_INVALID, "null argument");
+    if (rows <= 0 || rows > lm->max_batch) return mmi_fail(MMI_ERR_SHAPE, "mmi_lm_debug_linear: rows must be 1..max_batch");
+    auto it = lm->linear_by_name.find(weight_name);
+    if (it == lm->linear_by_name.end()) return mmi_fail(MMI_ERR_MISSING_WEIGHT, std::string("no packed linear named ") + weight_name);
+    const GemmW g = it->second;
+    const uint16_t* alpha = nullptr;
+    const bool normed = path == MMI_DBG_NORM || path == MMI_DBG_NORM_FUSED;
+    if (normed) {
+        auto ia = alpha_name ? lm->vector_by_name.find(alpha_name) : lm->vector_by_name.end();
+        if (ia == lm->vector_by_name.end()) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "mmi_lm_debug_linear: the norm's alpha vector was not found");
+        alpha = ia->second;
+    }
+    const char* e8 = getenv("MMI_Q8_ACT");
+    const bool a8 = lm->q8 == 1 && !lm->cfg.cross_attention && !(e8 && e8[0] == 'b');
+    if ((codes || absmax) && !(a8 && (path == MMI_DBG_PLAIN || path == MMI_DBG_SPLITK || path == MMI_DBG_NORM)))
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_lm_debug_linear: codes / absmax exist on the int8 x int8 paths that materialise the operand (plain, split-K, norm)");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = lm->T, mt = mmi_cdiv(rows, T), KS = mmi_kstep(T);
+    const int K = g.K, N = g.N, kin = packed_ksteps(lm, K), kout = packed_ksteps(lm, N);
+    const int nthK = [&] { int n = mmi_cdiv(K / 8, 64) * 64; return n > 1024 ? 1024 : n; }();
+    MmiArena A;
+    uint16_t *xp = nullptr, *yp = nullptr, *xres = nullptr, *zeros = nullptr, *outp = (uint16_t*)out_bf16;
+    uint8_t* xq = nullptr;
+    float *sx = nullptr, *partial = nullptr;
+    const size_t xelems = (size_t)mt * kin * 512, oelems = (size_t)mt * kout * 512;
+    bool ok = true;
+    ok &= hipSuccess == A.alloc(&xp, xelems);
+    ok &= hipSuccess == A.alloc(&yp, xelems);
+    ok &= hipSuccess == A.alloc(&xq, (size_t)mt * (kin / 2 + 1) * 1024);
+    ok &= hipSuccess == A.alloc(&sx, (size_t)mt * T);
+    ok &= hipSuccess == A.alloc(&xres, oelems);
+    ok &= hipSuccess == A.alloc(&zeros, (size_t)N + 8);
+    ok &= hipSuccess == A.alloc(&partial, (size_t)4 * rows * N);
+    auto done = [&](int rc) { hipStreamSynchronize(s); A.release(); return rc; };
+    if (!ok) return done(mmi_fail(MMI_ERR_HIP, "out of device memory (mmi_lm_debug_linear)"));
+    MMI_HIP_CHECK(hipMemsetAsync(xp, 0, xelems * 2, s));
+    MMI_HIP_CHECK(hipMemsetAsync(yp, 0, xelems * 2, s));
+    MMI_HIP_CHECK(hipMemsetAsync(xq, 0, (size_t)mt * (kin / 2 + 1) * 1024, s));
+    MMI_HIP_CHECK(hipMemsetAsync(sx, 0, (size_t)mt * T * sizeof(float), s));
+    MMI_HIP_CHECK(hipMemsetAsync(xres, 0, oelems * 2, s));
+    MMI_HIP_CHECK(hipMemsetAsync(zeros, 0, ((size_t)N + 8) * 2, s));
+    MMI_LAUNCH(k_pack_rows, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint16_t*)x_bf16, rows, K, xp, T, kin);
+    MMI_CHECK_LAUNCH();
+    const uint16_t* operand = xp;              // the packed bf16 rows the GEMM (or its quantiser) reads
+    const bool gated = g.gate != 0;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = outp; a.epi = gated ? MMI_EPI_GATE : MMI_EPI_STORE; a.B = rows; a.tok_rows = rows;
+    a.out_mode = MMI_OUT_ROWMAJOR; a.out_ld = N; a.out_ksteps = kout;
+    int rc = MMI_OK;
+    if (path == MMI_DBG_NORM) {                // the norm launch of the step: y (+ its int8 copy) = rms_norm(x) * alpha
+        MMI_LAUNCH(k_resid_rmsnorm, rows, nthK, 0, s, xp, (const float*)nullptr, 0, rows, alpha, yp, K, T, kin, 1e-8f,
+                   a8 ? xq : (uint8_t*)nullptr, a8 ? sx : (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        MMI_CHECK_LAUNCH();
+        operand = yp;
+        if (norm_out) MMI_LAUNCH(k_unpack_rows, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint16_t*)yp, rows, K, (uint16_t*)norm_out, T, kin);
+    } else if (a8 && (path == MMI_DBG_PLAIN || path == MMI_DBG_SPLITK)) {
+        MMI_LAUNCH(k_quant_rows_i8, rows, nthK, 0, s, (const uint16_t*)xp, rows, K, T, kin, xq, sx);
+        MMI_CHECK_LAUNCH();
+    }
+    if (path == MMI_DBG_PLAIN || path == MMI_DBG_NORM || path == MMI_DBG_SPLITK) {
+        a.xp = reinterpret_cast<const u32x4*>(operand);
+        if (a8) { a.xp = reinterpret_cast<const u32x4*>(xq); a.sx = sx; a.wq = 3; }
+        Pending pd;
+        if (path == MMI_DBG_SPLITK) {
+            const GemmPlan p = plan_gemm(g, true);
+            if (gated || p.ksplit <= 1) return done(mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_lm_debug_linear: the engine does not split this GEMM over K"));
+            a.epi = MMI_EPI_PARTIAL; a.partial = partial; a.out = nullptr;
+            pd.P = p.ksplit;
+            if (a8) { pd.sx = sx; pd.scb = g.scb; }
+        }
+        rc = launch_gemm(lm, s, g, a, false);
+        if (rc) return done(rc);
+        if (path == MMI_DBG_SPLITK) {          // the fold of the next norm launch: x (= 0) + bf16(sum of the partials)
+            const int nthN = [&] { int n = mmi_cdiv(N / 8, 64) * 64; return n > 1024 ? 1024 : n; }();
+            if (N > 8 * 1024 * MMI_NORM_MAXP) return done(mmi_fail(MMI_ERR_UNSUPPORTED, "row too long for the norm kernel"));
+            uint16_t* ytmp = nullptr;
+            if (A.alloc(&ytmp, oelems) != hipSuccess) return done(mmi_fail(MMI_ERR_HIP, "out of device memory"));
+            MMI_LAUNCH(k_resid_rmsnorm, rows, nthN, 0, s, xres, (const float*)partial, pd.P, rows, (const uint16_t*)zeros, ytmp, N, T, kout, 1e-8f,
+                       (uint8_t*)nullptr, (float*)nullptr, pd.sx, pd.scb);
+            MMI_LAUNCH(k_unpack_rows, mmi_cdiv(rows * N, 256), 256, 0, s, (const uint16_t*)xres, rows, N, outp, T, kout);
+            MMI_CHECK_LAUNCH();
+        }
+    } else if (path == MMI_DBG_FUSED) {
+        const int kmax = q8_fused_kmax(g);
+        if (!a8 || !kmax) return done(mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_lm_debug_linear: k_gemm_q8 needs an int8 x int8 model and rows of <= 88 entries"));
+        a.xp = reinterpret_cast<const u32x4*>(xp);
+        a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT; a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = gated ? g.N : 0;
+        a.wq = 3; a.xinv = g.xinv;
+        a.osplit = q8_fused_osplit(g, a.epi, T);
+        rc = launch_q8_fused(s, T, mt, kmax, g.NT * a.osplit, a);
+        if (rc) return done(rc);
+    } else if (path == MMI_DBG_NORM_FUSED) {
+        const int wq = (a8 && g.wq == 1) ? 3 : g.wq;
+        if (g.KSTEPS > (wq ? 32 : 64)) return done(mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_lm_debug_linear: the row is too long for the norm-fused GEMM"));
+        a.xp = reinterpret_cast<const u32x4*>(xp);
+        a.alpha = alpha; a.D = K; a.eps = 1e-8f;
+        a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT; a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = gated ? g.N : 0;
+        a.wq = wq; a.xinv = g.xinv; a.osplit = 1;
+        rc = launch_norm_fused(s, T, mt, wq, g.NT, a);
+        if (rc) return done(rc);
+    } else {
+        return done(mmi_fail(MMI_ERR_INVALID, "mmi_lm_debug_linear: unknown path"));
+    }
+    if (codes) MMI_LAUNCH(k_unpack_q8, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint8_t*)xq, rows, K, codes, T, kin);
+    if (absmax) MMI_HIP_CHECK(hipMemcpyAsync(absmax, sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MMI_CHECK_LAUNCH();
+    (void)KS;
+    if (hipStreamSynchronize(s) != hipSuccess) { A.release(); return mmi_fail(MMI_ERR_HIP, "mmi_lm_debug_linear: the launches failed"); }
+    A.release();
     return MMI_OK;
 }
 

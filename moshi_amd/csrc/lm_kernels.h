@@ -162,6 +162,12 @@ __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     return r;
 }
 __device__ __forceinline__ float mmi_i8_scale(float sca) { return sca > 0.f ? 127.0f / sca : 0.f; }
+// bitsandbytes' int8_mm_dequant: `out32 * (row_stats * col_stats) * (1 / 127^2)` evaluated left to right in fp32 - the
+// expression of its "default" backend (restated in oracle/lm_oracle.py linear_int8); the engine's int8 x int8 linears are
+// bit-identical to that restatement for the same bf16 input row (tests: *_int8_linear_bit_exact_*)
+__device__ __forceinline__ float mmi_i8_dequant(int out32, float sca, float scb) {
+    return ((float)out32 * (sca * scb)) * (1.0f / (127.0f * 127.0f));
+}
 
 // ------------------------------------------------------------------------------------------------
 // weight-streaming skinny GEMM
@@ -188,6 +194,8 @@ struct GemmArgs {
     int out_mode, out_ld, out_ksteps;
     int epi;
     const float* wscale;    // int8 / fp8 weights: dequantisation factor per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
+    const float* wscb;      // int8 weights: the raw row absmax SCB (`weight_scb`), read by the int8 x int8 dequantisation
+                            // out32 * (SCA[b] * SCB[n]) * (1 / 127^2) - bitsandbytes' int8_mm_dequant expression, in its order
     float xinv;             // fp8: 1 / input_scale, applied to the activations before the e4m3 conversion
     int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights, 3 int8 weights x int8 activations
     const float* sx;        // WQ = 3 with pre-quantised activations: xp holds int8 entries Xq[mt][kp][lane][16] (k_quant_rows_i8 / the
@@ -280,6 +288,7 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 
     // ---- epilogue: one task = 8 consecutive output features of one session
     const bool gate = a.epi == MMI_EPI_GATE;
+    const bool iacc = a.sx || sx_local;              // int8 x int8: accv holds int32 bit patterns
     const int rows_out = gate ? TN / 2 : TN;         // output features per tile
     const int G = rows_out / 8;                      // feature groups per tile
     const int ntasks = NTW * MT * G * TN;
@@ -308,6 +317,51 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
         float s[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; s2[e] = 0.f; }
+        if (iacc) {
+            // int8 x int8: the waves' accumulators are int32 bit patterns; their sum is the EXACT out32 of bitsandbytes'
+            // int8_linear_matmul, converted to fp32 once (round to nearest even, like `out32 * float_tensor` in torch)
+            int si[8], si2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { si[e] = 0; si2[e] = 0; }
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(rb + w * NE + off_lo);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(rb + w * NE + off_hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { si[e] += lo[e]; si[4 + e] += hi[e]; }
+            }
+            if (gate) {
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(rb + w * NE + off2_lo);
+                    const i32x4 hi = *reinterpret_cast<const i32x4*>(rb + w * NE + off2_hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { si2[e] += lo[e]; si2[4 + e] += hi[e]; }
+                }
+            }
+            if (a.epi == MMI_EPI_PARTIAL) {      // split-K: the consumer (k_resid_rmsnorm) adds the integer partials, then dequantises
+                int* pd = reinterpret_cast<int*>(a.partial) + ((long)blockIdx.y * a.B + b) * a.N + n0;
+                *reinterpret_cast<i32x4*>(pd) = i32x4{si[0], si[1], si[2], si[3]};
+                *reinterpret_cast<i32x4*>(pd + 4) = i32x4{si[4], si[5], si[6], si[7]};
+                continue;
+            }
+            // int8_mm_dequant: out32 * (SCA[b] * SCB[n]) * (1 / 127^2), fp32, in that order
+            const float sca = sx_local ? sx_local[m * TN + bl] : a.sx[b];      // sx_local: the kernel's own row absmax (LDS)
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.wscb + n0), c1 = *reinterpret_cast<const f32x4*>(a.wscb + n0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] = mmi_i8_dequant(si[e], sca, c0[e]);
+                s[4 + e] = mmi_i8_dequant(si[4 + e], sca, c1[e]);
+            }
+            if (gate) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.wscb + a.gate_rows + n0), g1 = *reinterpret_cast<const f32x4*>(a.wscb + a.gate_rows + n0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s2[e] = mmi_i8_dequant(si2[e], sca, g0[e]);
+                    s2[4 + e] = mmi_i8_dequant(si2[4 + e], sca, g1[e]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(rb + w * NE + off_lo);
@@ -324,7 +378,8 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
                 for (int e = 0; e < 4; ++e) { s2[e] += lo[e]; s2[4 + e] += hi[e]; }
             }
         }
-        if (a.wscale) {   // int8 weights: y = (sum_k q x) * SCB / 127, per original weight row
+        }
+        if (a.wscale && !iacc) {   // int8 weights, bf16 activations: y = (sum_k q x) * SCB / 127, per original weight row
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.wscale + n0), c1 = *reinterpret_cast<const f32x4*>(a.wscale + n0 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] *= c0[e]; s[4 + e] *= c1[e]; }
@@ -333,11 +388,6 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s2[e] *= g0[e]; s2[4 + e] *= g1[e]; }
             }
-        }
-        if (a.sx || sx_local) {       // int8 activations: x ~= q * SCA / 127 (bitsandbytes' int8_mm_dequant: out32 * SCA * SCB / 127^2)
-            const float sa = (sx_local ? sx_local[m * TN + bl] : a.sx[b]) * (1.0f / 127.0f);     // sx_local: the kernel's own row absmax (LDS)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] *= sa; s2[e] *= sa; }
         }
         if (a.epi == MMI_EPI_PARTIAL) {
             float* pd = a.partial + ((long)blockIdx.y * a.B + b) * a.N + n0;
@@ -591,8 +641,7 @@ __global__ __launch_bounds__(WAVES * 64, (TN == 16 && MT == 1 && NTW == 1 && WQ 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if constexpr (WQ == 3) accv[t][m][r] = (float)__builtin_bit_cast(iacc_t, acc[t][m])[r];   // the wave's int32 sum
-                else accv[t][m][r] = acc[t][m][r];
+                accv[t][m][r] = acc[t][m][r];      // WQ == 3: the wave's int32 sum, as its bit pattern (summed as integers by the epilogue)
             }
     mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
@@ -734,6 +783,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
     // batch tiles handled together: both while a lane's fragments of both fit its registers (short rows), else one after the other
     constexpr int MG = (MT * XMAX <= 16) ? MT : 1;
     typedef int iacc_t __attribute__((ext_vector_type(R)));
+    typedef float facc_t __attribute__((ext_vector_type(R)));
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     // octet sharing as in k_gemm_xp (a.osplit > 1): N = 1024 linears have 32 n-tiles for 256 CUs; a workgroup = (tile, part) owns
     // TN / 8 / osplit of the tile's 8-row groups, the lanes of the other groups repeat an owned lane's weight address
@@ -859,7 +909,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < R; ++r) accv[0][m][r] = (float)acc[m][r];
+        for (int r = 0; r < R; ++r) accv[0][m][r] = __builtin_bit_cast(facc_t, acc[m])[r];     // int32 bit patterns (see the epilogue)
     mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi, sxl);
 }
 
@@ -1032,10 +1082,7 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (WQ == 3) accv[0][m][r] = (float)__builtin_bit_cast(i32x16, acc[t][m])[r];
-                    else accv[0][m][r] = acc[t][m][r];
-                }
+                for (int r = 0; r < 16; ++r) accv[0][m][r] = acc[t][m][r];     // WQ == 3: int32 bit patterns (see the epilogue)
             mmi_gemm_epilogue<32, MT, 1, 8, true>(a, accv, wave, lane, t0 + t, u32x4{0u, 0u, 0u, 0u}, red, oct_lo(t), oct_hi(t));
         }
     }
@@ -1055,7 +1102,10 @@ __global__ __launch_bounds__(512) void k_gemm_xlds(GemmArgs a) {
 __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x, const float* __restrict__ partial, int P,
                                                         int B, const uint16_t* __restrict__ alpha, uint16_t* __restrict__ y,
                                                         int D, int T, int ksteps, float eps, uint8_t* __restrict__ yq = nullptr,
-                                                        float* __restrict__ sx = nullptr) {
+                                                        float* __restrict__ sx = nullptr, const float* __restrict__ psx = nullptr,
+                                                        const float* __restrict__ pscb = nullptr) {
+    // psx / pscb != null: the pending GEMM was int8 x int8 - its partials are int32 sums (the exact out32 once added), and the
+    // dequantisation out32 * (SCA[b] * SCB[n]) / 127^2 happens here (psx = the absmax of that GEMM's input rows, pscb = its SCB)
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float f[MMI_NORM_MAXP][8];
     u32x4 al[MMI_NORM_MAXP];
@@ -1083,11 +1133,29 @@ __global__ __launch_bounds__(1024) void k_resid_rmsnorm(uint16_t* __restrict__ x
                 plo[p] = *reinterpret_cast<const f32x4*>(pp);
                 phi[p] = *reinterpret_cast<const f32x4*>(pp + 4);
             }
+            if (psx) {
+                int si[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) si[e] = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (p < P) {
+                        const i32x4 ilo = __builtin_bit_cast(i32x4, plo[p]), ihi = __builtin_bit_cast(i32x4, phi[p]);   // (whole vectors:
+#pragma unroll                                                                                                      // an element-wise
+                        for (int e = 0; e < 4; ++e) { si[e] += ilo[e]; si[4 + e] += ihi[e]; }                            // bit_cast is not)
+                    }
+                }
+                const float sca = psx[b];
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(pscb + i), c1 = *reinterpret_cast<const f32x4*>(pscb + i + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u[e] = mmi_i8_dequant(si[e], sca, c0[e]); u[4 + e] = mmi_i8_dequant(si[4 + e], sca, c1[e]); }
+            } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float on = p < P ? 1.f : 0.f;                // exact: x*1 = x, finite x*0 = 0
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { u[e] += plo[p][e] * on; u[4 + e] += phi[p][e] * on; }
+            }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[j][e] = mmi_round_bf16(mmi_round_bf16(u[e]) + f[j][e]);
@@ -1272,6 +1340,18 @@ __global__ void k_pack_rows(const uint16_t* __restrict__ src, int n, int D, uint
 }
 
 // packed activation operand -> row-major rows [B][D] (the parity tap of the residual stream, mmi_lm_set_hidden_taps)
+// parity tap: the int8 operand Xq[mt][kp][lane][16] (k_quant_rows_i8 / the norm kernel) -> row-major codes [B][D]
+__global__ void k_unpack_q8(const uint8_t* __restrict__ xq, int B, int D, int8_t* __restrict__ dst, int T, int ksteps) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= B * D) return;
+    const int r = idx / D, k = idx - r * D;
+    const long at = mmi_xp_index(T, r, k, ksteps);
+    const long frag = at >> 9;
+    const int ln = (int)((at >> 3) & 63);
+    const long mt = frag / ksteps;
+    const int ks = (int)(frag - mt * ksteps);
+    dst[idx] = (int8_t)xq[((mt * (ksteps >> 1) + (ks >> 1)) * 64 + ln) * 16 + (ks & 1) * 8 + (at & 7)];
+}
 __global__ void k_unpack_rows(const uint16_t* __restrict__ xp, int B, int D, uint16_t* __restrict__ dst, int T, int ksteps) {
     const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (idx >= B * D) return;

@@ -4,6 +4,7 @@
 #include "../../include/moshi_mi.h"
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -86,6 +87,11 @@ struct MmiArena {
         if (nb == 0) nb = sizeof(T);
         hipError_t e = hipMalloc(&q, nb);
         if (e != hipSuccess) return e;
+        // MMI_DEBUG_POISON=1 (tests / scripts/gpu_check.sh): every allocation of a handle starts as 0xFF bytes (bf16 / fp32 NaNs,
+        // int -1) instead of whatever the allocator hands out, so that a read of state the engine never initialised shows up as
+        // a wrong result on every box, not only on the one whose memory happened to hold something else
+        static const bool poison = getenv("MMI_DEBUG_POISON") && getenv("MMI_DEBUG_POISON")[0] == '1';
+        if (poison && (e = hipMemset(q, 0xFF, nb)) != hipSuccess) { hipFree(q); return e; }
         ptrs.push_back(q);
         sizes.push_back(nb);
         bytes += nb;

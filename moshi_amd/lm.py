@@ -160,6 +160,57 @@ class LMModel:
         the last temporal layer (`LMGen.hidden_taps()`)."""
         self._lib.check(self._lib.mmi_lm_set_hidden_taps(self._handle, 1 if on else 0))
 
+    DEBUG_PATHS = {"plain": 0, "splitk": 1, "fused": 2, "norm": 3, "norm_fused": 4}
+
+    def debug_linear(self, weight_name: str, x: torch.Tensor, path: str = "plain", alpha_name: Optional[str] = None,
+                     want_codes: bool = False) -> dict:
+        """Parity tap (tests; `mmi_lm_debug_linear`): ONE linear of the model - the module stored under `weight_name`, i.e.
+        `F.linear` / `QLinear.forward` (utils/quantize.py:24-40) - on the bf16 rows `x` [rows, in_features], through the kernels
+        the step uses for it.  Returns {"out": bf16 [rows, out_features] (a gated linear_in: silu(gate) * value), and on request
+        "codes" int8 [rows, in_features] / "absmax" fp32 [rows] (the row-wise quantisation the int8 x int8 GEMM consumed),
+        "norm": the normalised rows (path "norm")}."""
+        lib = self._lib
+        x = x.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        rows, K = x.shape
+        w = weight_name.encode()
+        # out_features from the config-independent side: ask for a generous buffer, the engine writes [rows][N]
+        n_out = self._linear_out_features(weight_name)
+        out = torch.empty(rows, n_out, dtype=torch.bfloat16, device=self.device)
+        codes = torch.empty(rows, K, dtype=torch.int8, device=self.device) if want_codes else None
+        absmax = torch.empty(rows, dtype=torch.float32, device=self.device) if want_codes else None
+        norm = torch.empty(rows, K, dtype=torch.bfloat16, device=self.device) if path == "norm" else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        lib.check(lib.mmi_lm_debug_linear(self._handle, w, alpha_name.encode() if alpha_name else None, self.DEBUG_PATHS[path],
+                                          x.data_ptr(), rows, out.data_ptr(), ptr(codes), ptr(absmax), ptr(norm),
+                                          _capi.stream_ptr(self.device)))
+        res = {"out": out}
+        if want_codes:
+            res.update(codes=codes, absmax=absmax)
+        if norm is not None:
+            res["norm"] = norm
+        return res
+
+    def _linear_out_features(self, weight_name: str) -> int:
+        c = self.config
+        dd = c.depformer_dim
+        dep = weight_name.startswith("depformer.")
+        d = dd if dep else c.dim
+        if ".self_attn.in_projs." in weight_name:
+            return 3 * d
+        if ".self_attn.out_projs." in weight_name:
+            return d
+        if "linear_in" in weight_name:           # gated: the engine returns the hidden tensor
+            return c.depformer_ffn_hidden if dep else c.ffn_hidden
+        if "linear_out" in weight_name:
+            return d
+        if weight_name.startswith("text_linear"):
+            return c.text_card
+        if weight_name.startswith("depformer_in."):
+            return dd
+        if weight_name.startswith("linears."):
+            return c.card
+        raise KeyError(weight_name)
+
     # attributes callers read (SURVEY.md 8b)
     @property
     def dep_q(self) -> int:

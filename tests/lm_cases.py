@@ -35,14 +35,6 @@ def logits_close(a: np.ndarray, ref: np.ndarray, widen: float = 1.0) -> bool:
 GUIDED_WIDEN = 1.5
 
 
-# int8 x int8 linears (bitsandbytes' rule): every linear re-quantises its input row to 8 bits, a DISCONTINUOUS map - where the
-# engine's bf16 activation differs from the checker's by one rounding flip (summation order), an int8 code moves by one step
-# (0.4 % of the row's absmax) and the difference is carried through the remaining layers instead of averaging out.  Measured on
-# the simulator over seeds: most (row, site) pairs are bit-identical to the oracle (median error 0), the worst at 5.8 % max /
-# 1.9 % mean of max|logit| (tiny model, 34 sessions, seed 88; same figures through k_gemm_xp and k_gemm_xlds) -> tolerance x 1.75.
-INT8_ACT_WIDEN = 1.75
-
-
 def near_tie(ref_logits: np.ndarray, tok_a: int, tok_b: int, widen: float = 1.0) -> bool:
     """Two implementations may pick different tokens only where the reference logits nearly tie."""
     scale = float(np.abs(ref_logits).max()) + 1e-6
@@ -303,6 +295,8 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
 
 
 def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0, stats=None, int8_activations=True):
+    if quantize is True and int8_activations:      # int8 x int8 linears: per-linear bit equality + a statistical network gate (below)
+        return int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=use_masks, stats=stats)
     sd = random_lm_state_dict(cfg, seed=seed)
     if quantize == "fp8":   # e4m3fn linears on the fp8 MFMA (BASELINE configs[4]); engine and oracle get the same fp8 tensors
         from moshi_amd.weights import quantize_lm_state_dict_fp8
@@ -311,8 +305,8 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
         from moshi_amd.weights import quantize_lm_state_dict
         sd = quantize_lm_state_dict(sd)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
-    orc = LMOracle(sd, cfg, int8_activations=int8_activations)      # int8 linears: bitsandbytes' int8 x int8 rule, or weight-only
-    widen = INT8_ACT_WIDEN if (quantize is True and int8_activations) else 1.0
+    orc = LMOracle(sd, cfg, int8_activations=int8_activations)      # int8 linears here: weight-only (the int8 x int8 rule: above)
+    widen = 1.0
     orc.streaming(B)
     rng = np.random.default_rng(seed)
     with gen.streaming(B):
@@ -983,3 +977,181 @@ def check_full_multinomial(device, lib, steps=4, B=3, seed=77):
                 assert np.array_equal(out[:, 0], prev[0]) and np.array_equal(out[:, 1], prev[1][:, 0]), f"step {s}"
                 assert np.array_equal(out[:, 2:], audio[:, 1:]), f"step {s}"
             prev = (text, audio)
+
+
+# ---- C5, per linear, bit for bit ("the int8 GEMM is integer work") ------------------------------------------------
+# `QLinear.forward` (utils/quantize.py:24-40) of ONE module on the same bf16 rows, engine (`mmi_lm_debug_linear`: the kernels the
+# step uses) against the oracle's restatement of bitsandbytes' rule: the int8 codes, the row absmax and the bf16 output must be
+# IDENTICAL - row-wise quantisation, an exact int32 dot product and one fp32 expression `out32 * (SCA * SCB) * (1 / 127^2)` leave
+# no room for rounding-order differences.  Gated linears: the SiLU's exp is a transcendental (device expf vs numpy exp), so their
+# gated output is held to ">= 99.9 % of the elements identical, the others one bf16 ulp apart"; their integer part is the same
+# kernel code as the un-gated linears'.
+def _dyadic_rows(rng, B, K):
+    """Rows whose sum of squares is exact in fp32 in ANY summation order (entries +-2^-2 .. +-2^1): the RMSNorm in front of a
+    linear is then one well-defined function, and the norm-fused kernels can be held to bit equality too."""
+    mag = 2.0 ** rng.integers(-2, 2, (B, K)).astype(np.float32)
+    return (mag * rng.choice(np.array([-1.0, 1.0], np.float32), (B, K))).astype(np.float32)
+
+
+def _bf16_bits(a: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(a, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def int8_linears_bit_exact(device, lib, cfg, B, seed, report=None):
+    from moshi_amd.weights import quantize_lm_state_dict
+    from oracle.lm_oracle import QWeight, bf16r, int8_vectorwise_quant, linear_int8, rms_norm, silu
+    sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=seed))
+    lm = LMModel(sd, cfg, device=device, max_batch=B, lib=lib)
+    rng = np.random.default_rng(seed)
+    d, dd = cfg.dim, cfg.depformer_dim
+    k_last = cfg.dep_q - 1
+    # (weight key, the norm vector in front of it in the model or None, paths)
+    sites = [
+        ("transformer.layers.0.self_attn.in_projs.0.weight", "transformer.layers.0.norm1.alpha", ["plain", "norm"]),
+        ("transformer.layers.0.self_attn.out_projs.0.weight", None, ["plain", "splitk"]),
+        ("transformer.layers.0.gating.linear_in.weight", "transformer.layers.0.norm2.alpha", ["plain", "norm"]),
+        ("transformer.layers.0.gating.linear_out.weight", None, ["plain", "splitk"]),
+        ("text_linear.weight", "out_norm.alpha", ["plain", "norm"]),
+        ("depformer_in.1.weight", None, ["plain"]),
+        (f"depformer.layers.0.self_attn.in_projs.{k_last}.weight", "depformer.layers.0.norm1.alpha", ["plain", "norm", "norm_fused"]),
+        ("depformer.layers.1.self_attn.out_projs.0.weight", None, ["plain", "fused"]),
+        (f"depformer.layers.1.gating.{k_last}.linear_in.weight", "depformer.layers.1.norm2.alpha", ["plain", "norm", "norm_fused"]),
+        ("depformer.layers.0.gating.2.linear_out.weight", None, ["plain", "fused"]),
+        ("linears.3.weight", None, ["plain", "fused"]),
+    ]
+    checked = []
+    for key, alpha_key, paths in sites:
+        w = QWeight(sd[key].numpy(), sd[key + "_scb"].numpy())
+        w.act8 = True
+        K = w.q.shape[1]
+        gated = "linear_in" in key
+        alpha = None if alpha_key is None else bf16r(sd[alpha_key].float().numpy().reshape(-1))
+
+        def oracle_out(rows):
+            h = linear_int8(rows, w)
+            if not gated:
+                return h
+            H = h.shape[1] // 2
+            return bf16r(bf16r(silu(h[:, :H])) * h[:, H:])
+
+        for path in paths:
+            if path in ("norm", "norm_fused"):
+                x = _dyadic_rows(rng, B, K)
+            else:           # heavy-tailed rows, a zero row and a row whose absmax sits on one entry
+                x = bf16r((rng.standard_normal((B, K)) * np.exp(rng.standard_normal((B, 1)))).astype(np.float32))
+                x[B - 1] = 0.0
+                if B > 1:
+                    x[0, rng.integers(0, K)] = 37.0
+            xt = torch.from_numpy(x)
+            try:
+                res = lm.debug_linear(key, xt, path=path, alpha_name=alpha_key if path in ("norm", "norm_fused") else None,
+                                      want_codes=path in ("plain", "splitk", "norm"))
+            except NotImplementedError as e:
+                if path == "splitk" and "does not split" in str(e):     # tiny shapes are not split over K unless forced
+                    continue
+                raise
+            out = res["out"].float().cpu().numpy()
+            name = f"{key} [{path}] B={B}"
+            rows = x
+            if path == "norm":        # the engine's norm output must be the oracle's, and it is what the linear quantises
+                yn = res["norm"].float().cpu().numpy()
+                assert np.array_equal(_bf16_bits(yn), _bf16_bits(rms_norm(x, alpha))), f"{name}: RMSNorm output differs on exact-sum rows"
+                rows = yn
+            elif path == "norm_fused":
+                rows = rms_norm(x, alpha)
+            if "codes" in res:
+                ca, sca = int8_vectorwise_quant(rows)
+                assert np.array_equal(res["absmax"].cpu().numpy(), sca[:, 0]), f"{name}: row absmax differs"
+                assert np.array_equal(res["codes"].cpu().numpy().astype(np.int32), ca.astype(np.int32)), f"{name}: int8 codes differ"
+            ref = oracle_out(rows)
+            same = _bf16_bits(out) == _bf16_bits(ref)
+            if gated:
+                ulp = np.abs(out - ref) <= np.maximum(np.abs(ref), 1e-30) * 2.0 ** -7
+                assert same.mean() >= 0.999 and ulp.all(), f"{name}: gated output {same.mean():.5f} identical, worst {np.abs(out - ref).max()}"
+            else:
+                assert same.all(), f"{name}: {int((~same).sum())} of {same.size} bf16 outputs differ (first at {np.argwhere(~same)[0]})"
+            checked.append((name, float(same.mean())))
+    if report is not None:
+        report.extend(checked)
+    return checked
+
+
+# ---- C5 at network level: a statistical gate with a yardstick (VERDICT r4 item 1) ------------------------------------------------------
+# With every int8 linear bit-identical to the oracle for the same input rows (int8_linears_bit_exact), engine and oracle can
+# only part ways at the pieces that are NOT integer work - RMSNorm's mean of squares and rsqrt, the softmax of the attentions,
+# SiLU, RoPE - where summation order / the device's exp move a bf16 result by one rounding flip now and then.  Re-quantising
+# every activation row to 8 bits is a discontinuous map: most flips vanish (the int8 codes do not change: the (row, site) pair
+# is bit-identical to the oracle), a few are carried to the logits, and a flip of a row's absmax entry moves the whole row.  The
+# error per (row, site) is therefore heavy-tailed, and a threshold on its MAXIMUM over a few thousand pairs is a coin that
+# eventually lands wrong - it did, at the driver, in round 4.  The gate: (1) token-ring outputs exact under teacher forcing;
+# (2) the share of pairs inside the plain bf16 tolerance, the median and the 90th percentile of the error are no worse than
+# those of ANOTHER correct implementation of the same network (the oracle with its norm / softmax / SiLU statistics in fp64,
+# `LMOracle(stat64=True)`), with a margin; (3) no pair is grossly wrong (a broken kernel gives errors of order max|logit|).
+INT8_NET_GROSS_MAX, INT8_NET_GROSS_MEAN = 0.35, 0.10
+
+
+def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=None, stats=None):
+    from moshi_amd.weights import quantize_lm_state_dict
+    sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=seed))
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    orc, yard = LMOracle(sd, cfg), LMOracle(sd, cfg, stat64=True)
+    orc.streaming(B); yard.streaming(B)
+    rng = np.random.default_rng(seed)
+    eng, yd = [], []
+
+    def rel(a, ref):
+        sc = float(np.abs(ref).max()) + 1e-6
+        dlt = np.abs(a - ref)
+        return float(dlt.max()) / sc, float(dlt.mean()) / sc
+    with gen.streaming(B):
+        for s in range(S):
+            mask = np.ones(B, bool)
+            if use_masks and B > 1:
+                mask = rng.random(B) > 0.3
+                mask[0] = True
+                if s == S // 2:
+                    r = np.zeros(B, bool); r[B - 1] = True
+                    for o in (orc, yard):
+                        o.reset_streaming(r)
+                    gen.reset_streaming(torch.from_numpy(r).to(device))
+                    mask[B - 1] = True
+            for o in (orc, yard):
+                o.set_exec_mask(mask)
+            gen.set_exec_mask(torch.from_numpy(mask).to(device))
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            oo, (otl, oal, ott, oat) = orc.step(codes, use_sampling=False, support_out_of_sync=True)
+            forced = np.concatenate([ott[:, None], oat], 1)
+            _, (ytl, yal, _, _) = yard.step(codes, use_sampling=False, support_out_of_sync=True, forced=forced)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            for b in range(B):
+                if not mask[b]:
+                    continue
+                assert np.array_equal(out[b], oo[b]), f"step {s} row {b}: ring output differs"
+                eng.append(rel(tl[b], otl[b])); yd.append(rel(ytl[b], otl[b]))
+                for k in range(cfg.dep_q):
+                    eng.append(rel(al[b, k], oal[b, k])); yd.append(rel(yal[b, k], oal[b, k]))
+        if stats is not None:
+            import collections
+            stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
+            stats["launch_sites"] = dict(collections.Counter(site for site, _ in gen.launch_list()))
+    e, y = np.array(eng), np.array(yd)
+
+    def summ(v):
+        inside = (v[:, 0] <= LOGIT_MAX_REL) & (v[:, 1] <= LOGIT_MEAN_REL)
+        return {"pairs": int(len(v)), "identical": float((v[:, 0] == 0).mean()), "inside_bf16_tolerance": float(inside.mean()),
+                "max_rel_median": float(np.median(v[:, 0])), "max_rel_p90": float(np.quantile(v[:, 0], 0.9)),
+                "max_rel_p99": float(np.quantile(v[:, 0], 0.99)), "max_rel_worst": float(v[:, 0].max()),
+                "mean_rel_median": float(np.median(v[:, 1])), "mean_rel_p90": float(np.quantile(v[:, 1], 0.9)), "mean_rel_worst": float(v[:, 1].max())}
+    es, ys = summ(e), summ(y)
+    res = {"case": name or f"int8_network_b{B}", "engine_vs_oracle": es, "yardstick_fp64_statistics_vs_oracle": ys}
+    print(f"[parity] {res['case']}: engine {es}\n[parity] {res['case']}: yardstick {ys}")
+    out_dir = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out_dir.is_dir() and name:
+        import json
+        (out_dir / f"parity_{name}.json").write_text(json.dumps(res, indent=1))
+    assert es["inside_bf16_tolerance"] >= min(0.85, ys["inside_bf16_tolerance"] - 0.10), f"too few (row, site) pairs inside the bf16 tolerance: {es} vs yardstick {ys}"
+    for key, slack in (("max_rel_median", 0.005), ("max_rel_p90", 0.01), ("mean_rel_median", 0.002), ("mean_rel_p90", 0.004)):
+        assert es[key] <= 1.5 * ys[key] + slack, f"{key}: engine {es[key]:.4f} vs yardstick {ys[key]:.4f}"
+    assert es["max_rel_worst"] <= INT8_NET_GROSS_MAX and es["mean_rel_worst"] <= INT8_NET_GROSS_MEAN, f"a (row, site) pair is grossly wrong: {es}"
+    return res

@@ -192,6 +192,27 @@ def test_int8_activations_on_the_lds_resident_gemm(sim_lib, monkeypatch):
     assert st["xlds_launches"] >= 2 * (2 * 2 + 1)
 
 
+@pytest.mark.parametrize("B", [3, 18, 40])
+def test_int8_linear_bit_exact_per_linear_against_the_oracle(sim_lib, B):
+    """`QLinear.forward` of ONE module (utils/quantize.py:24-40) through the step's kernels
+    (`mmi_lm_debug_linear`) - int8 codes, row absmax and bf16 output IDENTICAL to the oracle's restatement, for every linear
+    family of the model (k_quant_rows_i8 + k_gemm_xp, the norm launch's int8 copy, k_gemm_q8 with and without the norm), at the
+    16-row tile, one and two batch tiles of the 32-row tile."""
+    checked = lm_cases.int8_linears_bit_exact("cpu", sim_lib, tiny_lm_config(), B, seed=500 + B)
+    assert len(checked) >= 20
+
+
+@pytest.mark.parametrize("B", [18, 40])
+def test_int8_linear_bit_exact_on_the_split_k_and_lds_resident_forms(sim_lib, monkeypatch, B):
+    """The same per-linear bit equality with the full-size plans forced onto the tiny shapes: the K-split GEMM whose int32
+    partials the norm launch adds and dequantises (out_proj / linear_out at the 7B widths), and k_gemm_xlds on int8 operands."""
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
+    monkeypatch.setenv("MMI_GEMM_LDS", "1")
+    monkeypatch.setenv("MMI_GEMM_LDS_GRID", "8")
+    checked = lm_cases.int8_linears_bit_exact("cpu", sim_lib, tiny_lm_config(), B, seed=520 + B)
+    assert any("[splitk]" in n for n, _ in checked)
+
+
 def test_bitsandbytes_rule_restated_known_answers():
     """The oracle's restatement of bitsandbytes' int8 rule on hand-computed cases: absmax scaling, round HALF TO EVEN, an
     all-zero row, exact integer accumulation beyond 2^24, the dequantisation constant."""
