@@ -451,7 +451,7 @@ def main():
                    "pipelined": dup is not None,
                    "schedule": ("three HIP streams (encoder / LM / decoder) + events: encode(t+1) and decode(t-1) run under LMGen.step(t); "
                                 "ms_per_step = steady-state interval between frames of the 32-session batch, p50/p95 = one frame alone, "
-                                "PCM in -> PCM out; outputs bit-identical to the serial loop (tests/test_duplex_gpu.py)") if dup is not None
+                                "PCM in -> PCM out; outputs bit-identical to the serial loop (tests/test_c_duplex_gpu.py)") if dup is not None
                                else "one stream: encode -> step -> decode back to back (server.py:132-146)",
                    "rvq": "exact fp64 argmin of ||x - e||^2 (equals the reference's fp32 cdist argmin except at fp32 near-ties: 16 of 131072 decisions, profiles/r02_logs/parity_rvq_indices_z.json)",
                    "mimi_dtype": "f32", "weights": "random-init (seeded), architecture of the named model" + {"none": "", "q8": ", LM linears row-wise int8", "fp8": ", LM linears row-wise e4m3"}[args.quant],

@@ -30,7 +30,7 @@ def broadcast_state_dict(state_dict: Optional[Dict[str, torch.Tensor]], spec: Sp
     without any metadata exchange.  Returns the full state dict on every rank (on `device`)."""
     import os
     import torch.distributed as dist
-    # MMI_FORCE_BCAST (test switch; tests/test_loaders_gpu.py): "1" = run the bucket pack + collective even when the job has one
+    # MMI_FORCE_BCAST (test switch; tests/test_c_loaders_gpu.py): "1" = run the bucket pack + collective even when the job has one
     # rank (so the device path executes on a 1-GPU box); "recv" = this rank also UNPACKS like a receiver (its result is the
     # views into the buckets, not its own tensors)
     force = os.environ.get("MMI_FORCE_BCAST", "")

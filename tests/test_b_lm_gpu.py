@@ -42,34 +42,6 @@ def test_tiny_matches_oracle_with_masks_and_reset(gpu_lib, B):
     lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=50 + B, B=B, S=16 if B <= 5 else 4)
 
 
-@pytest.mark.parametrize("B", [2, 18, 40])
-def test_int8_weights_match_the_int8_oracle(gpu_lib, B):
-    """C5's weight format (`quantize=True`: row-wise int8 + `weight_scb`) run the reference's way - int8 activations on
-    v_mfma_i32_{16x16x64,32x32x32}_i8, bitsandbytes' row-wise rule (utils/quantize.py:24-40, restated in oracle/lm_oracle.py;
-    unpinned against the library itself) - on the tiny model, all three batch tilings."""
-    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=80 + B, B=B, S=3, quantize=True)
-
-
-def test_int8_weight_only_mode_matches_its_oracle(gpu_lib, monkeypatch):
-    """MMI_Q8_ACT=bf16: the weight-only form of rounds 1-3 stays selectable (same-box A/Bs)."""
-    monkeypatch.setenv("MMI_Q8_ACT", "bf16")
-    lm_cases.oracle_vs_engine(DEV, None, tiny_lm_config(), seed=98, B=18, S=3, quantize=True, int8_activations=False)
-
-
-def test_int8_full_width_layers_match_oracle(gpu_lib):
-    """int8 linears at the 7B layer shapes (2 temporal layers, full depformer), B=3 with masks."""
-    cfg = LMConfig(num_layers=2, context=64)
-    lm_cases.oracle_vs_engine(DEV, None, cfg, seed=9, B=3, S=3, use_masks=True, quantize=True)
-
-
-@pytest.mark.parametrize("B,S", [(2, 15), (18, 4), (40, 3)])
-def test_fp8_kv_ring_matches_the_oracle(gpu_lib, B, S):
-    """`kv_cache_dtype="fp8"`: e4m3 keys / values in the ring (written by in_proj's epilogue, widened exactly by the decode
-    attention), bf16 weights, all three batch tilings; S > context: the ring wraps."""
-    from dataclasses import replace
-    lm_cases.oracle_vs_engine(DEV, None, replace(tiny_lm_config(), kv_cache_dtype="fp8"), seed=120 + B, B=B, S=S)
-
-
 @pytest.mark.parametrize("kv,path", [("bf16", "launch"), ("bf16", "solo"), ("bf16", "switch"), ("bf16", "kernel"), ("fp8", "switch")])
 def test_long_ring_split_over_workgroups_matches_oracle(gpu_lib, monkeypatch, kv, path):
     """A ring longer than one 256-slot chunk with few (session, head) pairs: the decode attention (k_lm_attn_wave) splits the
@@ -103,39 +75,6 @@ def test_long_ring_split_over_workgroups_matches_oracle(gpu_lib, monkeypatch, kv
             assert lm_cases.logits_close(tl[0].cpu().numpy(), otl[0]), f"step {s}: text logits"
             for k in range(cfg.dep_q):
                 assert lm_cases.logits_close(al[0, k].cpu().numpy(), oal[0, k]), f"step {s} cb {k}"
-
-
-def test_fp8_hardware_primitives_match_their_definition(gpu_lib, tmp_path):
-    """scripts/fp8_probe.hip on this GPU: v_cvt_pk_fp8_f32 bit-exact against the software e4m3 rounding the oracle uses
-    (every bf16 value + ties), subnormal inputs honoured by the fp8 MFMA, and its dot product within 5e-4 of exact (it is
-    NOT exact: small products are aligned to the group's largest - the figure tests/lm_cases.py FP8_HW_ACC_NOISE is taken from)."""
-    import re
-    import subprocess
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    exe = tmp_path / "fp8_probe"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", f"-I{root / 'moshi_amd' / 'csrc'}",
-                           str(root / "scripts" / "fp8_probe.hip"), "-o", str(exe)])
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, check=True).stdout
-    assert re.search(r"cvt: \d+ values, 0 mismatches", out), out
-    for shape in ("32x32x16", "16x16x32"):
-        err = float(re.search(rf"mfma {shape} fp8: worst \|err\| / sum\|products\| = ([0-9.e+-]+)", out).group(1))
-        assert err < 5e-4, out
-    got, want = map(float, re.search(r"subnormal A x 1.0: got ([0-9.e+-]+) expected ([0-9.e+-]+)", out).groups())
-    assert got == want, out
-
-
-@pytest.mark.parametrize("B,input_scale", [(2, 1.0), (18, 0.25), (40, 1.0)])
-def test_fp8_engine_is_within_the_conditioning_of_the_fp8_network(gpu_lib, B, input_scale):
-    """BASELINE configs[4]'s fp8 MFMA GEMMs (`quantize="fp8"`) on the tiny model, all three batch tilings: ring outputs exact;
-    logits as close to the exact-accumulation fp8 oracle as that oracle stays to itself under the hardware's measured
-    accumulate error, and as accurate against the bf16 model as the fp8 oracle (tests/lm_cases.py, "fp8 on hardware")."""
-    print(lm_cases.fp8_engine_within_format_conditioning(DEV, None, tiny_lm_config(), seed=90 + B, B=B, S=3, input_scale=input_scale))
-
-
-def test_fp8_full_width_within_the_conditioning_of_the_fp8_network(gpu_lib):
-    """The same at the 7B layer shapes (2 temporal layers, full depformer), B=3."""
-    print(lm_cases.fp8_engine_within_format_conditioning(DEV, None, LMConfig(num_layers=2, context=64), seed=10, B=3, S=2))
 
 
 @pytest.mark.parametrize("name", ["a", "b", "c", "d"])
@@ -216,16 +155,6 @@ def test_benchmark_kernels_match_the_reference_at_full_depth(gpu_lib):
     """The same golden run on a handle built for 32 sessions: the 32-row tile, k_gemm_xlds, the split-K temporal GEMMs - the
     kernels `bench.py` times - against the reference's own logits (a 2-session handle takes the 16-row tile)."""
     lm_cases.check_golden_full(DEV, None, max_batch=32, name="golden_full_cuda_tile32")
-
-
-def test_c5_shape_int8_linears_at_64_sessions_match_oracle(gpu_lib):
-    """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), row-wise int8 linears."""
-    lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, quantize=True)
-
-
-def test_c5_shape_fp8_linears_at_64_sessions_within_the_conditioning_of_the_fp8_network(gpu_lib):
-    """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), e4m3 linears on the fp8 MFMA."""
-    print(lm_cases.fp8_engine_within_format_conditioning(DEV, None, LMConfig(num_layers=2, context=64), seed=464, B=64, S=2))
 
 
 @pytest.mark.parametrize("B", [40, 64])

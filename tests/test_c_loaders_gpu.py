@@ -1,7 +1,7 @@
 """Checkpoint loading on the real device: a released-style directory (config.json + safetensors with the
 reference's keys) -> CheckpointInfo -> MimiModel / LMModel on cuda:0 through the product library, and the quantised exports
 through the same door.  The models built straight from the state dict are pinned on the oracle / the reference's golden vectors
-by test_lm_gpu.py and test_mimi_gpu.py; here the loaders must hand the engine exactly the same weights."""
+by test_b_lm_gpu.py and test_a_mimi_gpu.py; here the loaders must hand the engine exactly the same weights."""
 import json
 from dataclasses import replace
 

@@ -11,7 +11,7 @@ def test_pipelined_frames_equal_the_serial_loop(sim_lib, use_sampling):
 
 def test_pipeline_crosses_the_attention_program_switch(sim_lib, monkeypatch):
     """The LM's change of step program (decode attention with / without its merge launch) in the middle of a pipelined run, the
-    ring split forced onto the tiny model: same bits as the serial loop (the two-graph form of it: tests/test_duplex_gpu.py)."""
+    ring split forced onto the tiny model: same bits as the serial loop (the two-graph form of it: tests/test_c_duplex_gpu.py)."""
     monkeypatch.setenv("MMI_ATTN_NS", "3")
     monkeypatch.setenv("MMI_ATTN_SOLO", "5")
     duplex_cases.check_pipeline_is_bit_identical("cpu", sim_lib, use_sampling=True)

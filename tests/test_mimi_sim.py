@@ -138,6 +138,6 @@ def test_decode_takes_any_number_of_codebooks(sim_lib):
 
 def test_c2_recipe_on_the_tiny_codec(factory):
     """The C2 recipe (random exec masks, mid-run reset, rings wrapping many times over: context 6) on the simulator: the
-    same case the GPU suite runs at full size for 200 frames (tests/test_mimi_gpu.py)."""
+    same case the GPU suite runs at full size for 200 frames (tests/test_a_mimi_gpu.py)."""
     res = mimi_cases.check_c2_recipe(factory, "cpu", tiny_mimi_config(), B=4, F=14, K=5)
     assert res["wrapped"]
