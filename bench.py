@@ -99,6 +99,29 @@ def gather_per_rank(x, dist, dev, world):
     return [float(v[0]) for v in allr]
 
 
+def rank_report(rank, local, world, dist, dev):
+    """One line per rank on stderr, and the same facts gathered for the JSON line: which physical device the rank drives (PCI bus
+    id), what the weight broadcast at load moved and at what rate.  The first real N-GPU run is then self-diagnosing: N distinct
+    bus ids = N GPUs, `bcast_world` = the ranks RCCL saw, `bcast_gb_per_s` = the rate the weights crossed xGMI at."""
+    from moshi_amd.dist import BROADCAST_STATS as st
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        name = pr.name
+    except Exception:      # the gloo / CPU test configuration
+        bus, name = "n/a", "cpu"
+    mine = {"rank": rank, "local_rank": local, "device": name, "pci_bus_id": bus, "bcast_world": st["world"],
+            "bcast_gb": round(st["bytes"] / 1e9, 3), "bcast_s": round(st["seconds"], 3), "bcast_buckets": st["buckets"],
+            "bcast_gb_per_s": round(st["bytes"] / 1e9 / st["seconds"], 2) if st["seconds"] > 0 else None}
+    sys.stderr.write("bench.py rank %(rank)d/%(w)d: %(device)s at %(pci_bus_id)s; weight broadcast over %(bcast_world)d rank(s): "
+                     "%(bcast_gb).2f GB in %(bcast_s).2f s, %(bcast_buckets)d buckets -> %(bcast_gb_per_s)s GB/s\n" % {**mine, "w": world})
+    if dist is None:
+        return [mine]
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    return allr
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -270,6 +293,13 @@ def launchcheck_main(args, backend):
     ms_ranks = [1e3 * v / args.steps for v in gather_per_rank(dt_local, dist, dev, world)]
     first_core = gather_per_rank(-1 if not cores else cores[0], dist, dev, world)
     p50, p95, p50s, p95s = job_latency(5.0 + rank, 6.0 + rank, dist, dev, world)      # rank r pretends to be r ms slower
+    if dist is not None:      # the load-time collective on a small model, so that the per-rank report carries a broadcast
+        from moshi_amd.config import tiny_lm_config
+        from moshi_amd.dist import broadcast_state_dict
+        from moshi_amd.weights import lm_state_spec, random_lm_state_dict
+        tcfg = tiny_lm_config()
+        broadcast_state_dict(random_lm_state_dict(tcfg, seed=1) if rank == 0 else None, lm_state_spec(tcfg), torch.bfloat16, dev, src=0)
+    ranks_info = rank_report(rank, local, world, dist, dev)
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -277,7 +307,7 @@ def launchcheck_main(args, backend):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50s, "p95_ms_per_rank": p95s,
                           "ms_per_step_per_rank": ms_ranks, "host_first_core_per_rank": [int(c) for c in first_core],
-                          "backend": backend}), flush=True)
+                          "ranks": ranks_info, "backend": backend}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -318,6 +348,7 @@ def main():
     load_local = time.perf_counter() - t_load
     load_s = job_time(load_local, dist, dev)      # rank 0 draws, RCCL broadcasts in 1 GiB buckets, every rank packs
     load_ranks = gather_per_rank(load_local, dist, dev, world)
+    ranks_info = rank_report(rank, local, world, dist, dev)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
     user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)
@@ -438,7 +469,7 @@ def main():
         "metric": "12.5 Hz frames/s end-to-end Mimi+Moshi-7B" if workload == "duplex" else f"12.5 Hz frames/s ({workload} only)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "p50_ms_per_step": p50, "p95_ms_per_step": p95, "p50_ms_per_rank": p50_ranks, "p95_ms_per_rank": p95_ranks,
-        "ms_per_step_per_rank": ms_ranks, "load_s": load_s, "load_s_per_rank": load_ranks,
+        "ms_per_step_per_rank": ms_ranks, "load_s": load_s, "load_s_per_rank": load_ranks, "ranks": ranks_info,
         "host_affinity": {"cores_per_rank": None if not cores else len(cores), "first_core_per_rank": [int(c) for c in first_core],
                           "note": "each rank's main thread (the duplex pipeline's host-kept gate) and the HIP runtime threads it starts are "
                                   "confined to a disjoint block of cores; -1 = not pinned"},

@@ -573,6 +573,13 @@ void add_hidden_tap(mmi_lm* lm, int which) {
     });
 }
 
+// k_gemm_q8 at 33..64 sessions: one batch tile per workgroup (grid.y = tiles; the default) or both tiles walked by one workgroup
+// (MMI_Q8_TILES=serial: the round-4 form, same-box A/B)
+static bool q8_tiles_over_grid() {
+    const char* e = getenv("MMI_Q8_TILES");
+    return !(e && e[0] == 's');
+}
+
 // RMSNorm fused in front of a short-row GEMM (k_gemm_xp_norm; int8 x int8: k_gemm_q8<NORM>): the launch by tile / batch tiles / weight format
 int launch_norm_fused(hipStream_t s, int T, int mt, int wq, int NT, const GemmArgs& a) {
     if (wq == 1) {
@@ -581,6 +588,7 @@ int launch_norm_fused(hipStream_t s, int T, int mt, int wq, int NT, const GemmAr
         else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4, 1>), NT, 512, 0, s, a);
     } else if (wq == 3) {
         if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, true>), NT, 512, 0, s, a);
+        else if (T == 32 && q8_tiles_over_grid()) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, true>), dim3(NT, mt), 512, 0, s, a);
         else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, true>), NT, 512, 0, s, a);
         else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, true>), NT, 512, 0, s, a);
     } else if (wq == 2) {
@@ -604,10 +612,12 @@ int launch_norm_fused(hipStream_t s, int T, int mt, int wq, int NT, const GemmAr
 int launch_q8_fused(hipStream_t s, int T, int mt, int kmax, int NT, const GemmArgs& a) {
     if (kmax == 4) {
         if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, false>), NT, 512, 0, s, a);
+        else if (T == 32 && q8_tiles_over_grid()) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 4, false>), dim3(NT, mt), 512, 0, s, a);
         else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 4, false>), NT, 512, 0, s, a);
         else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 4, false>), NT, 512, 0, s, a);
     } else {
         if (T == 32 && mt == 1) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 11, false>), NT, 512, 0, s, a);
+        else if (T == 32 && q8_tiles_over_grid()) MMI_LAUNCH((k_gemm_q8<32, 1, 8, 11, false>), dim3(NT, mt), 512, 0, s, a);
         else if (T == 32) MMI_LAUNCH((k_gemm_q8<32, 2, 8, 11, false>), NT, 512, 0, s, a);
         else MMI_LAUNCH((k_gemm_q8<16, 1, 8, 11, false>), NT, 512, 0, s, a);
     }
@@ -1521,6 +1531,13 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
         });
     } else rc = lm->prog.run(s, lm->use_graph && !lm->profiling, lm->cap_stream);
     if (rc) return rc;
+    if (lm->attn_ns > 1 && lm->use_graph && !lm->profiling && !hooked && attn_wave_kernel() && !getenv("MMI_NO_PRECAPTURE")) {
+        // both attention programs exist from the stream's first step on: the switch at depth solo_rows is then a graph launch
+        // like any other (without this the deep program was captured + instantiated ~61 s into a live single-session stream)
+        const bool split = lm->phase_fn != nullptr;
+        for (int v = 0; v < MmiProgram::NV; ++v)
+            if (!lm->prog.ready(v, split) && (rc = lm->prog.precapture(v, lm->cap_stream, split, lm->op_depformer))) return rc;
+    }
     MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(B * (c.dep_q + 1), 256), 256, 0, s, (const int*)lm->out_i32, (long*)out_tokens, B * (c.dep_q + 1));
     if (opt_text_logits)
         MMI_LAUNCH(k_bf16_to_f32, (int)mmi_cdiv64((int64_t)B * c.text_card_out, 256), 256, 0, s, (const uint16_t*)lm->text_logits, opt_text_logits, (long)B * c.text_card_out);
@@ -1636,7 +1653,15 @@ extern "C" int mmi_lm_state_load(mmi_lm* lm, const void* src, int64_t bytes, int
     if (bytes != (int64_t)lm->st.bytes) return mmi_fail(MMI_ERR_SHAPE, "snapshot taken from a different stream (batch / guidance)");
     MMI_HIP_CHECK(lm->st.load(src, (hipStream_t)stream));
     lm->offset_cpu = (long)host_word;
-    lm->depth_bound = 1L << 40;        // the snapshot's offsets are not known here: take the program that is right at any depth
+    {   // the snapshot's offsets bound the ring depth (which step program the next steps take): read them back - a restore is not
+        // a per-frame call, and without this a shallow restored session paid the merge launch for the rest of the stream
+        std::vector<long> off(lm->batch);
+        MMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        MMI_HIP_CHECK(hipMemcpy(off.data(), lm->offsets_m, (size_t)lm->batch * sizeof(long), hipMemcpyDeviceToHost));
+        long mx = 0;
+        for (long o : off) mx = o > mx ? o : mx;
+        lm->depth_bound = mx;
+    }
     lm->forced_armed = false;
     lm->noise_on = true;               // the snapshot carries its own use_noise word: the next step rewrites it
     return MMI_OK;

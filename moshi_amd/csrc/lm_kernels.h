@@ -775,8 +775,26 @@ __global__ __launch_bounds__(WAVES * 64, (TN == 16 && KMAX == 4 && WQ == 0) ? 4 
 // bf16 tensor the linear quantises,) the block reduces the rows' absmax through LDS, every lane converts its own fragments
 // (round half even) and feeds v_mfma_i32_{32x32x32,16x16x64}_i8; the epilogue scales the int32 sums by SCA[b] * SCB[n] / 127^2.
 // a.KSTEPS counts weight entries (two bf16 k-steps each).
+// gridDim.y > 1 (MT == 1 only): ONE BATCH TILE PER WORKGROUP - blockIdx.y picks the tile, and the workgroup sees the GEMM of those
+// TN rows alone (operand, output, residual, frame-cache pointers moved to the tile; B = the rows it holds).  At 33..64 sessions the
+// MT = 2 form walks the two tiles one after the other through the same registers, three barriers each, on a latency-bound chain
+// (dep.ffn_out 19.5 us against 8.2 for the bf16 kernel at 32 sessions, profiles/r04_q8_b64_sites.csv); the weights are 3-6 MB per
+// linear and a tile's second reader finds them in its XCD's L2 (grid.x is a multiple of 8: both readers of an n-tile share an XCD).
+template <int TN>
+__device__ __forceinline__ void mmi_gemm_batch_tile_view(GemmArgs& a, int y, int x_frags_per_tile) {
+    const int r0 = y * TN;
+    a.xp += (long)y * x_frags_per_tile * 64;
+    const long oshift = a.out_mode == MMI_OUT_PACKED ? (long)y * a.out_ksteps * 512 : (long)r0 * a.out_ld;
+    if (a.out) a.out += oshift;
+    if (a.resid) a.resid += oshift;
+    if (a.kc) { a.kc += (long)r0 * a.H * a.cap * a.Dh; a.vc += (long)r0 * a.H * a.cap * a.Dh; }
+    a.B = min(TN, a.B - r0);
+}
+
 template <int TN, int MT, int WAVES, int KMAX, bool NORM>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a) {
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_q8(GemmArgs a_in) {
+    GemmArgs a = a_in;
+    if constexpr (MT == 1) { if (gridDim.y > 1) mmi_gemm_batch_tile_view<TN>(a, (int)blockIdx.y, a.KSTEPS * 2); }
     constexpr int R = TN == 32 ? 16 : 4;
     constexpr int KS = TN == 32 ? 16 : 32;
     constexpr int XMAX = 2 * KMAX;

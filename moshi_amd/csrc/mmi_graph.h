@@ -64,30 +64,58 @@ struct MmiProgram {
         return rc;
     }
 
+    // the CURRENT variant's whole list captured into graph[v] / exec[v] (nothing executes; the first capture also records the launch list)
+    int capture_full(hipStream_t capture_stream) {
+        const int v = variant;
+        if (exec[v]) return MMI_OK;
+        MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
+        int rc = run_eager(capture_stream);
+        hipError_t e = hipStreamEndCapture(capture_stream, &graph[v]);
+        if (rc || e != hipSuccess) {
+            if (e == hipSuccess && graph[v]) hipGraphDestroy(graph[v]);
+            graph[v] = nullptr;
+            if (rc) return rc;
+            return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&exec[v], graph[v], nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            hipGraphDestroy(graph[v]);
+            graph[v] = nullptr;
+            exec[v] = nullptr;
+            return mmi_fail(MMI_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        return MMI_OK;
+    }
+
     int run(hipStream_t s, bool use_graph, hipStream_t capture_stream) {
         if (!use_graph) return run_eager(s);
         const int v = variant;
         if (!exec[v]) {
-            MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
-            int rc = run_eager(capture_stream);
-            hipError_t e = hipStreamEndCapture(capture_stream, &graph[v]);
-            if (rc || e != hipSuccess) {
-                if (e == hipSuccess && graph[v]) hipGraphDestroy(graph[v]);
-                graph[v] = nullptr;
-                if (rc) return rc;
-                return mmi_fail(MMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            }
-            e = hipGraphInstantiate(&exec[v], graph[v], nullptr, nullptr, 0);
-            if (e != hipSuccess) {
-                hipGraphDestroy(graph[v]);
-                graph[v] = nullptr;
-                exec[v] = nullptr;
-                return mmi_fail(MMI_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-            }
+            int rc = capture_full(capture_stream);
+            if (rc) return rc;
         }
         MMI_HIP_CHECK(hipGraphLaunch(exec[v], s));
         return MMI_OK;
     }
+
+    // Variant v made ready AHEAD of the step that first needs it (a stream whose rings grow past the short-ring program
+    // would otherwise capture and instantiate the other program in the middle of a live session - a one-off latency spike in a
+    // real-time stream): its graph(s) captured and instantiated now, nothing launched.  split: the two-graph form run_split uses.
+    int precapture(int v, hipStream_t capture_stream, bool split, size_t cut) {
+        const int keep = variant;
+        variant = v;
+        int rc = MMI_OK;
+        if (!split || !logged_[v]) rc = capture_full(capture_stream);       // (also records the variant's launch list)
+        if (!rc && split && (!exec_a[v] || cut_[v] != cut)) {
+            drop_split(v);
+            if (!(rc = capture_range(capture_stream, 0, cut, &graph_a[v], &exec_a[v])) &&
+                !(rc = capture_range(capture_stream, cut, ops.size(), &graph_b[v], &exec_b[v])))
+                cut_[v] = cut;
+        }
+        variant = keep;
+        return rc;
+    }
+    bool ready(int v, bool split) const { return split ? (exec_a[v] && exec_b[v]) : exec[v] != nullptr; }
 
     int capture_range(hipStream_t capture_stream, size_t i0, size_t i1, hipGraph_t* g, hipGraphExec_t* e) {
         MMI_HIP_CHECK(hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));

@@ -14,6 +14,12 @@ import torch
 
 Spec = Sequence[Tuple[str, Tuple[int, ...], str]]
 
+# What the replication cost on THIS rank, accumulated over every broadcast_state_dict call of the process: bytes that went through
+# the collective, seconds inside it (device-synchronised around each bucket), buckets.  bench.py prints it per rank, next to the
+# rank's PCI bus id, so that the first real multi-GPU run says by itself whether RCCL saw N ranks and at what rate the weights
+# crossed xGMI.
+BROADCAST_STATS = {"bytes": 0, "seconds": 0.0, "buckets": 0, "world": 1}
+
 
 def _numel(shape) -> int:
     n = 1
@@ -62,7 +68,18 @@ def broadcast_state_dict(state_dict: Optional[Dict[str, torch.Tensor]], spec: Sp
                 n = _numel(shape)
                 flat[at:at + n].copy_(state_dict[name].reshape(-1).to(device=device, dtype=dtype))
                 at += n
+        import time
+        on_gpu = torch.device(device).type == "cuda"
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
         dist.broadcast(flat, src=src, group=group)
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        BROADCAST_STATS["seconds"] += time.perf_counter() - t0
+        BROADCAST_STATS["bytes"] += total * esize
+        BROADCAST_STATS["buckets"] += 1
+        BROADCAST_STATS["world"] = dist.get_world_size(group)
         at = 0
         for name, shape in items:
             n = _numel(shape)

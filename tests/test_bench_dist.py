@@ -95,6 +95,10 @@ def test_bench_spawns_its_own_ranks():
     assert out["ms_per_step_per_rank"] == [50.0, 75.0] and out["ms_per_step"] == 75.0
     cores = out["host_first_core_per_rank"]
     assert len(cores) == 2 and (cores[0] != cores[1] or len(os.sched_getaffinity(0)) < 2)
+    # every rank reports the device it drives and what the weight broadcast at load moved: a first real
+    # N-GPU run shows by itself that the collective saw N ranks, and at what rate
+    info = out["ranks"]
+    assert [r["rank"] for r in info] == [0, 1] and all(r["bcast_world"] == 2 and r["bcast_gb"] > 0 and r["bcast_buckets"] >= 1 for r in info)
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -439,3 +439,11 @@ def test_cross_attention_more_positions_than_slots(sim_lib):
     passes and the batched key / value projection at stream start."""
     from dataclasses import replace
     lm_cases.cross_vs_oracle("cpu", sim_lib, replace(tiny_lm_config(), cross_attention=True), B=18, S=2, Tc=41, seed=8)
+
+
+def test_int8_depformer_batch_tiles_walked_by_one_workgroup(sim_lib, monkeypatch):
+    """MMI_Q8_TILES=serial: k_gemm_q8<32, 2, ..> (both batch tiles through one workgroup's registers, the round-4 form kept for
+    same-box A/Bs) stays bit-identical to the oracle; the default at 33..64 sessions is one batch tile per workgroup (grid.y)."""
+    monkeypatch.setenv("MMI_Q8_TILES", "serial")
+    lm_cases.int8_linears_bit_exact("cpu", sim_lib, tiny_lm_config(), 40, seed=561)
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=562, B=40, S=2, quantize=True)
