@@ -240,8 +240,10 @@ int mmi_lm_streaming_batch(const mmi_lm* lm);
 int mmi_lm_device(const mmi_lm* lm);
 int mmi_mimi_device(const mmi_mimi* m);
 /* Engine counters for tests / diagnostics.  which = 0: GEMM launches (or captured graph nodes) that took the LDS-resident
- * kernel (k_gemm_xlds, enabled with MMI_GEMM_LDS=1). */
-int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which);   /* rows the model runs for the current stream: batch, or 2 * batch when guided */
+ * kernel (k_gemm_xlds); 1: bit v set = step program v (short-ring / deep-ring decode attention) is captured and instantiated -
+ * both are from the stream's first step on, so that the switch is never a capture inside a live session; 2: the host's bound on
+ * the ring depth (steps since streaming_start / seek / the offsets of a restored snapshot). */
+int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which);
 /* LMGen.step_with_extra_heads (lm.py:793-807): softmax(extra_head(transformer_out)) of the LAST step for every head:
  * probs f32 [model rows, extra_heads_num_heads, extra_heads_dim]. */
 int mmi_lm_extra_heads(mmi_lm* lm, float* probs, mmi_stream stream);

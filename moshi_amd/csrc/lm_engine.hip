@@ -1834,7 +1834,15 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
 extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
     if (!lm) return -1;
-    return which == 0 ? (int64_t)lm->xlds_launches : -1;
+    if (which == 0) return (int64_t)lm->xlds_launches;
+    if (which == 1) {       // bit v set: step program v (attn_variant) is captured and instantiated (either graph form)
+        int64_t m = 0;
+        for (int v = 0; v < MmiProgram::NV; ++v)
+            if (lm->prog.ready(v, false) || lm->prog.ready(v, true)) m |= 1ll << v;
+        return m;
+    }
+    if (which == 2) return (int64_t)lm->depth_bound;
+    return -1;
 }
 
 extern "C" int mmi_lm_profile_begin(mmi_lm* lm) {

@@ -247,3 +247,38 @@ def test_cross_attention_at_full_width_matches_oracle(gpu_lib, B, Tc):
     keys / values projected through the weight-streaming GEMM in batches) against the oracle, both batch tilings."""
     from dataclasses import replace
     lm_cases.cross_vs_oracle(DEV, None, replace(LMConfig(num_layers=2, context=64), cross_attention=True), B=B, S=2, Tc=Tc, seed=77 + B)
+
+
+def test_attention_program_switch_is_a_graph_launch_not_a_capture(gpu_lib, monkeypatch):
+    """with the ring split over workgroups (< 4 sessions) a stream moves from the short-ring step program to the
+    deep-ring one after ~768 steps.  Both programs are captured and instantiated at the stream's FIRST step (mmi_lm_stat 1 == 0b11),
+    so the step at the switch costs what its neighbours cost (host wall time with a synchronisation per step: no spike), and a
+    snapshot restored at a shallow depth goes back to the short-ring program (mmi_lm_stat 2 = the restored offsets' maximum)."""
+    import time
+    from dataclasses import replace
+    monkeypatch.setenv("MMI_ATTN_SOLO", "40")
+    cfg = replace(tiny_lm_config(), context=600)
+    sd = random_lm_state_dict(cfg, seed=45)
+    lm = LMModel(sd, cfg, device=DEV, max_batch=1)
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    rng = np.random.default_rng(45)
+    ms = []
+    with gen.streaming(1):
+        for s in range(80):
+            codes = torch.from_numpy(rng.integers(0, cfg.card, (1, 8, 1))).to(DEV)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gen.step(codes)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+            if s == 0:
+                assert gen._lib.mmi_lm_stat(lm._handle, 1) == 3, "both step programs must exist after the first step"
+            if s == 10:
+                snap = gen.get_streaming_state()
+        assert gen._lib.mmi_lm_stat(lm._handle, 2) >= 79
+        gen.set_streaming_state(snap)
+        assert gen._lib.mmi_lm_stat(lm._handle, 2) == 11       # the snapshot's offset, not "assume deep"
+    steady = float(np.median(ms[5:35]))
+    at_switch = max(ms[36:46])
+    print(f"[switch] steady step {steady:.3f} ms, worst step around the switch {at_switch:.3f} ms, first step {ms[0]:.1f} ms")
+    assert at_switch <= 3.0 * steady + 1.0, f"the step at the program switch is a latency spike: {at_switch:.3f} ms against {steady:.3f}"
