@@ -41,6 +41,23 @@ def near_tie(ref_logits: np.ndarray, tok_a: int, tok_b: int, widen: float = 1.0)
     return abs(float(ref_logits[tok_a]) - float(ref_logits[tok_b])) <= 2 * widen * LOGIT_MAX_REL * scale
 
 
+_SD_CACHE: "dict" = {}
+
+
+def cached_lm_state_dict(cfg, seed: int, keep: int = 2):
+    """`random_lm_state_dict(cfg, seed)` (the CPU draw the golden generators and every earlier measurement used), kept for the
+    next test that asks for the same (architecture, seed): drawing ~1 B parameters on the host is 10 s of each full-width test,
+    and the GPU suite has a time budget.  The tensors are shared: callers must not modify them."""
+    key = (repr(cfg), int(seed))
+    if key not in _SD_CACHE:
+        while len(_SD_CACHE) >= keep:
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
+        _SD_CACHE[key] = random_lm_state_dict(cfg, seed=seed)
+    else:
+        _SD_CACHE[key] = _SD_CACHE.pop(key)          # most recently used last
+    return dict(_SD_CACHE[key])
+
+
 def make_engine(cfg, sd, device, lib, max_batch, **gen_kwargs):
     lm = LMModel(sd, cfg, device=device, max_batch=max_batch, lib=lib)
     return LMGen(lm, **gen_kwargs)
@@ -153,14 +170,33 @@ def load_full():
     return g, LMConfig()
 
 
+_FULL_SD = {}
+
+
+def full_golden_state_dict(device):
+    """The 7.7 B parameters of tests/golden/lm_full.npz's model: drawn ONCE per process on the host (the generator's draw - the
+    CUDA RNG stream differs) and kept on the device for the three tests that read them (25 s of host RNG each otherwise)."""
+    g, cfg = load_full()
+    key = (int(g["seed"][0]), str(device))
+    if key not in _FULL_SD:
+        _FULL_SD.clear()
+        sd = random_lm_state_dict(cfg, seed=key[0])
+        if torch.device(device).type == "cuda":
+            sd = {k: v.to(device) for k, v in sd.items()}
+        _FULL_SD[key] = sd
+    return dict(_FULL_SD[key])
+
+
+def release_full_golden_state_dict():
+    _FULL_SD.clear()
+
+
 def check_golden_full(device, lib, max_batch=None, name=None):
     """The engine on the benchmark model (32 layers, context 3000) against the reference's own output, teacher-forced.
     max_batch: build the handle for that many sessions (> 16: the 32-row MFMA tile and k_gemm_xlds - the benchmark's kernels -
     instead of the 16-row tile a 2-session handle gets)."""
     g, cfg = load_full()
-    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))     # CPU draw, as in the generator (the CUDA RNG stream differs)
-    if torch.device(device).type == "cuda":
-        sd = {k: v.to(device) for k, v in sd.items()}
+    sd = full_golden_state_dict(device)
     B = g["codes"].shape[1]
     gen = make_engine(cfg, sd, device, lib, max_batch or B, use_sampling=False, support_out_of_sync=True)
     del sd
@@ -172,16 +208,17 @@ def check_golden_full(device, lib, max_batch=None, name=None):
                                 set_mask=lambda m: gen.set_exec_mask(torch.from_numpy(m).to(device)))
 
 
-def check_free_running(device, lib, g, cfg, widen, name, max_batch=None, on_cuda_weights=False):
+def check_free_running(device, lib, g, cfg, widen, name, max_batch=None, on_cuda_weights=False, sd=None):
     """NOT teacher-forced: the engine runs greedy on its own tokens through a golden run of the reference - what
     it samples at step s is what it reads at step s + 1.  Per row, the first (step, site) where its token differs from the
     reference's is reported, and it must be a near-tie of the REFERENCE's logits at that site (all inputs up to there were
     identical, so those logits are comparable); from there on the row is on another trajectory and is not compared (until a
     reset of that row puts it back on the reference's)."""
     import json
-    sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
-    if on_cuda_weights and torch.device(device).type == "cuda":
-        sd = {k: v.to(device) for k, v in sd.items()}
+    if sd is None:
+        sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))
+        if on_cuda_weights and torch.device(device).type == "cuda":
+            sd = {k: v.to(device) for k, v in sd.items()}
     S, B = g["g_text_tok"].shape
     gen = make_engine(cfg, sd, device, lib, max_batch or B, use_sampling=False, support_out_of_sync=True)
     del sd
@@ -228,7 +265,7 @@ def check_free_running(device, lib, g, cfg, widen, name, max_batch=None, on_cuda
 def check_golden_full_free_running(device, lib, max_batch=None, name="golden_full_free_running"):
     """The benchmark model (32 layers, context 3000) free-running against the reference's own run (lm_full.npz)."""
     g, cfg = load_full()
-    return check_free_running(device, lib, g, cfg, FULL_WIDEN, name, max_batch=max_batch, on_cuda_weights=True)
+    return check_free_running(device, lib, g, cfg, FULL_WIDEN, name, max_batch=max_batch, sd=full_golden_state_dict(device))
 
 
 def check_golden_tiny_free_running(device, lib):
@@ -297,7 +334,7 @@ def engine_sampling_matches_oracle_rule(device, lib, cfg=None, top_k=20, top_k_t
 def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=False, input_scale=1.0, stats=None, int8_activations=True):
     if quantize is True and int8_activations:      # int8 x int8 linears: per-linear bit equality + a statistical network gate (below)
         return int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=use_masks, stats=stats)
-    sd = random_lm_state_dict(cfg, seed=seed)
+    sd = cached_lm_state_dict(cfg, seed)
     if quantize == "fp8":   # e4m3fn linears on the fp8 MFMA (BASELINE configs[4]); engine and oracle get the same fp8 tensors
         from moshi_amd.weights import quantize_lm_state_dict_fp8
         sd = quantize_lm_state_dict_fp8(sd, input_scale=input_scale)
@@ -813,7 +850,7 @@ FP8_HW_ACC_NOISE = 2.5e-4
 
 def fp8_engine_within_format_conditioning(device, lib, cfg, seed, B, S, input_scale=1.0):
     from moshi_amd.weights import quantize_lm_state_dict_fp8
-    bf = random_lm_state_dict(cfg, seed=seed)
+    bf = cached_lm_state_dict(cfg, seed)
     sd = quantize_lm_state_dict_fp8(bf, input_scale=input_scale)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
     exact, moved, plain = LMOracle(sd, cfg), LMOracle(sd, cfg, fp8_accumulate_noise=FP8_HW_ACC_NOISE, noise_seed=seed), LMOracle(bf, cfg)
@@ -997,10 +1034,10 @@ def _bf16_bits(a: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(a, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
 
 
-def int8_linears_bit_exact(device, lib, cfg, B, seed, report=None):
+def int8_linears_bit_exact(device, lib, cfg, B, seed, report=None, weights_seed=None):
     from moshi_amd.weights import quantize_lm_state_dict
     from oracle.lm_oracle import QWeight, bf16r, int8_vectorwise_quant, linear_int8, rms_norm, silu
-    sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=seed))
+    sd = quantize_lm_state_dict(cached_lm_state_dict(cfg, weights_seed if weights_seed is not None else seed))
     lm = LMModel(sd, cfg, device=device, max_batch=B, lib=lib)
     rng = np.random.default_rng(seed)
     d, dd = cfg.dim, cfg.depformer_dim
@@ -1092,7 +1129,7 @@ INT8_NET_GROSS_MAX, INT8_NET_GROSS_MEAN = 0.35, 0.10
 
 def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=None, stats=None):
     from moshi_amd.weights import quantize_lm_state_dict
-    sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=seed))
+    sd = quantize_lm_state_dict(cached_lm_state_dict(cfg, seed))
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
     orc, yard = LMOracle(sd, cfg), LMOracle(sd, cfg, stat64=True)
     orc.streaming(B); yard.streaming(B)

@@ -154,12 +154,14 @@ def oracle_vs_engine(model_factory, device, cfg, seed, B, F, K, use_masks=True):
                 assert close(pe[b], po[b], PCM_ATOL, PCM_RTOL), f"pcm differs frame {f} row {b}"
 
 
-def check_c2_recipe(model_factory, device, cfg, B=8, F=200, K=8, seed=0, p_exec=0.5, max_flips=2):
+def check_c2_recipe(model_factory, device, cfg, B=8, F=200, K=8, seed=0, p_exec=0.5, max_flips=2, oracle_rows=None):
     """SURVEY.md 8d's C2 recipe against the oracle: B streams of 0.1 * N(0, 1) PCM plus a sine row, F frames, a random exec
     mask per frame and ONE mid-run `reset_streaming(mask)`.  Row 0 always executes and row 1 executes nine frames in ten, so
     that at the full size (context 250, two positions per frame) their KV rings WRAP inside the run (frame 126 for row 0):
     the state the benchmark runs in and, before round 4, no full-size parity test reached (transformer.py:236-288).  Codes
-    equal on executed rows (near-tie flips audited, at most `max_flips` vectors), PCM of the oracle's codes within 2e-5."""
+    equal on executed rows (near-tie flips audited, at most `max_flips` vectors), PCM of the oracle's codes within 2e-5.
+    oracle_rows: the engine runs all B streams, the (slow, numpy) checker only these rows of the batch - streams are independent
+    (`test_batch_rows_are_independent_and_graph_equals_eager`), and the GPU suite has a time budget; default: every row."""
     sd = random_mimi_state_dict(cfg, seed=1234)
     m = model_factory(sd, cfg, K)
     orc = MimiOracle(sd, cfg, num_codebooks=K)
@@ -177,33 +179,38 @@ def check_c2_recipe(model_factory, device, cfg, B=8, F=200, K=8, seed=0, p_exec=
     rmask[B - 1] = True
     if B > 3:
         rmask[2] = True
+    rows = np.arange(B) if oracle_rows is None else np.asarray(sorted(oracle_rows))
     executed = np.zeros(B, int)
     wrapped = False
     mism, lats = [], {}
     worst = 0.0
-    orc.streaming(B)
+    orc.streaming(len(rows))
     with m.streaming(B):
         for f in range(F):
             if f == reset_at:
-                orc.reset_streaming(rmask)
+                orc.reset_streaming(rmask[rows])
                 m.reset_streaming(torch.from_numpy(rmask).to(device))
                 executed[rmask] = 0
             mask = rng.random(B) < pr
-            orc.set_exec_mask(mask)
+            orc.set_exec_mask(mask[rows])
             m.set_exec_mask(torch.from_numpy(mask).to(device))
             xf = x[..., f * fs:(f + 1) * fs]
-            lat = orc.encode_to_latent(xf)
+            lat = orc.encode_to_latent(xf[rows])
             co = orc.quantize(lat)
             ce = m.encode(torch.from_numpy(xf).to(device)).cpu().numpy()
             po = orc.decode(co)
-            pe = m.decode(torch.from_numpy(co).to(device)).cpu().numpy()
+            cd = ce.copy()                      # the decoder is fed the CHECKER's codes on the checked rows (its own elsewhere)
+            cd[rows] = co
+            pe = m.decode(torch.from_numpy(cd).to(device)).cpu().numpy()
             executed += mask
-            wrapped |= bool((executed * (fs // cfg.hop_length) > cfg.tr_context).any())
-            for b in np.flatnonzero(mask):
-                for k, t in np.argwhere(ce[b] != co[b]):
-                    mism.append((f, int(b), int(k), int(t), int(ce[b, k, t]), int(co[b, k, t])))
+            wrapped |= bool((executed[rows] * (fs // cfg.hop_length) > cfg.tr_context).any())
+            for i, b in enumerate(rows):
+                if not mask[b]:
+                    continue
+                for k, t in np.argwhere(ce[b] != co[i]):
+                    mism.append((f, int(i), int(k), int(t), int(ce[b, k, t]), int(co[i, k, t])))
                     lats[f] = lat
-                err = float(np.abs(pe[b] - po[b]).max()) / (PCM_ATOL + PCM_RTOL * float(np.abs(po[b]).max()))
+                err = float(np.abs(pe[b] - po[i]).max()) / (PCM_ATOL + PCM_RTOL * float(np.abs(po[i]).max()))
                 worst = max(worst, err)
                 assert err <= 1.0, f"pcm differs frame {f} row {b}: {err:.2f} x the tolerance"
     total = int(executed.sum()) * K            # (an underestimate after the reset: the reset rows' earlier frames counted too)
@@ -211,4 +218,5 @@ def check_c2_recipe(model_factory, device, cfg, B=8, F=200, K=8, seed=0, p_exec=
           f"{worst:.3f} x tolerance; ring wrapped: {wrapped}")
     if mism:
         audit_code_mismatches(orc, lats, mism, max_vectors=max_flips)
-    return {"frames": F, "batch": B, "decisions_differing": len(mism), "worst_pcm_over_tol": worst, "wrapped": wrapped}
+    return {"frames": F, "batch": B, "rows_checked": [int(r) for r in rows], "decisions_differing": len(mism), "worst_pcm_over_tol": worst,
+            "wrapped": wrapped}

@@ -41,7 +41,9 @@ def test_full_size_c2_recipe_crosses_the_ring_wrap(factory):
     transformers wrap at frame 126 (the state bench.py runs in, never parity-tested at full size before)."""
     import json
     from pathlib import Path
-    res = mimi_cases.check_c2_recipe(factory, DEV, MimiConfig(), B=8, F=200)
+    # the engine runs the 8 streams; the numpy checker follows four of them (the always-executing row whose rings wrap at frame
+    # 126, the nine-in-ten row (wraps ~140), a reset row, the sine row) for 160 frames: 85 s instead of 210 in a suite with a budget
+    res = mimi_cases.check_c2_recipe(factory, DEV, MimiConfig(), B=8, F=160, oracle_rows=[0, 1, 2, 7])
     assert res["wrapped"]
     out = Path(__file__).resolve().parent.parent / "gpurun_out"
     if out.is_dir():
