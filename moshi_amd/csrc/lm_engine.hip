@@ -6,6 +6,7 @@
 #include "mmi_graph.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <map>
 
 namespace {
@@ -132,6 +133,14 @@ struct mmi_lm {
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
     bool dominant_xlds = false;     // the profiled (dominant) GEMM ran on k_gemm_xlds
     MmiProgram prog;
+    // MMI_DEBUG_TRACE=<prefix> (debug: finding which launch of the step is not reproducible): every step runs its launch list
+    // eagerly and, after EVERY op, checksums every allocation of the streaming state; lines "step op site allocation bytes
+    // checksum" for the allocations an op changed go to <prefix>.<n> (n = streaming sessions of the process so far).  Two
+    // sessions fed the same inputs must write the same file.
+    FILE* trace_file = nullptr;
+    unsigned long long* trace_dev = nullptr;
+    std::vector<unsigned long long> trace_prev;
+    long trace_step = 0;
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
     // profiling tap
@@ -1453,6 +1462,16 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     rc = build_program(lm);
     if (rc) return fail(rc);
     MMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (const char* tp = getenv("MMI_DEBUG_TRACE")) {
+        static int session = 0;
+        lm->trace_file = fopen((std::string(tp) + "." + std::to_string(session++)).c_str(), "w");
+        lm->trace_prev.assign(lm->st.ptrs.size(), 0ull);
+        lm->trace_step = 0;
+        if (lm->trace_file && hipMalloc((void**)&lm->trace_dev, lm->st.ptrs.size() * sizeof(unsigned long long)) != hipSuccess) {
+            fclose(lm->trace_file);
+            lm->trace_file = nullptr;
+        }
+    }
     lm->streaming = true;
     return MMI_OK;
 }
@@ -1462,6 +1481,8 @@ extern "C" int mmi_lm_streaming_stop(mmi_lm* lm) {
     if (!lm) return mmi_fail(MMI_ERR_INVALID, "null handle");
     if (!lm->streaming) return MMI_OK;
     hipDeviceSynchronize();
+    if (lm->trace_file) { fclose(lm->trace_file); lm->trace_file = nullptr; }
+    if (lm->trace_dev) { hipFree(lm->trace_dev); lm->trace_dev = nullptr; }
     lm->prog.clear();
     lm->st.release();
     lm->streaming = false;
@@ -1523,6 +1544,30 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
             hipMemsetAsync(lm->use_forced, 0, sizeof(int), s);   // this step does not leak into the next one
             lm->forced_armed = false;
         }
+    }
+    else if (lm->trace_file) {
+        lm->prog.tap = [lm](size_t i, bool begin, hipStream_t st) {
+            if (begin) return;
+            const size_t n = lm->st.ptrs.size();
+            hipMemsetAsync(lm->trace_dev, 0, n * sizeof(unsigned long long), st);
+            for (size_t a = 0; a < n; ++a) {
+                const long nb = (long)lm->st.sizes[a];
+                int blocks = (int)((nb / 4 + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                if (blocks < 1) blocks = 1;
+                hipLaunchKernelGGL(k_checksum, blocks, 256, 0, st, (const uint8_t*)lm->st.ptrs[a], nb, lm->trace_dev + a);
+            }
+            std::vector<unsigned long long> now(n);
+            hipStreamSynchronize(st);
+            hipMemcpy(now.data(), lm->trace_dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            for (size_t a = 0; a < n; ++a)
+                if (now[a] != lm->trace_prev[a])
+                    fprintf(lm->trace_file, "%ld %zu %s %zu %zu %016llx\n", lm->trace_step, i, lm->prog.sites[i].c_str(), a, lm->st.sizes[a], now[a]);
+            lm->trace_prev = now;
+        };
+        rc = lm->prog.run_eager(s);
+        lm->prog.tap = nullptr;
+        lm->trace_step += 1;
     }
     else if (lm->phase_fn) {
         auto fn = lm->phase_fn; void* user = lm->phase_user;

@@ -1358,6 +1358,18 @@ __global__ void k_pack_rows(const uint16_t* __restrict__ src, int n, int D, uint
 }
 
 // packed activation operand -> row-major rows [B][D] (the parity tap of the residual stream, mmi_lm_set_hidden_taps)
+// debug trace (MMI_DEBUG_TRACE): order-independent 64-bit checksum of a buffer (sum of its 32-bit words, tail bytes included)
+__global__ void k_checksum(const uint8_t* __restrict__ p, long nbytes, unsigned long long* __restrict__ out) {
+    const long nwords = nbytes >> 2;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+    unsigned long long acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x)
+        acc += (unsigned long long)w[i] * (unsigned long long)(2 * (i % 1021) + 1);       // position-weighted: a swap of two words shows
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = nwords << 2; i < nbytes; ++i) acc += (unsigned long long)p[i] << (8 * (i & 3));
+    atomicAdd(out, acc);
+}
+
 // parity tap: the int8 operand Xq[mt][kp][lane][16] (k_quant_rows_i8 / the norm kernel) -> row-major codes [B][D]
 __global__ void k_unpack_q8(const uint8_t* __restrict__ xq, int B, int D, int8_t* __restrict__ dst, int T, int ksteps) {
     const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -36,6 +36,9 @@ void mmi_note_launch(const char* kernel);
         hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); });        \
     } while (0)
 
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    hipsim::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+
 using std::min;
 using std::max;
 
@@ -308,6 +311,7 @@ inline i32x4 mmi_mfma_i8_16x16x64(u32x4 a, u32x4 b, i32x4 c) {
     hipsim::sync_wave();
     return d;
 }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicMax(unsigned* p, unsigned v) {
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
