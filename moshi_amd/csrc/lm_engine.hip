@@ -138,6 +138,7 @@ struct mmi_lm {
     // checksum" for the allocations an op changed go to <prefix>.<n> (n = streaming sessions of the process so far).  Two
     // sessions fed the same inputs must write the same file.
     FILE* trace_file = nullptr;
+    std::string trace_name;
     unsigned long long* trace_dev = nullptr;
     std::vector<unsigned long long> trace_prev;
     long trace_step = 0;
@@ -1464,7 +1465,8 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     MMI_HIP_CHECK(hipStreamSynchronize(s));
     if (const char* tp = getenv("MMI_DEBUG_TRACE")) {
         static int session = 0;
-        lm->trace_file = fopen((std::string(tp) + "." + std::to_string(session++)).c_str(), "w");
+        lm->trace_name = std::string(tp) + "." + std::to_string(session++);
+        lm->trace_file = fopen(lm->trace_name.c_str(), "w");
         lm->trace_prev.assign(lm->st.ptrs.size(), 0ull);
         lm->trace_step = 0;
         if (lm->trace_file && hipMalloc((void**)&lm->trace_dev, lm->st.ptrs.size() * sizeof(unsigned long long)) != hipSuccess) {
@@ -1564,6 +1566,22 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
                 if (now[a] != lm->trace_prev[a])
                     fprintf(lm->trace_file, "%ld %zu %s %zu %zu %016llx\n", lm->trace_step, i, lm->prog.sites[i].c_str(), a, lm->st.sizes[a], now[a]);
             lm->trace_prev = now;
+            // MMI_DEBUG_DUMP="step:op:alloc[,alloc...]": those allocations, as they are after that op, to <prefix>.<session>.a<alloc>
+            if (const char* dd = getenv("MMI_DEBUG_DUMP")) {
+                long ds = -1, dop = -1;
+                int used = 0;
+                if (sscanf(dd, "%ld:%ld:%n", &ds, &dop, &used) >= 2 && ds == lm->trace_step && dop == (long)i) {
+                    const char* q = dd + used;
+                    while (*q) {
+                        const long a = strtol(q, (char**)&q, 10);
+                        if (*q == ',') ++q;
+                        if (a < 0 || a >= (long)n) break;
+                        std::vector<char> host(lm->st.sizes[a]);
+                        hipMemcpy(host.data(), lm->st.ptrs[a], host.size(), hipMemcpyDeviceToHost);
+                        if (FILE* df = fopen((lm->trace_name + ".a" + std::to_string(a)).c_str(), "wb")) { fwrite(host.data(), 1, host.size(), df); fclose(df); }
+                    }
+                }
+            }
         };
         rc = lm->prog.run_eager(s);
         lm->prog.tap = nullptr;

@@ -421,12 +421,16 @@ __device__ __forceinline__ void mmi_gemm_epilogue(const GemmArgs& a, float (&acc
             if (sec < 2) {
                 const float* cs = a.rope + ((long)b * (a.Dh / 2) + d0 / 2) * 2;      // 4 (cos, sin) pairs = 32 contiguous bytes
                 const f32x4 cs0 = *reinterpret_cast<const f32x4*>(cs), cs1 = *reinterpret_cast<const f32x4*>(cs + 4);
-#pragma unroll
+    #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float c = j < 2 ? cs0[2 * j] : cs1[2 * j - 4], sn = j < 2 ? cs0[2 * j + 1] : cs1[2 * j - 3];
+                    // mmi_rope_rotate = four multiplies, a subtract, an add as separate VALU instructions.  Written as
+                    // `re * c - im * sn` the compiler packs the four pairs into v_pk_mul_f32 / v_pk_add_f32 with op_sel swizzles,
+                    // one of them in place, and on gfx950 that sequence inside k_gemm_xp<32, 2, ..> (64 sessions) returned, now and
+                    // then, a stale last element for lanes 48-63 - q / k of 16 sessions wrong in one feature, a different one
+                    // from run to run: the "row 17" failure of the driver's round-4 suite (profiles/r05_logs/c5_trace_*.txt)
                     const float re = v8[2 * j], im = v8[2 * j + 1];
-                    v8[2 * j] = re * c - im * sn;
-                    v8[2 * j + 1] = re * sn + im * c;
+                    mmi_rope_rotate(re, im, c, sn, v8[2 * j], v8[2 * j + 1]);
                 }
             }
             if (sec != 0 && a.kv8) {   // fp8 ring: the bf16 k / v values (k after RoPE, as the bf16 ring would hold them) -> e4m3

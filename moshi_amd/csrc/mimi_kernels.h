@@ -1056,11 +1056,14 @@ __global__ __launch_bounds__(256) void k_mimi_attn(MimiAttnArgs a) {
         const float c = cosf(ang), s = sinf(ang);
         const float qr = qrow[(long)(h * D + 2 * j) * T + t], qi = qrow[(long)(h * D + 2 * j + 1) * T + t];
         const float kr = qrow[(long)(HD + h * D + 2 * j) * T + t], ki = qrow[(long)(HD + h * D + 2 * j + 1) * T + t];
-        qs[t * D + 2 * j] = qr * c - qi * s;
-        qs[t * D + 2 * j + 1] = qr * s + qi * c;
+        float q_re, q_im, k_re, k_im;          // (plain VALU rotations: see mmi_rope_rotate)
+        mmi_rope_rotate(qr, qi, c, s, q_re, q_im);
+        mmi_rope_rotate(kr, ki, c, s, k_re, k_im);
+        qs[t * D + 2 * j] = q_re;
+        qs[t * D + 2 * j + 1] = q_im;
         const int slot = (int)((off + t) % cap);
-        kcb[(long)slot * D + 2 * j] = kr * c - ki * s;
-        kcb[(long)slot * D + 2 * j + 1] = kr * s + ki * c;
+        kcb[(long)slot * D + 2 * j] = k_re;
+        kcb[(long)slot * D + 2 * j + 1] = k_im;
     }
     for (int i = tid; i < T * D; i += 256) {
         const int t = i / D, d = i % D;
@@ -1206,10 +1209,8 @@ __global__ __launch_bounds__(256) void k_mimi_attn_1pass(MimiAttnArgs a) {
         const float c = cosf(ang), s = sinf(ang);
         const float qr = qrow[(long)(h * D + 2 * j) * T + t], qi = qrow[(long)(h * D + 2 * j + 1) * T + t];
         const float kr = qrow[(long)(HD + h * D + 2 * j) * T + t], ki = qrow[(long)(HD + h * D + 2 * j + 1) * T + t];
-        qs[t * D + 2 * j] = qr * c - qi * s;
-        qs[t * D + 2 * j + 1] = qr * s + qi * c;
-        kn[t * D + 2 * j] = kr * c - ki * s;
-        kn[t * D + 2 * j + 1] = kr * s + ki * c;
+        mmi_rope_rotate(qr, qi, c, s, qs[t * D + 2 * j], qs[t * D + 2 * j + 1]);      // (plain VALU rotations: see mmi_rope_rotate)
+        mmi_rope_rotate(kr, ki, c, s, kn[t * D + 2 * j], kn[t * D + 2 * j + 1]);
     }
     for (int i = tid; i < T * D; i += 256) {
         const int t = i / D, d = i % D;

@@ -90,8 +90,10 @@ struct MmiArena {
         // MMI_DEBUG_POISON=1 (tests / scripts/gpu_check.sh): every allocation of a handle starts as 0xFF bytes (bf16 / fp32 NaNs,
         // int -1) instead of whatever the allocator hands out, so that a read of state the engine never initialised shows up as
         // a wrong result on every box, not only on the one whose memory happened to hold something else
-        static const bool poison = getenv("MMI_DEBUG_POISON") && getenv("MMI_DEBUG_POISON")[0] == '1';
-        if (poison && (e = hipMemset(q, 0xFF, nb)) != hipSuccess) { hipFree(q); return e; }
+        // (MMI_DEBUG_POISON=0: zero-fill instead - two sessions then start from identical memory, which is what MMI_DEBUG_TRACE's
+        // per-op checksums need to be comparable line by line)
+        static const char* pz = getenv("MMI_DEBUG_POISON");
+        if (pz && (pz[0] == '1' || pz[0] == '0') && (e = hipMemset(q, pz[0] == '1' ? 0xFF : 0x00, nb)) != hipSuccess) { hipFree(q); return e; }
         ptrs.push_back(q);
         sizes.push_back(nb);
         bytes += nb;

@@ -97,6 +97,20 @@ __device__ __forceinline__ f32x4 mmi_mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 
                                                    __builtin_bit_cast(mmi_bf16x8, b), c, 0, 0, 0);
 }
 
+// One RoPE rotation (re, im) -> (re c - im s, re s + im c) in plain (un-packed) fp32 VALU instructions, each rounded once (no
+// fma), pinned by inline asm so that the compiler cannot re-form them into packed-math (v_pk_mul_f32 / v_pk_add_f32 with op_sel
+// swizzles) - see the note at its call site in lm_kernels.h (mmi_gemm_epilogue, MMI_EPI_ROPE_KV).  Arithmetic unchanged: the same
+// six IEEE operations the C expression means under -ffp-contract=off.
+__device__ __forceinline__ void mmi_rope_rotate(float re, float im, float c, float sn, float& out_re, float& out_im) {
+    float a, b, d, e;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a) : "v"(re), "v"(c));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b) : "v"(im), "v"(sn));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(re), "v"(sn));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e) : "v"(im), "v"(c));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(out_re) : "v"(a), "v"(b));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(out_im) : "v"(d), "v"(e));
+}
+
 // ---- fp8 (OCP e4m3fn on gfx950: 4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinity) -----------------------
 // four fp32 -> four fp8 bytes (byte i = value i), round-to-nearest-even, clamped to +-448 first so that the result does not
 // depend on the conversion's overflow mode

@@ -26,6 +26,11 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define gridDim hipsim::t_gridDim
 #define __syncthreads() hipsim::sync_block()
 
+inline void mmi_rope_rotate(float re, float im, float c, float sn, float& out_re, float& out_im) {
+    const float a = re * c, b = im * sn, d = re * sn, e = im * c;
+    out_re = a - b;
+    out_im = d + e;
+}
 #define MMI_WAVE 64
 #define MMI_SHARED static thread_local
 #define MMI_DYN_SHARED(T, name) T* name = reinterpret_cast<T*>(hipsim::dyn_smem())

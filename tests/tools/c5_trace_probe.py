@@ -58,22 +58,45 @@ def main():
                     gen.reset_streaming(torch.from_numpy(p["reset"]).to("cuda"))
                 gen.set_exec_mask(torch.from_numpy(p["mask"]).to("cuda"))
                 gen.step_with_taps(torch.from_numpy(p["codes"]).to("cuda"), forced_tokens=torch.from_numpy(p["forced"]).to("cuda"))
-    traces = [Path(f"{prefix}.{i}").read_text().splitlines() for i in range(n_sessions)]
-    ref = traces[0]
-    print(f"TRACE session 0: {len(ref)} lines")
+    dump = os.environ.get("MMI_DEBUG_DUMP")
+    if dump:                     # element-level view of the dumped allocations: which (row, column) differ between sessions
+        allocs = [int(a) for a in dump.split(":")[2].split(",")]
+        for a in allocs:
+            ref = np.fromfile(f"{prefix}.0.a{a}", dtype=np.uint16)
+            for i in range(1, n_sessions):
+                cur = np.fromfile(f"{prefix}.{i}.a{a}", dtype=np.uint16)
+                bad = np.flatnonzero(ref != cur)
+                msg = f"DUMP allocation {a} ({NAMES[a]}) session {i} vs 0: {bad.size} of {ref.size} 16-bit words differ"
+                if bad.size and NAMES[a] == "qrot":
+                    HD = cfg.dim
+                    rows, cols = bad // HD, bad % HD
+                    msg += f"; rows {sorted(set(rows.tolist()))[:40]}; heads {sorted(set((cols // 128).tolist()))[:40]}; dims {sorted(set((cols % 128).tolist()))[:64]}"
+                    msg += f"; first: " + ", ".join(f"[{r},{c}] {ref[k]:04x}->{cur[k]:04x}" for r, c, k in list(zip(rows, cols, bad))[:8])
+                elif bad.size:
+                    msg += f"; first indices {bad[:16].tolist()}"
+                print(msg)
+
+    def load(i):
+        d = {}
+        for ln in Path(f"{prefix}.{i}").read_text().splitlines():
+            f = ln.split()
+            d[(int(f[0]), int(f[1]), int(f[3]))] = (f[2], f[4], f[5])
+        return d
+    ref = load(0)
+    print(f"TRACE session 0: {len(ref)} (step, op, allocation) records")
     for i in range(1, n_sessions):
-        t = traces[i]
-        diffs = [(a, b) for a, b in zip(ref, t) if a != b]
-        if len(ref) != len(t):
-            print(f"TRACE session {i}: {len(t)} lines against {len(ref)}")
+        t = load(i)
+        keys = sorted(set(ref) | set(t))
+        diffs = [k for k in keys if ref.get(k, (None, None, None))[2] != t.get(k, (None, None, None))[2]]
         if not diffs:
             print(f"TRACE session {i}: identical to session 0")
             continue
-        print(f"TRACE session {i}: {len(diffs)} lines differ; the first 12:")
-        for a, b in diffs[:12]:
-            fa, fb = a.split(), b.split()
-            name = NAMES[int(fa[3])] if int(fa[3]) < len(NAMES) else "?"
-            print(f"    step {fa[0]} op {fa[1]} site {fa[2]} allocation {fa[3]} ({name}, {fa[4]} bytes): {fa[5]} vs {fb[5]}" + ("" if fa[:5] == fb[:5] else f"   [other line: {b}]"))
+        print(f"TRACE session {i}: {len(diffs)} records differ; the first 10:")
+        for k in diffs[:10]:
+            a, b = ref.get(k), t.get(k)
+            site = (a or b)[0]
+            name = NAMES[k[2]] if k[2] < len(NAMES) else "?"
+            print(f"    step {k[0]} op {k[1]} site {site} allocation {k[2]} ({name}, {(a or b)[1]} bytes): {a[2] if a else 'unchanged'} vs {b[2] if b else 'unchanged'}")
 
 
 if __name__ == "__main__":
