@@ -125,6 +125,12 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
             rec.update({"bytes_per_op": wbytes, "GBps": wbytes / us / 1e3, "frac": wbytes / us / 1e3 / HBM_PEAK_GBS})
         sites[site] = rec
     out["sites"] = sites
+    # the largest site by time per step (at the mid-run depth the decode attention outweighs the dominant GEMM)
+    timed = {k: v for k, v in sites.items() if "frac" in v}
+    if timed:
+        big = max(timed, key=lambda k: timed[k]["us_per_step"])
+        out["largest_site"] = {"site": big, "kernel": {"L.attn": "k_lm_attn_wave"}.get(big, "see mmi_lm_launch_list"), **timed[big],
+                               "note": "live hipEvents around each op of un-graphed steps (a few us of dispatch per op included)"}
     # secondary figure (north_star: "achieved MFMA/HBM fraction"): the same launch's matrix-core rate.  The GEMM is
     # 2 * N * K * B flops with N = 2 * ffn_hidden rows, K = dim, B sessions; dense peaks from MI355X_MICROARCH.md.
     cfg = lm_gen.lm_model.config
@@ -149,6 +155,10 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
                                          f"FETCH_SIZE x2 + WRITE_SIZE, separate passes, {where}; " + ", ".join(rec.get("sources", [])) + ") - not collected in this run")
                 out["traffic_measured_in_this_run"] = False
                 break
+        att = doc.get("attention")
+        if att and "largest_site" in out and out["largest_site"]["site"] == "L.attn":
+            out["largest_site"]["traffic"] = {"fetch_bytes_per_launch": att[0]["fetch_bytes_corrected"], "what": att[0]["what"],
+                                              "note": att[0]["note"], "sources": att[0]["sources"], "measured_in_this_run": False}
     return out
 
 

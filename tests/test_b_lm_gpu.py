@@ -283,3 +283,8 @@ def test_attention_program_switch_is_a_graph_launch_not_a_capture(gpu_lib, monke
     at_switch = max(ms[36:46])
     print(f"[switch] steady step {steady:.3f} ms, worst step around the switch {at_switch:.3f} ms, first step {ms[0]:.1f} ms")
     assert at_switch <= 3.0 * steady + 1.0, f"the step at the program switch is a latency spike: {at_switch:.3f} ms against {steady:.3f}"
+
+
+def test_benchmark_batch_step_is_bit_reproducible_between_streams(gpu_lib):
+    """32 sessions, bf16, 7B layer widths (the benchmark's kernels): repeated streams on one handle equal the first bit for bit."""
+    lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=32, quantize=False, seed=15, repeats=3)

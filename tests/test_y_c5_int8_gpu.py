@@ -64,3 +64,9 @@ def test_int8_full_width_layers_match_oracle(gpu_lib):
 def test_c5_shape_int8_linears_at_64_sessions_match_oracle(gpu_lib):
     """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), row-wise int8 linears."""
     lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, quantize=True)
+
+
+def test_c5_step_is_bit_reproducible_between_streams(gpu_lib):
+    """64 sessions, int8 x int8, 7B layer widths: four more streams on the same handle, fed the same frames, reproduce the first
+    one's tokens, logits and hidden states bit for bit.  (Round 4's driver failure - row 17 - was a launch that did not.)"""
+    lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=64, quantize=True, seed=364)

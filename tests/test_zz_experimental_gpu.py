@@ -18,3 +18,11 @@ def test_non_default_gemm_paths_at_full_width_match_oracle(gpu_lib, monkeypatch,
     st = {}
     lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=15, B=B, S=2, use_masks=False, stats=st)
     assert (st["xlds_launches"] >= 2 * 2 + 1) if mode == "1" else st["xlds_launches"] == 0
+
+
+def test_gemm_xp_with_rope_epilogue_is_bit_reproducible_at_two_batch_tiles(gpu_lib, monkeypatch):
+    """MMI_GEMM_LDS=0 at 64 sessions, bf16: the temporal in_proj on k_gemm_xp<32, 2, ..> with the RoPE + ring-write epilogue - the
+    launch whose q / k output changed from run to run before round 5 (packed-math rotation, lm_kernels.h) - repeated streams equal
+    the first bit for bit."""
+    monkeypatch.setenv("MMI_GEMM_LDS", "0")
+    lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=64, quantize=False, seed=15)
