@@ -126,7 +126,12 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
         sites[site] = rec
     out["sites"] = sites
     # the largest site by time per step (at the mid-run depth the decode attention outweighs the dominant GEMM)
-    timed = {k: v for k, v in sites.items() if "frac" in v}
+    timed = {k: dict(v) for k, v in sites.items() if "frac" in v}
+    if "L.ffn_in" in timed and mean_ms.value > 0:
+        # this site's ops carry a SECOND event pair (the dominant-kernel tap above): rank it by that tap's own figure instead
+        t = timed["L.ffn_in"]
+        t.update({"us_per_op": 1e3 * mean_ms.value, "us_per_step": 1e3 * mean_ms.value * t["ops_per_step"],
+                  "GBps": t["bytes_per_op"] / (1e3 * mean_ms.value) / 1e3, "frac": t["bytes_per_op"] / (1e3 * mean_ms.value) / 1e3 / HBM_PEAK_GBS})
     if timed:
         big = max(timed, key=lambda k: timed[k]["us_per_step"])
         out["largest_site"] = {"site": big, "kernel": {"L.attn": "k_lm_attn_wave"}.get(big, "see mmi_lm_launch_list"), **timed[big],

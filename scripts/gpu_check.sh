@@ -5,7 +5,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 O=$GRAFT_REPO_ROOT/gpurun_out
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
-timeout 2400 python -m pytest tests -m gpu -q --timeout=900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+# exactly as the driver runs it (-x: the first failure stops the run), plus the slowest tests for the suite's time budget (600 s)
+timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -18 $O/pytest_gpu.log | cut -c1-200
 ( time timeout 900 python bench.py --steps 20 --warmup 5 ) > $O/bench_default.log 2>&1; grep '"metric"' $O/bench_default.log | cut -c1-400
 timeout 300 python bench.py --no-cpu-baseline --no-extras --serial > $O/bench_default_serial.log 2>&1
 timeout 300 python bench.py --no-cpu-baseline --workload mimi --batch 8 > $O/bench_mimi_b8.log 2>&1
