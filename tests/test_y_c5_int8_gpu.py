@@ -63,7 +63,8 @@ def test_int8_full_width_layers_match_oracle(gpu_lib):
 
 def test_c5_shape_int8_linears_at_64_sessions_match_oracle(gpu_lib):
     """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), row-wise int8 linears."""
-    lm_cases.oracle_vs_engine(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, quantize=True)
+    res = lm_cases.int8_network_vs_oracle(DEV, None, LMConfig(num_layers=2, context=64), seed=364, B=64, S=2, use_masks=True, name="c5_int8_b64")
+    print(res)
 
 
 def test_c5_step_is_bit_reproducible_between_streams(gpu_lib):
