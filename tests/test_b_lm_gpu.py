@@ -282,7 +282,9 @@ def test_attention_program_switch_is_a_graph_launch_not_a_capture(gpu_lib, monke
     steady = float(np.median(ms[5:35]))
     at_switch = max(ms[36:46])
     print(f"[switch] steady step {steady:.3f} ms, worst step around the switch {at_switch:.3f} ms, first step {ms[0]:.1f} ms")
-    assert at_switch <= 3.0 * steady + 1.0, f"the step at the program switch is a latency spike: {at_switch:.3f} ms against {steady:.3f}"
+    # (the deterministic half of the check is the readiness mask above; the timing half leaves room for a host hiccup - capturing and
+    # instantiating a step program costs tens of milliseconds)
+    assert at_switch <= 3.0 * steady + 3.0, f"the step at the program switch is a latency spike: {at_switch:.3f} ms against {steady:.3f}"
 
 
 def test_benchmark_batch_step_is_bit_reproducible_between_streams(gpu_lib):
