@@ -41,7 +41,8 @@ typedef enum mmi_status {
     MMI_ERR_HIP = -4,            /* a HIP runtime call failed                                           */
     MMI_ERR_MISSING_WEIGHT = -5, /* a state-dict key required by the config was not supplied             */
     MMI_ERR_UNSUPPORTED = -6,    /* config outside what the kernels implement                           */
-    MMI_ERR_BUSY = -7            /* batcher: no free slot / a channel's buffer is full                    */
+    MMI_ERR_BUSY = -7,           /* batcher: no free slot / a channel's buffer is full                    */
+    MMI_ERR_NO_CHANNEL = -8      /* batcher: the channel id names no open channel (closed, or re-opened under a new id) */
 } mmi_status;
 
 typedef enum mmi_dtype { MMI_F32 = 0, MMI_BF16 = 1, MMI_I64 = 2, MMI_F16 = 3, MMI_I8 = 4, MMI_F8E4M3 = 5 /* OCP e4m3fn */ } mmi_dtype;

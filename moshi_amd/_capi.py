@@ -16,8 +16,8 @@ import torch
 _PKG = Path(__file__).resolve().parent
 DEFAULT_LIB = _PKG / "libmoshi_mi.so"
 
-MMI_OK, MMI_ERR_INVALID, MMI_ERR_SHAPE, MMI_ERR_STATE, MMI_ERR_HIP, MMI_ERR_MISSING_WEIGHT, MMI_ERR_UNSUPPORTED, MMI_ERR_BUSY = \
-    0, -1, -2, -3, -4, -5, -6, -7
+MMI_OK, MMI_ERR_INVALID, MMI_ERR_SHAPE, MMI_ERR_STATE, MMI_ERR_HIP, MMI_ERR_MISSING_WEIGHT, MMI_ERR_UNSUPPORTED, MMI_ERR_BUSY, \
+    MMI_ERR_NO_CHANNEL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 MMI_F32, MMI_BF16, MMI_I64, MMI_F16, MMI_I8, MMI_F8E4M3 = 0, 1, 2, 3, 4, 5
 
 _DTYPES = {torch.float32: MMI_F32, torch.bfloat16: MMI_BF16, torch.int64: MMI_I64, torch.float16: MMI_F16,
@@ -185,6 +185,9 @@ class Lib:
             raise KeyError(msg)
         if rc == MMI_ERR_BUSY:
             raise BufferError(msg)
+        if rc == MMI_ERR_NO_CHANNEL:                # its own status: no matching on the message text
+            from .errors import UnknownChannel
+            raise UnknownChannel(msg)
         if rc == MMI_ERR_UNSUPPORTED:
             raise NotImplementedError(msg)          # a RuntimeError, like every other engine failure
         raise RuntimeError(msg)

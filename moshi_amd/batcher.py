@@ -21,7 +21,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _capi
-from .errors import UnknownChannel
+from .errors import UnknownChannel  # noqa: F401  (re-exported: callers catch it from here)
 from .lm import LMModel
 from .mimi import MimiModel
 
@@ -113,10 +113,7 @@ class SessionBatcher:
         pcm = np.empty(self.frame_size, dtype=np.float32)
         tok = np.empty(self.n_tokens, dtype=np.int64)
         got = C.c_int32(0)
-        rc = self._lib.mmi_batcher_pop(self._handle, int(channel), pcm.ctypes.data, tok.ctypes.data, C.byref(got))
-        if rc == _capi.MMI_ERR_INVALID and "unknown channel" in self._lib.last_error():
-            raise UnknownChannel(f"channel {channel} is not open")
-        self._lib.check(rc)
+        self._lib.check(self._lib.mmi_batcher_pop(self._handle, int(channel), pcm.ctypes.data, tok.ctypes.data, C.byref(got)))      # MMI_ERR_NO_CHANNEL -> UnknownChannel
         return (pcm, tok) if got.value else None
 
     # ---- model loop ----------------------------------------------------------------------------------

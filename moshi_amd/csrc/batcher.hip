@@ -228,7 +228,7 @@ extern "C" int mmi_batcher_close(mmi_batcher* b, int64_t channel_id) {
     if (!b) return mmi_fail(MMI_ERR_INVALID, "null handle");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
-    if (!c) return mmi_fail(MMI_ERR_INVALID, "unknown channel");
+    if (!c) return mmi_fail(MMI_ERR_NO_CHANNEL, "unknown channel");
     *c = Channel();
     b->stats.used_slots -= 1;
     return MMI_OK;
@@ -239,7 +239,7 @@ extern "C" int mmi_batcher_push_pcm(mmi_batcher* b, int64_t channel_id, const fl
     if (!b || (!pcm && n_samples > 0) || n_samples < 0) return mmi_fail(MMI_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
-    if (!c) return mmi_fail(MMI_ERR_INVALID, "unknown channel");
+    if (!c) return mmi_fail(MMI_ERR_NO_CHANNEL, "unknown channel");
     if (c->in.size() + (size_t)n_samples > (size_t)b->cfg.max_buffered_frames * b->F)
         return mmi_fail(MMI_ERR_BUSY, "channel input buffer full");
     c->in.insert(c->in.end(), pcm, pcm + n_samples);
@@ -340,7 +340,7 @@ extern "C" int mmi_batcher_pop(mmi_batcher* b, int64_t channel_id, float* pcm, i
     if (!b || !got) return mmi_fail(MMI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(b->mu);
     Channel* c = find_channel(b, channel_id);
-    if (!c) return mmi_fail(MMI_ERR_INVALID, "unknown channel");
+    if (!c) return mmi_fail(MMI_ERR_NO_CHANNEL, "unknown channel");
     *got = 0;
     if (c->out.empty()) return MMI_OK;
     OutFrame& f = c->out.front();

@@ -1,4 +1,7 @@
 """Session batcher on the CPU kernel simulator: slot allocation, per-row reset, stream masks, routing."""
+import numpy as np
+import pytest
+
 from tests import batcher_cases
 
 
@@ -81,3 +84,18 @@ def test_io_threads_push_and_pop_while_the_loop_steps(sim_lib):
     for i in range(slots):
         assert len(results[i]) == n_frames - lcfg.max_delay
         assert all(np.isfinite(p).all() and (t >= 0).all() for p, t in results[i])
+
+
+def test_a_vanished_channel_has_its_own_status(sim_lib):
+    """push / pop / close on a channel id that names no open channel return MMI_ERR_NO_CHANNEL, which the binding maps
+    to `UnknownChannel` (a ValueError) - no matching on the message text; a REAL argument error stays a plain ValueError."""
+    from moshi_amd.batcher import SessionBatcher
+    from moshi_amd.errors import UnknownChannel
+    mimi, lm, mcfg, _ = batcher_cases.tiny_pair("cpu", sim_lib, 2)
+    b = SessionBatcher(mimi, lm, slots=2)
+    ch = b.open()
+    b.close(ch)
+    for call in (lambda: b.pop(ch), lambda: b.push(ch, np.zeros(mcfg.frame_size, np.float32)), lambda: b.close(ch)):
+        with pytest.raises(UnknownChannel):
+            call()
+    assert issubclass(UnknownChannel, ValueError)
