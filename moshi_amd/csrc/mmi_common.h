@@ -92,7 +92,7 @@ struct MmiArena {
         // a wrong result on every box, not only on the one whose memory happened to hold something else
         // (MMI_DEBUG_POISON=0: zero-fill instead - two sessions then start from identical memory, which is what MMI_DEBUG_TRACE's
         // per-op checksums need to be comparable line by line)
-        static const char* pz = getenv("MMI_DEBUG_POISON");
+        const char* pz = getenv("MMI_DEBUG_POISON");
         if (pz && (pz[0] == '1' || pz[0] == '0') && (e = hipMemset(q, pz[0] == '1' ? 0xFF : 0x00, nb)) != hipSuccess) { hipFree(q); return e; }
         ptrs.push_back(q);
         sizes.push_back(nb);

@@ -447,3 +447,27 @@ def test_int8_depformer_batch_tiles_walked_by_one_workgroup(sim_lib, monkeypatch
     monkeypatch.setenv("MMI_Q8_TILES", "serial")
     lm_cases.int8_linears_bit_exact("cpu", sim_lib, tiny_lm_config(), 40, seed=561)
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=562, B=40, S=2, quantize=True)
+
+
+def test_debug_trace_of_two_sessions_is_identical(sim_lib, monkeypatch, tmp_path):
+    """MMI_DEBUG_TRACE (the tool that found round 5's unreproducible launch): every op followed by a checksum of every
+    allocation of the streaming state.  Two sessions of one handle that start from identical memory (MMI_DEBUG_POISON=0) and are
+    fed the same frames write the same file - on the simulator by construction; on MI355X it is the property under test."""
+    monkeypatch.setenv("MMI_DEBUG_TRACE", str(tmp_path / "trace"))
+    monkeypatch.setenv("MMI_DEBUG_POISON", "0")
+    monkeypatch.setenv("MMI_DEBUG_DUMP", "1:2:10")           # q of the temporal in_proj, step 1
+    from moshi_amd.weights import quantize_lm_state_dict
+    cfg = tiny_lm_config()
+    sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=3))
+    gen = lm_cases.make_engine(cfg, sd, "cpu", sim_lib, 5, use_sampling=False, support_out_of_sync=True)
+    rng = np.random.default_rng(0)
+    codes = [torch.from_numpy(rng.integers(0, cfg.card, (5, 8, 1))) for _ in range(2)]
+    for _ in range(2):
+        with gen.streaming(5):
+            for c in codes:
+                gen.step(c)
+    files = sorted(tmp_path.glob("trace.*"))
+    traces = [f for f in files if f.suffix[1:].isdigit()]
+    assert len(traces) == 2 and traces[0].read_text() == traces[1].read_text() and len(traces[0].read_text().splitlines()) > 100
+    dumps = sorted(tmp_path.glob("trace.*.a10"))
+    assert len(dumps) == 2 and dumps[0].read_bytes() == dumps[1].read_bytes() and any(dumps[0].read_bytes())
