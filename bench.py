@@ -102,24 +102,30 @@ def gather_per_rank(x, dist, dev, world):
 def rank_report(rank, local, world, dist, dev):
     """One line per rank on stderr, and the same facts gathered for the JSON line: which physical device the rank drives (PCI bus
     id), what the weight broadcast at load moved and at what rate.  The first real N-GPU run is then self-diagnosing: N distinct
-    bus ids = N GPUs, `bcast_world` = the ranks RCCL saw, `bcast_gb_per_s` = the rate the weights crossed xGMI at."""
+    bus ids = N GPUs, `bcast_world` = the ranks RCCL saw, `bcast_gb_per_s` = the rate the weights crossed xGMI at.  Gathered with
+    the benchmark's one collective pattern (an all_gather of a float64 per rank, `gather_per_rank`): no object collective."""
     from moshi_amd.dist import BROADCAST_STATS as st
     try:
         pr = torch.cuda.get_device_properties(dev)
-        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        code = (int(getattr(pr, "pci_domain_id", 0)) << 16) | (int(getattr(pr, "pci_bus_id", 0)) << 8) | int(getattr(pr, "pci_device_id", 0))
         name = pr.name
     except Exception:      # the gloo / CPU test configuration
-        bus, name = "n/a", "cpu"
-    mine = {"rank": rank, "local_rank": local, "device": name, "pci_bus_id": bus, "bcast_world": st["world"],
-            "bcast_gb": round(st["bytes"] / 1e9, 3), "bcast_s": round(st["seconds"], 3), "bcast_buckets": st["buckets"],
-            "bcast_gb_per_s": round(st["bytes"] / 1e9 / st["seconds"], 2) if st["seconds"] > 0 else None}
-    sys.stderr.write("bench.py rank %(rank)d/%(w)d: %(device)s at %(pci_bus_id)s; weight broadcast over %(bcast_world)d rank(s): "
-                     "%(bcast_gb).2f GB in %(bcast_s).2f s, %(bcast_buckets)d buckets -> %(bcast_gb_per_s)s GB/s\n" % {**mine, "w": world})
-    if dist is None:
-        return [mine]
-    allr = [None] * world
-    dist.all_gather_object(allr, mine)
-    return allr
+        code, name = -1, "cpu"
+
+    def bus(c):
+        c = int(c)
+        return "n/a" if c < 0 else "%04x:%02x:%02x.0" % (c >> 16, (c >> 8) & 0xff, c & 0xff)
+    rate = st["bytes"] / 1e9 / st["seconds"] if st["seconds"] > 0 else None
+    sys.stderr.write("bench.py rank %d/%d: %s at %s; weight broadcast over %d rank(s): %.2f GB in %.2f s, %d buckets -> %s GB/s\n"
+                     % (rank, world, name, bus(code), st["world"], st["bytes"] / 1e9, st["seconds"], st["buckets"],
+                        "%.2f" % rate if rate else "n/a"))
+    cols = [gather_per_rank(v, dist, dev, world) for v in (code, st["world"], st["bytes"], st["seconds"], st["buckets"])]
+    out = []
+    for r in range(world):
+        c, w, nb, sec, bk = (col[r] for col in cols)
+        out.append({"rank": r, "device": name if r == rank else None, "pci_bus_id": bus(c), "bcast_world": int(w), "bcast_gb": round(nb / 1e9, 3),
+                    "bcast_s": round(sec, 3), "bcast_buckets": int(bk), "bcast_gb_per_s": round(nb / 1e9 / sec, 2) if sec > 0 else None})
+    return out
 
 
 def _free_port():
