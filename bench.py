@@ -354,7 +354,7 @@ def main():
     load_local = time.perf_counter() - t_load
     load_s = job_time(load_local, dist, dev)      # rank 0 draws, RCCL broadcasts in 1 GiB buckets, every rank packs
     load_ranks = gather_per_rank(load_local, dist, dev, world)
-    ranks_info = rank_report(rank, local, world, dist, dev)
+    ranks_info = rank_report(rank, local, world, dist, dev)      # (every rank calls it: it gathers)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     pcm = 0.1 * torch.randn(B, 1, mcfg.frame_size, device=dev, generator=g)
     user_codes = torch.randint(0, mcfg.q_bins, (B, 8, 1), device=dev, generator=g)

@@ -126,7 +126,7 @@ def roofline_lm(lm_gen, step_fn, args, sync, kv_rows=None):
         sites[site] = rec
     out["sites"] = sites
     # the largest site by time per step (at the mid-run depth the decode attention outweighs the dominant GEMM)
-    timed = {k: dict(v) for k, v in sites.items() if "frac" in v}
+    timed = {k: dict(v) for k, v in sites.items() if "frac" in v and v.get("ops_per_step", 0) > 0}
     if "L.ffn_in" in timed and mean_ms.value > 0:
         # this site's ops carry a SECOND event pair (the dominant-kernel tap above): rank it by that tap's own figure instead
         t = timed["L.ffn_in"]
