@@ -70,7 +70,11 @@ class QWeight:
           out32   = CA @ CB^T                                             (exact int32)
           y[b,n]  = out32[b, n] * (SCA[b] * SCB[n]) * (1 / (127 * 127))   (fp32)
       PARITY UNPINNED AGAINST bitsandbytes: no reference test exercises QLinear and the library cannot run here; this is a
-      restatement of its documented rule, not a check against its output.  Two deliberate differences, both no-ops in range:
+      restatement of its documented rule, not a check against its output.  One known point where the library's own variants
+      differ from each other and from this restatement: the scale 127 / SCA is the correctly rounded fp32 quotient here (and in
+      the engine), `tensor.reciprocal() * 127.0` in the library's torch backend (what PyTorch makes of `127.0 / tensor`), the
+      approximate `__fdividef` in its CUDA kernel - a code moves by one step where x * scale lands within an ulp of a rounding tie
+      (1 in 36 608 codes in tests/test_oracle_pinned.py::test_int8_rule_agrees_with_a_torch_restatement_of_the_library_ops).  Two deliberate differences, both no-ops in range:
       `x.half()` (bf16 -> fp16 is exact for |x| in [2^-14, 65504]; smaller values quantise to 0 either way) is skipped, and
       the result is rounded to the engine's activation type bf16 where bnb returns fp16.
     * act8 = False - weight-only dequantisation (activations stay bf16; the engine's `MMI_Q8_ACT=bf16` mode, rounds 1-3)."""
