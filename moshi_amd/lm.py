@@ -265,6 +265,25 @@ class LMModel:
         return self.config.existing_text_padding_id
 
     @property
+    def end_of_text_padding_id(self) -> int:
+        # lm.py:260-263: `existing_text_end_padding_id` (constructor default 0; no released config overrides it)
+        return 0
+
+    @property
+    def existing_text_padding_id(self) -> int:
+        return self.config.existing_text_padding_id
+
+    # lm.py:176-183 builds a ConditionProvider from the checkpoint's `conditioners`; turning attributes (a speaker wav, a text
+    # description) into tensors is not on the frame step and is out of scope here.  Callers that branch on
+    # `lm.condition_provider is not None` (run_inference.py:38, tts.py:449-460) see None and pass `condition_tensors` to LMGen.
+    condition_provider = None
+
+    def set_streaming_detached(self, streaming_detached: bool) -> None:
+        """streaming.py:78-86.  The reference detaches a module so that a parent's `.streaming()` does not reach it; an engine
+        handle has no parent module and is only ever put into streaming mode by a direct call, i.e. it is always detached."""
+        self._streaming_detached = bool(streaming_detached)
+
+    @property
     def zero_token_id(self) -> int:
         return -1
 
@@ -452,6 +471,10 @@ class LMGen:
             raise RuntimeError("Expected to find a streaming state for lm_gen.")
         buf = state["lm_gen"]
         self._lib.check(self._lib.mmi_lm_state_load(self.lm_model._handle, buf.data_ptr(), buf.numel(), int(state["offset_cpu"]), self._stream()))
+
+    def set_streaming_detached(self, streaming_detached: bool) -> None:
+        """streaming.py:78-86 (lm.py:579 calls it on the model): see LMModel.set_streaming_detached."""
+        self._streaming_detached = bool(streaming_detached)
 
     def set_exec_mask(self, exec_mask: torch.Tensor) -> None:
         assert self.is_streaming

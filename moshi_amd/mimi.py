@@ -175,6 +175,11 @@ class MimiModel:
         keep, ptr = self._mask_arg(reset_mask)
         self._lib.check(self._lib.mmi_mimi_reset(self._handle, ptr, self._stream()))
 
+    def set_streaming_detached(self, streaming_detached: bool) -> None:
+        """streaming.py:78-86: keeps a parent module's `.streaming()` from reaching this one.  An engine handle has no parent and
+        enters streaming mode only through its own `streaming()` / `streaming_forever()`: always detached; the flag is kept."""
+        self._streaming_detached = bool(streaming_detached)
+
     def set_exec_mask(self, exec_mask: torch.Tensor) -> None:
         assert self.is_streaming
         keep, ptr = self._mask_arg(exec_mask)

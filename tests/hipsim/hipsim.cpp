@@ -19,6 +19,42 @@ namespace {
 constexpr size_t kStackBytes = 256 * 1024;
 constexpr int kMaxThreads = 1024;
 
+// ---- fiber schedule ------------------------------------------------------------------------
+// On the GPU the waves of a workgroup run in no particular order between two barriers; the simulator's default (waves 0, 1, ...
+// one after the other, lanes 0..63 inside each) is ONE of those orders, and a kernel with a missing barrier (wave 1 reading what
+// wave 0 writes) passes under it by luck.  The schedule can therefore be perturbed: REVERSE walks waves and lanes backwards, RANDOM
+// draws a new permutation of the waves and of each wave's lanes at every scheduling pass (seeded by the block index, reproducible).
+// A kernel whose result is a function of its inputs alone gives the same bits under every schedule (tests/test_schedule_sim.py).
+enum Sched { SCHED_FORWARD = 0, SCHED_REVERSE = 1, SCHED_RANDOM = 2 };
+std::atomic<int> g_sched_mode{-1};
+std::atomic<uint64_t> g_sched_seed{1};
+
+int sched_mode() {
+    int m = g_sched_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    const char* e = getenv("HIPSIM_SCHED");           // forward | reverse | random[:seed]
+    m = SCHED_FORWARD;
+    if (e && !strncmp(e, "reverse", 7)) m = SCHED_REVERSE;
+    if (e && !strncmp(e, "random", 6)) {
+        m = SCHED_RANDOM;
+        if (e[6] == ':') g_sched_seed.store(strtoull(e + 7, nullptr, 10));
+    }
+    g_sched_mode.store(m);
+    return m;
+}
+
+struct Rng {
+    uint64_t s;
+    uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s * 0x2545F4914F6CDD1DULL; }
+};
+
+// fills order[0..n) with the visiting order of the indices 0..n-1 under the current schedule
+void fill_order(int* order, int n, int mode, Rng& rng) {
+    for (int i = 0; i < n; ++i) order[i] = mode == SCHED_REVERSE ? n - 1 - i : i;
+    if (mode == SCHED_RANDOM)
+        for (int i = n - 1; i > 0; --i) std::swap(order[i], order[(int)(rng.next() % (uint64_t)(i + 1))]);
+}
+
 enum State { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
 
 struct Fiber {
@@ -83,13 +119,21 @@ void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
     }
     const int nwaves = (n + 63) / 64;
     int live = n;
+    const int mode = sched_mode();
+    Rng rng{(g_sched_seed.load() * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)bid.x * 0x100000001B3ULL + bid.y * 7919u + bid.z * 104729u + 1)};
+    rng.next();
+    int wave_order[kMaxThreads / 64], lane_order[64];
     while (live > 0) {
         bool progressed = false;
-        for (int wv = 0; wv < nwaves; ++wv) {
+        fill_order(wave_order, nwaves, mode, rng);
+        for (int wi = 0; wi < nwaves; ++wi) {
+            const int wv = wave_order[wi];
             const int lo = wv * 64, hi = std::min(n, lo + 64);
             for (;;) {
                 bool ran = false;
-                for (int i = lo; i < hi; ++i) {
+                fill_order(lane_order, hi - lo, mode, rng);
+                for (int li = 0; li < hi - lo; ++li) {
+                    const int i = lo + lane_order[li];
                     Fiber& f = w->fibers[i];
                     if (f.state != RUNNABLE) continue;
                     w->cur = i;
@@ -231,6 +275,12 @@ void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>
     }
 }
 
+void set_schedule(int mode, uint64_t seed) {
+    g_sched_seed.store(seed ? seed : 1);
+    g_sched_mode.store(mode < 0 || mode > SCHED_RANDOM ? SCHED_FORWARD : mode);
+}
+int schedule() { return sched_mode(); }
+
 void sync_block() { yield_with(WAIT_BLOCK); }
 void sync_wave() { yield_with(WAIT_WAVE); }
 int lane_id() { return t_worker->cur & 63; }
@@ -290,3 +340,7 @@ hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+
+// C entry points for the tests (ctypes): 0 forward, 1 reverse, 2 random (seed)
+extern "C" void hipsim_set_schedule(int mode, unsigned long long seed) { hipsim::set_schedule(mode, seed); }
+extern "C" int hipsim_get_schedule(void) { return hipsim::schedule(); }

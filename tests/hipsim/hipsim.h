@@ -37,6 +37,10 @@ void* dyn_smem();
 
 int num_workers();
 void set_num_workers(int n);
+// order in which the waves of a block and the lanes of a wave are visited between two synchronisation points:
+// 0 forward (default), 1 reverse, 2 random (seed); also HIPSIM_SCHED=forward|reverse|random[:seed]
+void set_schedule(int mode, uint64_t seed);
+int schedule();
 
 }  // namespace hipsim
 

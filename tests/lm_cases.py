@@ -1195,12 +1195,15 @@ def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=No
 
 
 # ---- the step is a function of its inputs: two streams of one handle fed the same frames produce the same bits ----------------------
-def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, repeats=4, seed=77):
+def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, repeats=4, seed=77, before_repeat=None):
     """Round 5's root cause (the driver's round-4 failure) was a launch whose output changed from run to run; what caught it was
     comparing runs, not comparing with the checker.  Greedy, masks and a partial reset, hidden taps on: every repeat must equal the
     first in tokens, text / audio logits and the residual stream after the first and the last temporal layer, bit for bit."""
     sd = cached_lm_state_dict(cfg, seed)
-    if quantize:
+    if quantize == "fp8":
+        from moshi_amd.weights import quantize_lm_state_dict_fp8
+        sd = quantize_lm_state_dict_fp8(sd)
+    elif quantize:
         from moshi_amd.weights import quantize_lm_state_dict
         sd = quantize_lm_state_dict(sd)
     gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
@@ -1227,6 +1230,8 @@ def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, r
         return out
     first = run()
     for r in range(repeats):
+        if before_repeat is not None:       # the simulator's schedule test changes the fiber schedule between repeats
+            before_repeat(r)
         again = run()
         for s, (a, b) in enumerate(zip(first, again)):
             m = torch.from_numpy(plan[s][0])
