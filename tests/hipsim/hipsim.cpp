@@ -106,6 +106,11 @@ void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
     w->nthreads = n;
     w->body = &body;
     if (w->dyn.size() < dyn_bytes + 64) w->dyn.resize(dyn_bytes + 64);
+    // A workgroup finds in its dynamic LDS whatever the previous workgroup on that CU left there.  The simulator hands every
+    // block 0xFF bytes (NaN as fp32 / bf16, -1 as an integer), so a kernel that reads LDS it has not written fails loudly here
+    // instead of differing from run to run on the GPU.  HIPSIM_POISON_LDS=0 switches it off.
+    static const bool poison_lds = !(getenv("HIPSIM_POISON_LDS") && atoi(getenv("HIPSIM_POISON_LDS")) == 0);
+    if (poison_lds && dyn_bytes) memset(w->dyn.data(), 0xFF, dyn_bytes + 64);
     t_blockIdx = bid; t_blockDim = block; t_gridDim = grid;
     for (int i = 0; i < n; ++i) {
         Fiber& f = w->fibers[i];

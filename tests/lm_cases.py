@@ -15,11 +15,16 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 # Logits tolerance (bf16 model, fp32 accumulation; only summation order / attention-backend rounding differ):
 #   max |d| <= LOGIT_MAX_REL * max|ref|   and   mean |d| <= LOGIT_MEAN_REL * max|ref|   per (row, sampling site).
-# Measured: the numpy oracle sits at max 3.1 % / mean 0.9 % (median 1.2 % / 0.4 %) from the reference PyTorch CPU path
-# on the golden vectors - pure bf16 rounding-order noise through 2 + 8x2 transformer layers.  The ENGINE against the same
-# goldens on MI355X (profiles/r03_logs/parity_golden_{tiny,wide}_cuda.json): tiny worst max 3.12 % / mean 0.90 %, 7B widths x 1
-# layer worst max 2.38 % / mean 0.50 %.  Gate = worst measured x 1.5, rounded: max 3.12 % x 1.5 = 4.7 % -> 5 %; the mean gate
-# (1.2 %) is already tighter than 0.90 % x 1.5 and stays.
+# Yardstick: the distance between two CORRECT implementations of this bf16 model on the same inputs - the reference's PyTorch
+# CPU path (the golden vectors) and the numpy oracle - is max 3.12 % / mean 0.90 % of max|logit| in the worst of 162 (row,
+# site) pairs (median 1.2 % / 0.4 %): pure bf16 rounding-order noise through 2 + 8 x 2 transformer layers (the reviewer of
+# round 4 measured the reference moving 1.2 % against ITSELF between two hosts).  The gate is that distance x 1.6 (max) and
+# x 1.33 (mean): above the yardstick, because an engine is a third correct implementation and cannot be asked to sit closer to
+# the reference than the checker does, and below twice the yardstick - tests/test_oracle_pinned.py
+# (test_bf16_logit_gate_is_under_twice_the_distance_between_two_correct_implementations) re-measures the yardstick and holds
+# the gate inside [1 x, 2 x).  The ENGINE against the same goldens on MI355X sits AT the yardstick
+# (profiles/r05_logs/parity_golden_{tiny,wide}_cuda.json: tiny worst max 3.12 % / mean 0.90 %, 7B widths x 1 layer worst max
+# 2.33 % / mean 0.51 %).
 LOGIT_MAX_REL, LOGIT_MEAN_REL = 0.05, 0.012
 
 
@@ -157,9 +162,11 @@ def check_golden_wide(device, lib):
 # The reference ITSELF at the benchmark depth (tests/golden/make_golden_lm_full.py): Moshi-7B as loaders._lm_kwargs builds it,
 # 32 temporal layers, bf16 on the CPU, B = 2 with the rows one step apart, 4 greedy steps.  Two correct bf16 implementations
 # drift apart layer by layer under random-init weights (see FULL_DEPTH_FACTOR below), so the logits gate is FULL_WIDEN x the
-# shallow-model tolerance.  Measured against the reference at 32 layers (profiles/r03_logs/parity_golden_full_cuda.json,
-# parity_golden_full_oracle_cpu.txt): engine worst max 5.77 % / mean 1.13 % (text head 2.30 % / 0.44 %), numpy oracle worst max
-# 6.10 % / mean 1.15 %.  Gate = the larger x 1.5 = 9.2 % of max|logit| -> FULL_WIDEN = 9.2 / 5.
+# shallow-model tolerance.  Yardstick: the distance between the reference and the numpy oracle at 32 layers - two correct
+# implementations - is worst max 6.10 % / mean 1.15 % of max|logit| (parity_golden_full_oracle); gate = yardstick x 1.5 = 9.2 %
+# -> FULL_WIDEN = 9.2 / 5 (mean: 1.2 % x 1.85 = 2.2 %, x 1.9 the yardstick's mean); tests/test_oracle_pinned.py re-measures the
+# yardstick and holds the gate inside [1 x, 2 x) of it.  The engine on MI355X against the same file: worst max 4.85 % / mean
+# 1.09 % (text head 2.30 % / 0.44 %; profiles/r05_logs/parity_golden_full_cuda.json; round 3: 5.77 % / 1.13 %) - inside the yardstick.
 FULL_WIDEN = 1.85
 
 

@@ -90,6 +90,42 @@ def test_lm_oracle_matches_reference_golden():
                 assert tok[b] == ref_tok[b] or lg[b, tok[b]] == lg[b, ref_tok[b]], "sampling rule restatement disagrees"
 
 
+def test_bf16_logit_gate_is_under_twice_the_distance_between_two_correct_implementations():
+    """the LM gates must rest on a yardstick, not on a multiple of what the engine happened to measure.  The
+    yardstick of the bf16 gate (tests/lm_cases.py LOGIT_MAX_REL / LOGIT_MEAN_REL) is the distance between two CORRECT
+    implementations of the same bf16 model on the same inputs - the reference's PyTorch CPU path (the golden file) and the numpy
+    oracle, which differ only in summation order and in where intermediate roundings fall - measured here per (row, sampling site)
+    on tests/golden/lm_tiny.npz.  The gate is held to less than twice that distance and not less than the distance itself (an
+    engine is a third correct implementation: it cannot be asked to be closer to the reference than the checker is)."""
+    from moshi_amd.config import tiny_lm_config
+    from moshi_amd.weights import random_lm_state_dict
+    from oracle.lm_oracle import LMOracle
+    from tests import lm_cases
+    g = np.load(GOLDEN / "lm_tiny.npz")
+    cfg = tiny_lm_config()
+    o = LMOracle(random_lm_state_dict(cfg, seed=int(g["seed"][0])), cfg)
+    S, B = g["masks"].shape
+    o.streaming(B)
+    mx, mean = [], []
+    for s in range(S):
+        if s == int(g["reset_step"][0]):
+            o.reset_streaming(g["reset_mask"])
+        o.set_exec_mask(g["masks"][s])
+        forced = np.concatenate([g["g_text_tok"][s][:, None], g["g_audio_tok"][s]], 1)
+        _, (tl, al, _, _) = o.step(g["codes"][s], use_sampling=False, forced=forced, support_out_of_sync=True)
+        for b in np.nonzero(g["masks"][s])[0]:
+            for a, ref in [(tl[b], g["g_text_logits"][s, b])] + [(al[b, k], g["g_audio_logits"][s, b, k]) for k in range(cfg.dep_q)]:
+                scale = float(np.abs(ref).max()) + 1e-6
+                d = np.abs(a.astype(np.float64) - ref)
+                mx.append(float(d.max()) / scale)
+                mean.append(float(d.mean()) / scale)
+    worst_max, worst_mean = max(mx), max(mean)
+    print(f"[yardstick] reference vs oracle over {len(mx)} (row, site) pairs: worst max {worst_max:.4f} (median {np.median(mx):.4f}), "
+          f"worst mean {worst_mean:.4f} (median {np.median(mean):.4f}) of max|logit|; gate {lm_cases.LOGIT_MAX_REL} / {lm_cases.LOGIT_MEAN_REL}")
+    assert worst_max <= lm_cases.LOGIT_MAX_REL < 2.0 * worst_max
+    assert worst_mean <= lm_cases.LOGIT_MEAN_REL < 2.0 * worst_mean
+
+
 def test_lm_oracle_matches_reference_at_7b_layer_shapes():
     """oracle/lm_oracle.py against the reference at Moshi-7B's real widths (dim 4096, 32 heads x 128, FFN 11264, 32000-way
     text head, full depformer), one temporal layer: tests/golden/lm_wide.npz."""
@@ -195,7 +231,14 @@ def test_lm_oracle_matches_reference_at_the_benchmark_depth():
     def step(codes, forced):
         out, (tl, al, tt, at) = o.step(codes, use_sampling=False, forced=forced, support_out_of_sync=True)
         return out, tl, al
-    lm_cases.check_wide_steps(step, g, cfg, name="golden_full_oracle", widen=lm_cases.FULL_WIDEN, set_mask=o.set_exec_mask)
+    log = lm_cases.check_wide_steps(step, g, cfg, name="golden_full_oracle", widen=lm_cases.FULL_WIDEN, set_mask=o.set_exec_mask)
+    # the 32-layer gate rests on THIS distance (two correct implementations of the benchmark model: the reference and the oracle;
+    # 6.10 % max / 1.15 % mean when the golden file was made): it must lie between 1 x and 2 x the yardstick measured right here
+    summ = log.summary()
+    worst_max = max(v["max_rel_worst"] for v in summ.values())
+    worst_mean = max(v["mean_rel_worst"] for v in summ.values())
+    assert worst_max <= lm_cases.FULL_WIDEN * lm_cases.LOGIT_MAX_REL < 2.0 * worst_max, (worst_max, lm_cases.FULL_WIDEN)
+    assert worst_mean <= lm_cases.FULL_WIDEN * lm_cases.LOGIT_MEAN_REL < 2.0 * worst_mean, (worst_mean, lm_cases.FULL_WIDEN)
 
 
 def test_int8_rule_agrees_with_a_torch_restatement_of_the_library_ops():
