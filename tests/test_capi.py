@@ -118,3 +118,56 @@ def test_struct_layouts_of_the_header_equal_the_ctypes_binding(tmp_path):
             assert [n for n, *_ in cls._fields_] == structs[s], f"{s}: field names / order differ from the header"
         else:
             assert getattr(cls, f).offset == int(v), f"{s}.{f}: offset {v} in the header, {getattr(cls, f).offset} in the binding"
+
+
+def _header_prototypes():
+    """{function: (return class, [argument classes])} from the header; classes: ptr, i32, i64, u64, f32, f64, void."""
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "moshi_mi.h").read_text(), flags=re.S)
+    text = re.sub(r"typedef struct mmi_\w+ \{.*?\} mmi_\w+;", "", text, flags=re.S)      # struct bodies hold function pointers
+
+    def cls(t):
+        t = t.strip()
+        if "*" in t or re.search(r"\bmmi_stream\b", t):
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned(?= long)|struct)\b", "", t).split()
+        base = base[0] if base else "void"
+        return {"int": "i32", "int32_t": "i32", "mmi_status": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "size_t": "u64",
+                "float": "f32", "double": "f64", "void": "void"}[base]
+    out = {}
+    def top_level_split(arglist):                                   # a function-pointer argument holds commas of its own
+        parts, depth, cur = [], 0, ""
+        for ch in arglist:
+            depth += ch == "("
+            depth -= ch == ")"
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return parts + [cur]
+    for m in re.finditer(r"([\w\s\*]+?)\b(mmi_[a-z0-9_]+)\s*\(([^;{}]*)\)\s*;", text):
+        args = [a for a in top_level_split(m.group(3)) if a.strip() and a.strip() != "void"]
+        out[m.group(2)] = (cls(m.group(1)), [cls(re.sub(r"\b\w+\s*$", "", a) if not a.strip().endswith("*") else a) for a in args])
+    return out
+
+
+def test_prototypes_of_the_header_equal_the_ctypes_signatures():
+    """Argument count and machine class (pointer / 32-bit / 64-bit / float) of every entry point: header == binding."""
+    import ctypes as C
+    from moshi_amd import _capi
+
+    def cls(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or issubclass(t, (C._Pointer, C._CFuncPtr)):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int32: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_size_t: "u64",
+                C.c_float: "f32", C.c_double: "f64"}[t]
+    protos = _header_prototypes()
+    assert sorted(protos) == declared_symbols()
+    bad = []
+    for name, (res, args) in _capi.SIGNATURES.items():
+        mine = (cls(res), [cls(a) for a in args])
+        if mine != protos[name]:
+            bad.append((name, "header", protos[name], "binding", mine))
+    assert not bad, bad
