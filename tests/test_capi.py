@@ -171,3 +171,43 @@ def test_prototypes_of_the_header_equal_the_ctypes_signatures():
         if mine != protos[name]:
             bad.append((name, "header", protos[name], "binding", mine))
     assert not bad, bad
+
+
+_NULL_PROBE = r"""
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1])
+from moshi_amd import _capi
+lib = _capi.load(sys.argv[2])
+for name, (res, args) in sorted(_capi.SIGNATURES.items()):
+    vals = [None if (a in (C.c_void_p, C.c_char_p) or issubclass(a, (C._Pointer, C._CFuncPtr))) else (0.0 if a in (C.c_float, C.c_double) else 0)
+            for a in args]
+    r = getattr(lib, name)(*vals)
+    print(name, r if res is C.c_int else "-", flush=True)
+"""
+
+
+def test_every_entry_point_survives_null_arguments(sim_lib, tmp_path):
+    """"Return 0 / a negative status, never throw across the ABI" (SURVEY.md 8b): every entry point called with a NULL handle,
+    NULL pointers and zero sizes returns - a status < 0 from everything that acts on a handle, 0 from the pure queries
+    (`*_batch`, `*_state_bytes`, `*_launch_list`, ...) - and the process is still alive afterwards.  Host code only, so the
+    simulator build of the library (the same sources) answers for the product; run in a child process so that a crash is a
+    failed assertion, not a dead test worker."""
+    import subprocess
+    import sys
+    from moshi_amd import _capi
+    script = tmp_path / "null_probe.py"
+    script.write_text(_NULL_PROBE)
+    p = subprocess.run([sys.executable, str(script), str(ROOT), str(sim_lib.path)], capture_output=True, text=True, timeout=120)
+    seen = dict(ln.split() for ln in p.stdout.splitlines() if len(ln.split()) == 2)
+    assert p.returncode == 0, f"crashed after {list(seen)[-1:]}: {p.stderr[-400:]}"
+    assert sorted(seen) == sorted(_capi.SIGNATURES)
+    queries = {"mmi_version", "mmi_duplex_batch", "mmi_lm_has_hooks", "mmi_lm_launch_list", "mmi_lm_model_rows", "mmi_lm_profile_sites",
+               "mmi_lm_state_bytes", "mmi_lm_streaming_batch", "mmi_mimi_launch_list", "mmi_mimi_num_codebooks", "mmi_mimi_state_bytes",
+               "mmi_mimi_streaming_batch"}
+    for name, r in seen.items():
+        if r == "-":
+            continue
+        if name in queries:
+            assert int(r) == (3 if name == "mmi_version" else 0), (name, r)
+        else:
+            assert int(r) < 0, f"{name} accepted a NULL handle: {r}"
