@@ -518,6 +518,13 @@ class LMGen:
         needed = cfg.n_q - cfg.dep_q
         assert Ki >= needed, f"We expect {needed} tokens from the user stream, got {Ki}."
         codes = input_tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        if self.check:
+            # lm.py:703-711 asserts on the model's input after the delay ring; the only values that enter that ring from outside
+            # are these user codes (the rest the engine samples itself), so the same two conditions are asserted on them here -
+            # like the reference's, a host synchronisation that only a debugging run pays
+            user = codes[:, :needed]
+            assert not (user == self.lm_model.ungenerated_token_id).any(), user
+            assert (user <= self.lm_model.card).all(), user
         out = torch.empty(B, cfg.dep_q + 1, 1, device=self.device, dtype=torch.int64)
         tl = al = None
         tlp = alp = None

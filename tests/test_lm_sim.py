@@ -341,6 +341,17 @@ def test_none_during_delay_and_errors(sim_lib):
         assert out.shape == (3, 9, 1) and out.dtype == torch.int64
     with pytest.raises(AssertionError, match="no fuser"):   # lm.py:600-603
         lm_cases.LMGen(gen.lm_model, cfg_coef=2.0)
+    # check=True (lm.py:703-711): an ungenerated (-2) or out-of-range user code is an AssertionError, the zero token (-1) is not
+    chk = lm_cases.LMGen(gen.lm_model, use_sampling=False, check=True)
+    with chk.streaming(3):
+        ok = torch.from_numpy(g["codes"][0]).clone()
+        ok[0, 0, 0] = -1
+        chk.step(ok)
+        for bad in (-2, cfg.card + 1):
+            codes = ok.clone()
+            codes[1, 2, 0] = bad
+            with pytest.raises(AssertionError):
+                chk.step(codes)
 
 
 @pytest.mark.parametrize("name", ["a", "b", "c", "d"])
