@@ -26,6 +26,32 @@ from .lm import ConditionFuser, LMModel
 from .mimi import MimiModel
 
 
+# Names the reference's callers import from this module (server.py / run_inference.py argparse defaults, scripts): the released
+# repository and the file names inside it (loaders.py:28-35)
+SAMPLE_RATE = 24000
+FRAME_RATE = 12.5
+TEXT_TOKENIZER_NAME = "tokenizer_spm_32k_3.model"
+MOSHI_NAME = "model.safetensors"
+MOSHI_Q8_NAME = "model.q8.safetensors"
+MIMI_NAME = "tokenizer-e351c8d8-checkpoint125.safetensors"
+DEFAULT_REPO = "kyutai/moshiko-pytorch-bf16"
+
+
+def hf_get(filename: str | Path, hf_repo: str | None = None, check_local_file_exists: bool = False,
+           revision: str | None = None) -> Path:
+    """loaders.py:122-142 without the download: a Path, a `file://` name or a plain name is returned as a local path exactly as
+    the reference does; a name that the reference would fetch (`hf://...`, or a bare name with `hf_repo` that is not already a
+    local file) raises - the engine has no network path (section 9 of DESIGN.md)."""
+    if isinstance(filename, Path):
+        return filename
+    if filename.startswith("file://"):
+        return Path(filename[len("file://"):])
+    if filename.startswith("hf://") or (hf_repo is not None and not (check_local_file_exists and Path(filename).exists())):
+        raise RuntimeError(f"no network path in the engine: fetch {filename!r} (repository {hf_repo!r}) beforehand and pass the local file, "
+                           "or use CheckpointInfo.from_local(dir)")
+    return Path(filename)
+
+
 def _is_safetensors(path: Path | str) -> bool:          # loaders.py:319-320
     return Path(path).suffix in (".safetensors", ".sft", ".sfts")
 
@@ -210,7 +236,8 @@ class CheckpointInfo:
     model_id: dict = field(default_factory=dict)
 
     @staticmethod
-    def from_hf_repo(*args, **kwargs):
+    def from_hf_repo(hf_repo: str = DEFAULT_REPO, moshi_weights=None, mimi_weights=None, tokenizer=None, config_path=None,
+                     mimi_config_path=None, lora_weights=None, revision=None):
         raise RuntimeError("the engine has no network path: download the repository and use CheckpointInfo.from_local(dir)")
 
     @staticmethod
@@ -264,11 +291,18 @@ class CheckpointInfo:
         n = 8 if self.lm_config is None else max(self.lm_config["dep_q"], self.lm_config["n_q"] - self.lm_config["dep_q"])
         return get_mimi(self.mimi_weights, self.mimi_config, device=device, num_codebooks=n, **kwargs)
 
-    def get_moshi(self, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16, **kwargs) -> LMModel:
+    def get_text_tokenizer(self):                                                         # loaders.py:315-316
+        import sentencepiece
+        if self.tokenizer is None:
+            raise FileNotFoundError("this checkpoint names no tokenizer (`tokenizer_name` in config.json)")
+        return sentencepiece.SentencePieceProcessor(str(self.tokenizer))
+
+    def get_moshi(self, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16, load_weight: bool = True,
+                  **kwargs) -> LMModel:
         def hibiki(state):   # loaders.py:308-312: an early EOS (2) is read as PAD (3)
             w = state["text_emb.weight"].clone()
             w[2] = w[3]
             state["text_emb.weight"] = w
         kwargs.setdefault("lora_weights", self.lora_weights)                                         # loaders.py:305
-        return get_moshi_lm(self.moshi_weights, lm_kwargs=self.lm_config, device=device, dtype=dtype,
+        return get_moshi_lm(self.moshi_weights if load_weight else None, lm_kwargs=self.lm_config, device=device, dtype=dtype,
                             state_patch=hibiki if self.model_type == "hibiki" else None, **kwargs)   # loaders.py:293-313

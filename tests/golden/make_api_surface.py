@@ -33,8 +33,30 @@ def surface(cls):
     return out
 
 
+def module_surface(mod):
+    """Public names DEFINED in a module (functions with their parameters, classes with their public methods, constants)."""
+    out = {}
+    for name in sorted(n for n in dir(mod) if not n.startswith("_")):
+        obj = getattr(mod, name)
+        if inspect.isclass(obj) and obj.__module__ == mod.__name__:
+            methods = {}
+            for m in sorted(x for x in dir(obj) if not x.startswith("_") and callable(getattr(obj, x))):
+                try:
+                    methods[m] = [q for q in inspect.signature(getattr(obj, m)).parameters if q != "self"]
+                except (TypeError, ValueError):
+                    methods[m] = None
+            out[name] = {"kind": "class", "methods": methods}
+        elif inspect.isfunction(obj) and obj.__module__ == mod.__name__:
+            out[name] = {"kind": "function", "params": list(inspect.signature(obj).parameters)}
+        elif name.isupper() and isinstance(obj, (int, float, str)):
+            out[name] = {"kind": "constant", "value": obj}
+    return out
+
+
 if __name__ == "__main__":
+    from moshi.models import loaders
     res = {c.__name__: surface(c) for c in (MimiModel, LMModel, LMGen)}
+    res["module:loaders"] = module_surface(loaders)
     path = Path(__file__).resolve().parent / "api_surface.json"
     path.write_text(json.dumps(res, indent=1, sort_keys=True) + "\n")
     print(path, {k: len(v) for k, v in res.items()})
