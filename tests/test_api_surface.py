@@ -126,3 +126,9 @@ def test_hf_get_resolves_local_names_and_refuses_downloads(tmp_path):
     for args in (("hf://kyutai/moshiko-pytorch-bf16/model.safetensors",), ("model.safetensors", loaders.DEFAULT_REPO)):
         with pytest.raises(RuntimeError, match="no network"):
             loaders.hf_get(*args)
+
+
+def test_models_namespace_mirrors_the_reference_import_line():
+    """server.py:24 / run_inference.py:20 of the reference: `from .models import loaders, MimiModel, LMModel, LMGen`."""
+    from moshi_amd.models import LMGen as G, LMModel as L, MimiModel as M, get_mimi, get_moshi_lm, loaders  # noqa: F401
+    assert (M, L, G) == (MimiModel, LMModel, LMGen) and loaders.get_mimi is get_mimi and loaders.get_moshi_lm is get_moshi_lm
