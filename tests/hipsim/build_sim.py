@@ -99,9 +99,41 @@ def build_asan(out_dir: Path) -> Path:
     return lib
 
 
+def build_ubsan(out_dir: Path) -> Path:
+    """An UndefinedBehaviorSanitizer build of the simulator library (signed overflow, shifts out of range, misaligned or null
+    accesses, out-of-range float -> int conversions, array indexing past a declared bound in the kernel and engine sources):
+
+        python tests/hipsim/build_sim.py --ubsan /tmp/ubsan
+        LD_PRELOAD=$(dirname $(dirname /opt/rocm/lib/llvm/bin))/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so \
+        UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan/report MMI_SIM_LIB=/tmp/ubsan/libmoshi_sim_ubsan.so \
+        python -m pytest tests/test_mimi_sim.py tests/test_lm_sim.py tests/test_batcher_sim.py tests/test_duplex_sim.py -m "not gpu"
+
+    Reports are recoverable (the suite runs to its end) and land in /tmp/ubsan/report.<pid>."""
+    out_dir.mkdir(parents=True, exist_ok=True)
+    flags = [_cxx(), "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value", "-Wno-psabi",
+             "-fsanitize=undefined,float-cast-overflow", "-fno-omit-frame-pointer", f"-I{HERE}", f"-I{CSRC}"]
+    jobs, objs = [], []
+    for name in SOURCES:
+        obj = out_dir / (Path(name).stem + ".ubsan.o")
+        jobs.append(subprocess.Popen(flags + ["-x", "c++", "-c", str(CSRC / name), "-o", str(obj)]))
+        objs.append(obj)
+    obj = out_dir / "hipsim.ubsan.o"
+    jobs.append(subprocess.Popen(flags + ["-c", str(HERE / "hipsim.cpp"), "-o", str(obj)]))
+    objs.append(obj)
+    if any(p.wait() != 0 for p in jobs):
+        raise RuntimeError("ubsan sim build failed")
+    lib = out_dir / "libmoshi_sim_ubsan.so"
+    subprocess.check_call([_cxx(), "-shared", "-fPIC", "-pthread", "-fsanitize=undefined,float-cast-overflow", "-shared-libsan",
+                           "-o", str(lib)] + [str(o) for o in objs])
+    return lib
+
+
 if __name__ == "__main__":
     if "--asan" in sys.argv:
         print(build_asan(Path(sys.argv[sys.argv.index("--asan") + 1])))
+        sys.exit(0)
+    if "--ubsan" in sys.argv:
+        print(build_ubsan(Path(sys.argv[sys.argv.index("--ubsan") + 1])))
         sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
