@@ -1,0 +1,139 @@
+"""Edge cases of the streaming control surface (`set_exec_mask`, `reset_streaming(mask | None)`, `streaming(B)`)
+against the numpy oracle, on the simulator: a step in which NO row executes, a reset before the first step, a reset of every row
+(`None`) in mid-run, a reset of a row that does not execute in that step, the same handle streaming a second time with another
+batch size, several frames through one codec call under a mask.  The seeded cases of tests/{mimi,lm}_cases.py always keep row 0
+running and reset one row once; these are the schedules a session scheduler produces at its edges (a server with no traffic
+steps nothing; a slot is reset while its neighbour waits for audio)."""
+import numpy as np
+import pytest
+import torch
+
+from moshi_amd import MimiModel, tiny_mimi_config
+from moshi_amd.config import tiny_lm_config
+from moshi_amd.lm import LMGen, LMModel
+from moshi_amd.weights import random_lm_state_dict, random_mimi_state_dict
+from oracle.lm_oracle import LMOracle
+from oracle.mimi_oracle import MimiOracle
+from tests import lm_cases, mimi_cases
+
+T, F_ = True, False
+# (exec mask, reset) per step for three rows; reset: None = no call, "all" = reset_streaming(None), or a mask
+SCRIPT = [
+    ([T, T, T], [F_, T, F_]),       # a reset before anything ran
+    ([F_, F_, F_], None),           # nothing executes: every state must come through untouched
+    ([T, F_, T], None),
+    ([T, T, T], "all"),             # every row starts over in mid-run
+    ([T, T, F_], [F_, F_, T]),      # row 2 is reset but does not execute in this step
+    ([F_, T, T], None),
+    ([T, T, T], None),
+]
+
+
+def _reset_args(reset, B):
+    if reset is None:
+        return None
+    return np.ones(B, bool) if isinstance(reset, str) else np.array(reset, bool)
+
+
+def test_mimi_control_surface_edges_match_the_oracle(sim_lib):
+    cfg = tiny_mimi_config()
+    sd = random_mimi_state_dict(cfg, seed=3)
+    m = MimiModel(sd, cfg, device="cpu", max_batch=4, num_codebooks=5, lib=sim_lib)
+    orc = MimiOracle(sd, cfg, num_codebooks=5)
+    rng = np.random.default_rng(3)
+    B, fs = 3, cfg.frame_size
+    orc.streaming(B)
+    with m.streaming(B):
+        for f, (mask, reset) in enumerate(SCRIPT):
+            mask = np.array(mask, bool)
+            r = _reset_args(reset, B)
+            if r is not None:
+                orc.reset_streaming(r)
+                m.reset_streaming(None if isinstance(reset, str) else torch.from_numpy(r))
+            orc.set_exec_mask(mask)
+            m.set_exec_mask(torch.from_numpy(mask))
+            x = (0.3 * rng.standard_normal((B, 1, fs))).astype(np.float32)
+            co, ce = orc.encode(x), m.encode(torch.from_numpy(x)).numpy()
+            codes = rng.integers(0, cfg.q_bins, (B, 5, 1))
+            po, pe = orc.decode(codes), m.decode(torch.from_numpy(codes)).numpy()
+            for b in np.nonzero(mask)[0]:
+                assert np.array_equal(ce[b], co[b]), f"frame {f} row {b}: codes"
+                assert mimi_cases.close(pe[b], po[b], mimi_cases.PCM_ATOL, mimi_cases.PCM_RTOL), f"frame {f} row {b}: pcm"
+    # the same handle, another batch size: a fresh stream equals a fresh oracle (nothing of the first stream survives)
+    orc2 = MimiOracle(sd, cfg, num_codebooks=5)
+    orc2.streaming(2)
+    with m.streaming(2):
+        for f in range(2):
+            x = (0.3 * rng.standard_normal((2, 1, fs))).astype(np.float32)
+            assert np.array_equal(m.encode(torch.from_numpy(x)).numpy(), orc2.encode(x)), f"second stream frame {f}"
+
+
+def test_mimi_several_frames_per_call_under_a_mask_match_frame_by_frame_calls(sim_lib):
+    """compression.py:338-374 accepts any multiple of the frame size in streaming mode; the mask holds for the whole call."""
+    cfg = tiny_mimi_config()
+    sd = random_mimi_state_dict(cfg, seed=4)
+    rng = np.random.default_rng(4)
+    B, fs = 3, cfg.frame_size
+    x = torch.from_numpy((0.3 * rng.standard_normal((B, 1, 4 * fs))).astype(np.float32))
+    masks = [torch.tensor([T, F_, T]), torch.tensor([T, T, F_])]
+
+    def run(chunked):
+        m = MimiModel(sd, cfg, device="cpu", max_batch=B, num_codebooks=5, lib=sim_lib)
+        codes, pcm = [], []
+        with m.streaming(B):
+            for i, mask in enumerate(masks):
+                m.set_exec_mask(mask)
+                part = x[..., 2 * i * fs:(2 * i + 2) * fs]
+                pieces = [part] if chunked else [part[..., :fs], part[..., fs:]]
+                for p in pieces:
+                    c = m.encode(p)
+                    codes.append(c.numpy().copy())
+                    pcm.append(m.decode(c).numpy().copy())
+        return np.concatenate(codes, -1), np.concatenate(pcm, -1)
+    c2, p2 = run(True)
+    c1, p1 = run(False)
+    for i, mask in enumerate(masks):
+        for b in np.nonzero(mask.numpy())[0]:
+            assert np.array_equal(c2[b, :, 2 * i:2 * i + 2], c1[b, :, 2 * i:2 * i + 2])
+            a, r = p2[b, :, 2 * i * fs:(2 * i + 2) * fs], p1[b, :, 2 * i * fs:(2 * i + 2) * fs]
+            assert mimi_cases.close(a, r, mimi_cases.PCM_ATOL, mimi_cases.PCM_RTOL)
+
+
+def test_lm_control_surface_edges_match_the_oracle(sim_lib):
+    cfg = tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=5)
+    lm = LMModel(sd, cfg, device="cpu", max_batch=4, lib=sim_lib)
+    gen = LMGen(lm, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sd, cfg)
+    rng = np.random.default_rng(5)
+    B = 3
+    orc.streaming(B)
+
+    def compare(step, mask, codes, o, g):
+        oo, (otl, oal, ott, oat) = o.step(codes, use_sampling=False, support_out_of_sync=True)
+        forced = np.concatenate([ott[:, None], oat], 1)
+        out, tl, al = g.step_with_taps(torch.from_numpy(codes), forced_tokens=torch.from_numpy(forced))
+        out, tl, al = out.numpy(), tl.numpy(), al.numpy()
+        for b in range(len(mask)):
+            if not mask[b]:
+                assert (out[b] == -2).all(), f"step {step} row {b}: a row that does not execute returns the ungenerated token (lm.py:781-782)"
+                continue
+            assert np.array_equal(out[b], oo[b]), f"step {step} row {b}: ring output"
+            assert lm_cases.logits_close(tl[b], otl[b]), f"step {step} row {b}: text logits"
+            for k in range(cfg.dep_q):
+                assert lm_cases.logits_close(al[b, k], oal[b, k]), f"step {step} row {b} cb {k}"
+    with gen.streaming(B):
+        for s, (mask, reset) in enumerate(SCRIPT + SCRIPT[2:]):        # long enough to pass the delays after the last reset
+            mask = np.array(mask, bool)
+            r = _reset_args(reset, B)
+            if r is not None:
+                orc.reset_streaming(r)
+                gen.reset_streaming(None if isinstance(reset, str) else torch.from_numpy(r))
+            orc.set_exec_mask(mask)
+            gen.set_exec_mask(torch.from_numpy(mask))
+            compare(s, mask, rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1)), orc, gen)
+    orc2 = LMOracle(sd, cfg)
+    orc2.streaming(2)
+    with gen.streaming(2):                                              # the same handle, another batch size
+        for s in range(4):
+            compare(100 + s, np.ones(2, bool), rng.integers(0, cfg.card, (2, cfg.n_q - cfg.dep_q, 1)), orc2, gen)
