@@ -325,10 +325,12 @@ int launch_conv_plan(hipStream_t s, const ConvGemmArgs& a, const ConvPlan& p) {
 int plan_conv(MmiArena& arena, ConvGemmArgs& a, ConvPlan* p) {
     const int N = a.Ntot;
     if (a.Cin * a.K >= (1 << 17) || N >= (1 << 17) || a.T_out >= (1 << 11) || a.K >= (1 << 11))
-        return mmi_fail(MMI_ERR_UNSUPPORTED, "conv dimensions outside the range of the kernels' index arithmetic");
+        return mmi_fail(MMI_ERR_UNSUPPORTED, "conv dimensions outside the range of the kernels' index arithmetic (sessions x samples per frame "
+                                             "must stay below 131072: 68 sessions per handle at 1920 samples per frame)");
     if (N > 128) {
         if (a.first || a.x_packed || a.out_mode != MMI_GOUT_NATURAL)
-            return mmi_fail(MMI_ERR_UNSUPPORTED, "wide conv path does not take replicate padding / packed operands");
+            return mmi_fail(MMI_ERR_UNSUPPORTED, "more than 128 columns (sessions x time steps per frame) on a conv with replicate padding or packed "
+                                                 "operands: lower max_batch (the 25 Hz layers of the released codec take 64 sessions)");
         p->wide = true;
         const int nsub = mmi_cdiv(N, 32);
         // m-tiles per wave (each gathered + ELU'd operand element is reused MTB times) vs. waves in flight:

@@ -137,3 +137,21 @@ def test_lm_control_surface_edges_match_the_oracle(sim_lib):
     with gen.streaming(2):                                              # the same handle, another batch size
         for s in range(4):
             compare(100 + s, np.ones(2, bool), rng.integers(0, cfg.card, (2, cfg.n_q - cfg.dep_q, 1)), orc2, gen)
+
+
+def test_maximum_batch_sizes(sim_lib):
+    """The largest batch a handle takes (64 sessions per GPU: BASELINE configs[4]) against the oracle, and what lies beyond it is
+    refused loudly at construction / at the first plan, with a message that names the limit - never computed wrongly."""
+    cfg = tiny_lm_config()
+    lm_cases.oracle_vs_engine("cpu", sim_lib, cfg, seed=164, B=64, S=2)
+    with pytest.raises(NotImplementedError, match="max_batch > 64"):
+        LMModel(random_lm_state_dict(cfg, seed=1), cfg, device="cpu", max_batch=65, lib=sim_lib)
+    mcfg = tiny_mimi_config()
+
+    def make(sd, c, K, max_batch=64):
+        return MimiModel(sd, c, device="cpu", max_batch=max_batch, num_codebooks=K, lib=sim_lib)
+    mimi_cases.oracle_vs_engine(make, "cpu", mcfg, seed=7, B=64, F=2, K=5)
+    with pytest.raises(NotImplementedError, match="lower max_batch"):
+        m = MimiModel(random_mimi_state_dict(mcfg, seed=7), mcfg, device="cpu", max_batch=256, num_codebooks=5, lib=sim_lib)
+        with m.streaming(256):
+            m.encode(torch.zeros(256, 1, mcfg.frame_size))
