@@ -83,7 +83,7 @@ def build_asan(out_dir: Path) -> Path:
     instrumented build misses - as in round 3)."""
     out_dir.mkdir(parents=True, exist_ok=True)
     flags = [_cxx(), "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value", "-Wno-psabi",
-             "-fsanitize=address", "-fno-omit-frame-pointer", f"-I{HERE}", f"-I{CSRC}"]
+             "-fsanitize=address", "-fno-omit-frame-pointer", "-DHIPSIM_UCONTEXT", f"-I{HERE}", f"-I{CSRC}"]
     jobs, objs = [], []
     for name in SOURCES:
         obj = out_dir / (Path(name).stem + ".asan.o")
@@ -111,7 +111,7 @@ def build_ubsan(out_dir: Path) -> Path:
     Reports are recoverable (the suite runs to its end) and land in /tmp/ubsan/report.<pid>."""
     out_dir.mkdir(parents=True, exist_ok=True)
     flags = [_cxx(), "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value", "-Wno-psabi",
-             "-fsanitize=undefined,float-cast-overflow", "-fno-omit-frame-pointer", f"-I{HERE}", f"-I{CSRC}"]
+             "-fsanitize=undefined,float-cast-overflow", "-fno-omit-frame-pointer", "-DHIPSIM_UCONTEXT", f"-I{HERE}", f"-I{CSRC}"]
     jobs, objs = [], []
     for name in SOURCES:
         obj = out_dir / (Path(name).stem + ".ubsan.o")

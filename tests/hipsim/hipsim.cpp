@@ -57,8 +57,70 @@ void fill_order(int* order, int n, int mode, Rng& rng) {
 
 enum State { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
 
+// ---- context switch --------------------------------------------------------------------------
+// glibc's swapcontext saves and restores the signal mask with a system call on every switch - a third of the simulator's run time
+// (a kernel thread yields at every shuffle, MFMA and barrier).  On x86-64 the switch is therefore a dozen instructions of our own:
+// callee-saved registers, the SSE / x87 control words and the stack pointer.  HIPSIM_UCONTEXT (set by the sanitizer builds, whose
+// runtime follows swapcontext) or any other architecture keeps the portable form.
+#if defined(__x86_64__) && !defined(HIPSIM_UCONTEXT)
+#define HIPSIM_ASM_SWITCH 1
+struct Ctx { void* sp; };
+extern "C" void hipsim_switch(Ctx* from, Ctx* to);
+asm(R"(
+    .text
+    .globl hipsim_switch
+    .type hipsim_switch,@function
+hipsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipsim_switch,.-hipsim_switch
+)");
+// a fresh context whose first switch-in "returns" into entry() on its own stack
+inline void ctx_make(Ctx* c, char* stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+    uint64_t* sp = (uint64_t*)top;
+    *--sp = 0;                        // the return address entry() would return to (it never does): rsp = 16 n + 8 at its first instruction
+    *--sp = (uint64_t)entry;          // popped by hipsim_switch's ret
+    for (int i = 0; i < 6; ++i) *--sp = 0;      // rbp rbx r12 r13 r14 r15
+    --sp;
+    ((uint32_t*)sp)[0] = 0x1F80;      // MXCSR: all exceptions masked, round to nearest
+    ((uint32_t*)sp)[1] = 0x037F;      // x87 control word: the same
+    c->sp = sp;
+}
+#else
+#define HIPSIM_ASM_SWITCH 0
+struct Ctx { ucontext_t uc; };
+inline void hipsim_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+inline void ctx_make(Ctx* c, char* stack, size_t bytes, void (*entry)()) {
+    getcontext(&c->uc);
+    c->uc.uc_stack.ss_sp = stack;
+    c->uc.uc_stack.ss_size = bytes;
+    c->uc.uc_link = nullptr;
+    makecontext(&c->uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     int state;
     dim3 tid;
 };
@@ -66,7 +128,7 @@ struct Fiber {
 struct Worker {
     std::vector<Fiber> fibers;
     char* stacks = nullptr;          // kMaxThreads * kStackBytes, lazily committed
-    ucontext_t sched;
+    Ctx sched;
     int cur = -1;
     int nthreads = 0;
     const std::function<void()>* body = nullptr;
@@ -89,14 +151,15 @@ void trampoline() {
     (*w->body)();
     Fiber& f = w->fibers[w->cur];
     f.state = DONE;
-    swapcontext(&f.ctx, &w->sched);
+    hipsim_switch(&f.ctx, &w->sched);
+    abort();                          // a finished fiber is never resumed
 }
 
 void yield_with(int st) {
     Worker* w = t_worker;
     Fiber& f = w->fibers[w->cur];
     f.state = st;
-    swapcontext(&f.ctx, &w->sched);
+    hipsim_switch(&f.ctx, &w->sched);
 }
 
 void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
@@ -116,11 +179,7 @@ void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
         Fiber& f = w->fibers[i];
         f.state = RUNNABLE;
         f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = w->stacks + (size_t)i * kStackBytes;
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        ctx_make(&f.ctx, w->stacks + (size_t)i * kStackBytes, kStackBytes, trampoline);
     }
     const int nwaves = (n + 63) / 64;
     int live = n;
@@ -143,7 +202,7 @@ void run_block(Worker* w, dim3 grid, dim3 block, dim3 bid, size_t dyn_bytes,
                     if (f.state != RUNNABLE) continue;
                     w->cur = i;
                     t_threadIdx = f.tid;
-                    swapcontext(&w->sched, &f.ctx);
+                    hipsim_switch(&w->sched, &f.ctx);
                     ran = true;
                     if (f.state == DONE) --live;
                 }

@@ -418,7 +418,7 @@ def test_full_depth_checker_plumbing_on_the_tiny_model(sim_lib):
 
 def test_rng_sampling_statistics(sim_lib):
     """The sampler's production form (on-device RNG, no rank computation) on the simulator: a coarser frequency check."""
-    lm_cases.rng_sampling_statistics("cpu", sim_lib, iters=5, tol=0.1)
+    lm_cases.rng_sampling_statistics("cpu", sim_lib, iters=3, tol=0.13)
 
 
 def test_step_hooks_see_and_modify_the_step_like_the_reference(sim_lib):
