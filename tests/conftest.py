@@ -33,6 +33,14 @@ def pytest_cmdline_main(config):
     return None
 
 
+def pytest_collection_modifyitems(config, items):
+    """CPU suite only: the one long test (the 32-layer oracle against the reference's own run: ~3 minutes of numpy on 15 GB of
+    weights) starts FIRST, so that it runs beside the rest instead of after it.  The GPU suite keeps its file order (core first)."""
+    if "not gpu" not in (config.getoption("markexpr", "") or ""):
+        return
+    items.sort(key=lambda it: 0 if "at_the_benchmark_depth" in it.nodeid else 1)      # stable: everything else keeps its place
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
