@@ -119,4 +119,9 @@ def main():
 
 
 if __name__ == "__main__":
+    # python tests/golden/make_native_selftest.py [batch [out_dir]]   (default: 2 sessions -> native_selftest/; 18 sessions, the 32-row
+    # batch tile and the wide-batch conv kernels -> native_selftest_b18/)
+    if len(sys.argv) > 1:
+        B = int(sys.argv[1])
+        OUT = Path(sys.argv[2]) if len(sys.argv) > 2 else OUT.parent / f"native_selftest_b{B}"
     main()

@@ -23,6 +23,10 @@ def test_native_selftest_passes_on_the_simulator_build(sim_lib, tmp_path):
     p = subprocess.run([str(exe), str(FIXTURE)], capture_output=True, text=True, timeout=300, env={"MMI_NO_GRAPH": "1"})
     assert p.returncode == 0 and "SELFTEST PASSED" in p.stdout, p.stdout + p.stderr
     assert "0 of 30 code indices differ" in p.stdout and "0 of 90 token-ring outputs differ" in p.stdout
+    # 18 sessions: the 32-row batch tile of the LM and the wide-batch conv kernels of the codec (native_selftest_b18/)
+    p = subprocess.run([str(exe), str(FIXTURE.parent / "native_selftest_b18")], capture_output=True, text=True, timeout=300, env={"MMI_NO_GRAPH": "1"})
+    assert p.returncode == 0 and "SELFTEST PASSED" in p.stdout, p.stdout + p.stderr
+    assert "0 of 270 code indices differ" in p.stdout and "0 of 810 token-ring outputs differ" in p.stdout
 
 
 def test_recorded_expectations_are_what_the_oracle_computes_today(tmp_path, monkeypatch):
