@@ -129,3 +129,29 @@ def test_mimi_wide_batch_kernels_are_independent_of_the_wave_schedule(sim_lib, m
 def test_duplex_pipeline_is_independent_of_the_wave_schedule(sim_lib):
     with schedule(sim_lib, RANDOM, 11):
         assert duplex_cases.check_pipeline_is_bit_identical("cpu", sim_lib, B=3, steps=6, use_sampling=True, join_every=3) >= 4
+
+
+def test_full_size_codec_at_the_c2_batch_is_independent_of_the_wave_schedule(sim_lib):
+    """The released codec's shapes, 8 streams (BASELINE configs[1]): every kernel at its production tiling (the wide-batch convs, the
+    split-K GEMMs of the 12.5 / 25 Hz layers, both transformers, the RVQ).  ~1 minute.  (The LM's benchmark kernels at the 7B widths
+    take minutes per run: tests/tools/sim_full_width_schedules.py, profiles/r05_logs/sim_full_width_schedules.log.)"""
+    from moshi_amd import MimiConfig
+    from moshi_amd.weights import random_mimi_state_dict
+    cfg = MimiConfig()
+    sd = random_mimi_state_dict(cfg, seed=3)
+    rng = np.random.default_rng(3)
+    B, F = 8, 2
+    x = torch.from_numpy((0.1 * rng.standard_normal((B, 1, F * cfg.frame_size))).astype(np.float32))
+
+    def run():
+        m = MimiModel(sd, cfg, device="cpu", max_batch=B, num_codebooks=8, lib=sim_lib)
+        with m.streaming(B):
+            codes = m.encode(x)
+            pcm = m.decode(codes)
+        return codes.numpy().copy(), pcm.numpy().copy()
+    codes0, pcm0 = run()
+    for mode, seed in SCHEDULES[:2]:
+        with schedule(sim_lib, mode, seed):
+            codes, pcm = run()
+        assert np.array_equal(codes, codes0), f"schedule {(mode, seed)}: codes differ"
+        assert np.array_equal(pcm.view(np.uint32), pcm0.view(np.uint32)), f"schedule {(mode, seed)}: PCM differs"
