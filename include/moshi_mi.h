@@ -243,7 +243,8 @@ int mmi_mimi_device(const mmi_mimi* m);
 /* Engine counters for tests / diagnostics.  which = 0: GEMM launches (or captured graph nodes) that took the LDS-resident
  * kernel (k_gemm_xlds); 1: bit v set = step program v (short-ring / deep-ring decode attention) is captured and instantiated -
  * both are from the stream's first step on, so that the switch is never a capture inside a live session; 2: the host's bound on
- * the ring depth (steps since streaming_start / seek / the offsets of a restored snapshot). */
+ * the ring depth (steps since streaming_start / seek / the offsets of a restored snapshot); 3: the depth transformer's MFMA tile
+ * (16 at <= 32 sessions with bf16 weights, else 32). */
 int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which);
 /* LMGen.step_with_extra_heads (lm.py:793-807): softmax(extra_head(transformer_out)) of the LAST step for every head:
  * probs f32 [model rows, extra_heads_num_heads, extra_heads_dim]. */

@@ -176,6 +176,19 @@ int create_impl(mmi_duplex* d) {
     MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)F_COUNT * 16 * sizeof(long)));
     MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)F_COUNT * 16 * sizeof(long)));
     int lo = 0, hi = 0;
+    // MMI_DUPLEX_CODEC_CUS=n (experiment, round 6): the codec streams confined to n of the CUs (a CU mask of n bits, which the driver
+    // deals out over the XCDs), so that the depth transformer's launches - 96..176 workgroups that need a whole CU's wave slots each -
+    // find free CUs while the codec of the neighbouring frames runs beside them; such streams have the default priority
+    const int codec_cus = getenv("MMI_DUPLEX_CODEC_CUS") ? atoi(getenv("MMI_DUPLEX_CODEC_CUS")) : 0;
+    if (codec_cus > 0 && codec_cus < 256) {
+        unsigned mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < codec_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+        int plo = 0, phi = 0;
+        if (hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && plo != phi) MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, plo));
+        else MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sL, hipStreamNonBlocking));
+        MMI_HIP_CHECK(hipExtStreamCreateWithCUMask(&d->sE, 8, mask));
+        MMI_HIP_CHECK(hipExtStreamCreateWithCUMask(&d->sD, 8, mask));
+    } else
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, lo));
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, hi));

@@ -19,6 +19,8 @@ struct GemmW {              // one packed nn.Linear
     int wq = 0;               // 0 bf16, 1 int8, 2 fp8
     float xinv = 1.f;         // fp8: 1 / input_scale
     size_t bytes = 0;
+    int T = 32;               // the MFMA tile the weight is packed for (lm->T; the depth transformer's linears: lm->Td) - also the
+                              // tile of the packed activation operand it reads and of a packed output it writes
 };
 
 struct LayerW {
@@ -43,7 +45,13 @@ struct mmi_lm {
     mmi_lm_cfg cfg;
     int device = -1;                // HIP device the handle lives on (current at create); see MmiDeviceGuard
     int max_batch = 0;
-    int T = 32;                     // MFMA tile of the whole model: 16 when max_batch <= 16, else 32 (lm_kernels.h)
+    int T = 32;                     // MFMA tile of the temporal transformer and the heads: 16 when max_batch <= 16, else 32 (lm_kernels.h)
+    int Td = 32;                    // MFMA tile of the depth transformer (its linears, dx / dxn / datt / dhb): T.  MMI_DEP_TILE=16 (17..32
+                                    // sessions, bf16): two 16-row batch tiles per 16-row weight tile - measured in round 6 inside the step
+                                    // (profiles/r06_logs/ab_dep_tile_once.txt): in_proj -0.14 us, linear_out -0.6, but the gated
+                                    // linear_in +3.0 (352 tiles at 128 registers: spills) and out_proj +0.3 -> +0.15 ms per step; the
+                                    // microbenchmark's -0.13 ms (round 5, independent launches) does not survive the dependent chain.
+                                    // Kept as an opt-in: the boundaries are row-major either way (dpre, dqkv, the logits)
     int q8 = -1;                    // -1 undecided, 0 bf16 linears, 1 int8 linears (`weight` int8 + `weight_scb`, utils/quantize.py),
                                     // 2 fp8 linears (`weight` e4m3fn + `weight_scale` [+ `input_scale`]) run on the fp8 MFMA
     int NC = 0, CT = 0, max_delay = 0;
@@ -175,7 +183,7 @@ __global__ void k_scb_to_scale(const float* __restrict__ scb, float* __restrict_
 
 // wp_dst / scale_dst: pack into a slice of a caller-owned allocation instead of a fresh one (see load_dep_in_group)
 int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N, int K, int gate_hidden, GemmW* g,
-                void* wp_dst = nullptr, float* scale_dst = nullptr, float* scb_dst = nullptr) {
+                void* wp_dst = nullptr, float* scale_dst = nullptr, float* scb_dst = nullptr, int tile = 0) {
     const mmi_tensor_desc* d = W.find(name);
     if (!d) return mmi_fail(MMI_ERR_MISSING_WEIGHT, "missing weight: " + name);
     if (d->dtype != MMI_BF16 && d->dtype != MMI_I8 && d->dtype != MMI_F8E4M3)
@@ -186,7 +194,8 @@ int load_linear(mmi_lm* lm, const MmiWeights& W, const std::string& name, int N,
     lm->q8 = q8;
     if (d->shape[0] != N || d->shape[1] != K) return mmi_fail(MMI_ERR_SHAPE, "shape mismatch for " + name);
     if (K % 8 != 0) return mmi_fail(MMI_ERR_UNSUPPORTED, "in_features must be a multiple of 8: " + name);
-    const int TN = lm->T;
+    const int TN = tile ? tile : lm->T;
+    g->T = TN;
     g->K = K;
     g->gate = gate_hidden > 0 ? 1 : 0;
     g->N = gate_hidden > 0 ? gate_hidden : N;
@@ -371,7 +380,7 @@ XldsPlan plan_xlds(const mmi_lm* lm, const GemmW& g, const GemmArgs& a, int mt) 
     XldsPlan p{false, 0, 0, 0, false};
     const char* en = getenv("MMI_GEMM_LDS");
     const char mode = en && en[0] ? en[0] : (g.wq == 0 ? '2' : '0');
-    if (mode == '0' || lm->T != 32 || mt > 2) return p;
+    if (mode == '0' || g.T != 32 || mt > 2) return p;
     if (a.epi != MMI_EPI_GATE && a.epi != MMI_EPI_ROPE_KV && a.epi != MMI_EPI_STORE) return p;   // no prefetched addend, no split-K
     int cus = 256;                                             // MI355X: 256 CUs
     const char* tg = getenv("MMI_GEMM_LDS_GRID");              // test hook: small grids / short chunks for the tiny shapes
@@ -426,14 +435,43 @@ int launch_xlds(hipStream_t s, const XldsPlan& p, const GemmArgs& a) {
     return p.stagger ? launch_xlds_kc<MT, true, 0>(s, p, a) : launch_xlds_kc<MT, false, 0>(s, p, a);
 }
 
+// k_gemm_xp_once (a wave's whole K-slice requested before its first MFMA) for the GEMMs k_gemm_xp would walk in three or more
+// dependent memory round trips although they are a latency chain, not a stream: bf16 weights behind at most 256 workgroups of 8
+// waves whose slice is longer than the two register buffers of k_gemm_xp (2 x 4 k-steps) and short enough for the registers -
+// the depth transformer's linear_out (2816 -> 1024: 22 k-steps per wave at the 32-row tile, 11 at the 16-row tile).
+// Returns the instantiated slice length, 0 = k_gemm_xp.  MMI_GEMM_ONCE=0: off (same-box A/B; bit-identical either way); "a": every
+// bf16 GEMM whose slices fit (test hook: the tiny shapes, always on 8 waves).
+int once_kmax(const GemmW& g, const GemmPlan& p, int mt, const GemmArgs& a) {
+    const char* e = getenv("MMI_GEMM_ONCE");
+    const bool off = e && e[0] == '0', all = e && e[0] == 'a';
+    if (off || a.wq != 0 || p.ntw != 1 || a.epi == MMI_EPI_GATE) return 0;
+    const int kper = mmi_cdiv(mmi_cdiv(g.KSTEPS, p.ksplit), 8);
+    if (!all) {
+        if (p.waves != 8 || p.ksplit != 1) return 0;   // (split-K GEMMs are streams: the temporal out_proj lost 0.9 us per launch on this form)
+        if ((long)g.NT * p.ksplit * (a.osplit > 1 ? a.osplit : 1) > 256) return 0;      // a stream: keep the double-buffered loop
+        if (kper <= 2 * p.u) return 0;                                                   // already one round trip
+    }
+    if (g.T == 32 && mt == 1) return kper <= 11 ? 11 : (kper <= 22 ? 22 : 0);
+    if (g.T == 16 && mt <= 2) return kper <= 11 ? 11 : 0;
+    return 0;
+}
+int launch_once(hipStream_t s, int T, int mt, int kmax, dim3 groups, const GemmArgs& a) {
+    if (T == 32 && kmax == 11) MMI_LAUNCH((k_gemm_xp_once<32, 1, 8, 11>), groups, 512, 0, s, a);
+    else if (T == 32) MMI_LAUNCH((k_gemm_xp_once<32, 1, 8, 22>), groups, 512, 0, s, a);
+    else if (mt == 1) MMI_LAUNCH((k_gemm_xp_once<16, 1, 8, 11>), groups, 512, 0, s, a);
+    else MMI_LAUNCH((k_gemm_xp_once<16, 2, 8, 11>), groups, 512, 0, s, a);
+    MMI_CHECK_LAUNCH();
+    return MMI_OK;
+}
+
 int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_dominant) {
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = (g.wq == 1 && a.wq >= 3) ? a.wq : g.wq;             // int8 linears: 3 / 4 = int8 activations (set by the program builder)
     a.xinv = g.xinv;
-    const int mt = mmi_cdiv(a.B, lm->T);
+    const int mt = mmi_cdiv(a.B, g.T);
     const GemmPlan p = plan_gemm(g, a.epi == MMI_EPI_PARTIAL);
-    a.osplit = plan_osplit(g, p, a.epi, lm->T);
+    a.osplit = plan_osplit(g, p, a.epi, g.T);
     const XldsPlan xl = plan_xlds(lm, g, a, mt);
     EvPair* ev = nullptr;
     if (lm->profiling && is_dominant) {
@@ -453,8 +491,10 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
     if (xl.on) {
         lm->xlds_launches += 1;
         rc = mt == 1 ? launch_xlds<1>(s, xl, a) : launch_xlds<2>(s, xl, a);
+    } else if (const int kmax = once_kmax(g, p, mt, a)) {
+        rc = launch_once(s, g.T, mt, kmax, dim3(g.NT * (a.osplit > 1 ? a.osplit : 1), p.ksplit), a);
     } else {
-        rc = lm->T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
+        rc = g.T == 32 ? launch_gemm_t<32>(s, p, g.NT, mt, a) : launch_gemm_t<16>(s, p, g.NT, mt, a);
     }
     if (rc) return rc;
     if (ev) MMI_HIP_CHECK(hipEventRecord(ev->b, s));
@@ -464,13 +504,15 @@ int launch_gemm(mmi_lm* lm, hipStream_t s, const GemmW& g, GemmArgs a, bool is_d
 // number of bf16 elements of a packed activation buffer with `features` columns
 // k-steps of a packed activation buffer with `features` columns (even when the linears are int8: their weight entries
 // carry k-step pairs, and the padding k-step reads as zero)
-int packed_ksteps(const mmi_lm* lm, int features) {
-    const int ks = mmi_cdiv(features, mmi_kstep(lm->T));
+int packed_ksteps_t(const mmi_lm* lm, int T, int features) {
+    const int ks = mmi_cdiv(features, mmi_kstep(T));
     return lm->q8 >= 1 ? 2 * mmi_cdiv(ks, 2) : ks;
 }
-size_t packed_elems(const mmi_lm* lm, int features) {
-    return (size_t)mmi_cdiv(lm->batch, lm->T) * packed_ksteps(lm, features) * 512;
+int packed_ksteps(const mmi_lm* lm, int features) { return packed_ksteps_t(lm, lm->T, features); }
+size_t packed_elems_t(const mmi_lm* lm, int T, int features) {
+    return (size_t)mmi_cdiv(lm->batch, T) * packed_ksteps_t(lm, T, features) * 512;
 }
+size_t packed_elems(const mmi_lm* lm, int features) { return packed_elems_t(lm, lm->T, features); }
 
 // x: packed activations.  out: packed with `out_features` columns (out_packed) or row-major with leading dim out_features.
 // MMI_EPI_DEP_QKV0 (the depth transformer's in_proj at micro-step 0): where its epilogue writes k / v (frame cache, position 0)
@@ -489,7 +531,7 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
     a.tok_stride = tok_stride; a.tok_rows = lm->gen_batch; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
     a.out_ld = out_features;
-    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.out_ksteps = packed_ksteps_t(lm, g.T, out_features);
     GemmW gw = g;
     lm->prog.add([lm, gw, a, dominant](hipStream_t s) { return launch_gemm(lm, s, gw, a, dominant); }, (long)g.bytes);
 }
@@ -499,7 +541,7 @@ void add_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, uint16_t* out, int 
 // per step (a wave works through its 2 B pairs one after the other; profiles/r04_logs/call_o2_summary.txt), hence one session only.
 // MMI_NO_DEP_ATTN_FUSION=1: the two launches (A/B and the bit-equality test)
 bool dep_attn_fusable(const mmi_lm* lm, const GemmW& g, int H, int Dh, int steps) {
-    if (lm->T != 16 || lm->batch != 1 || lm->act8 || g.wq != 0 || getenv("MMI_NO_DEP_ATTN_FUSION")) return false;
+    if (g.T != 16 || lm->batch != 1 || lm->act8 || g.wq != 0 || getenv("MMI_NO_DEP_ATTN_FUSION")) return false;
     if (Dh % 8 || Dh > 64 || steps > 8 || g.KSTEPS * 32 != H * Dh) return false;
     const GemmPlan p = plan_gemm(g, false);
     const int kper = mmi_cdiv(g.KSTEPS, p.waves);
@@ -518,10 +560,10 @@ void add_dep_attn_out_proj(mmi_lm* lm, const GemmW& g, const DepAttnArgs& da, ui
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.out = x; a.epi = MMI_EPI_RESID; a.resid = x; a.B = lm->batch; a.tok_rows = lm->gen_batch;
-    a.out_mode = MMI_OUT_PACKED; a.out_ld = features; a.out_ksteps = packed_ksteps(lm, features);
+    a.out_mode = MMI_OUT_PACKED; a.out_ld = features; a.out_ksteps = packed_ksteps_t(lm, g.T, features);
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT; a.wscale = g.scale; a.xinv = g.xinv;
     const GemmPlan p = plan_gemm(g, false);
-    a.osplit = plan_osplit(g, p, a.epi, lm->T);
+    a.osplit = plan_osplit(g, p, a.epi, g.T);
     const int groups = g.NT * (a.osplit > 1 ? a.osplit : 1), waves = p.waves;
     const long bytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
@@ -556,8 +598,9 @@ Pending add_gemm_resid(mmi_lm* lm, const GemmW& g, const uint16_t* in, uint16_t*
 
 // x (+= the P pending split-K partials), y = rms_norm(x) * alpha
 // yq / sx: also store the row quantised row-wise to int8 (+ its absmax) for the int8 linears that read it (lm->act8)
-void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, Pending pd, const uint16_t* alpha, uint16_t* y, int D, uint8_t* yq = nullptr, float* sx = nullptr) {
-    const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, D);
+void add_resid_rmsnorm(mmi_lm* lm, uint16_t* x, Pending pd, const uint16_t* alpha, uint16_t* y, int D, uint8_t* yq = nullptr, float* sx = nullptr,
+                       int tile = 0) {
+    const int B = lm->batch, T = tile ? tile : lm->T, ksteps = packed_ksteps_t(lm, T, D);
     const float* partial = lm->partial;
     const int P = pd.P;
     const float *psx = pd.sx, *pscb = pd.scb;
@@ -611,6 +654,8 @@ int launch_norm_fused(hipStream_t s, int T, int mt, int wq, int NT, const GemmAr
         // 16-row tile: rows of <= 32 k-steps (the depth transformer's 1024 features) need 4 fragments per wave, not 8: the
         // smaller register arrays let two workgroups share a CU, so the 352 gated tiles of linear_in are resident at once
         // instead of running as 256 + 96 (same k partition per wave: bit-identical)
+        else if (mt == 2 && a.KSTEPS <= 32) MMI_LAUNCH((k_gemm_xp_norm<16, 2, 8, 4>), NT, 512, 0, s, a);   // 17..32 sessions on the depth
+        else if (mt == 2) MMI_LAUNCH((k_gemm_xp_norm<16, 2, 8, 8>), NT, 512, 0, s, a);                      // transformer's own tile (lm->Td)
         else if (a.KSTEPS <= 32) MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 4>), NT, 512, 0, s, a);
         else MMI_LAUNCH((k_gemm_xp_norm<16, 1, 8, 8>), NT, 512, 0, s, a);
     }
@@ -655,12 +700,12 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     const bool fuse = g.KSTEPS <= (wq ? 32 : 64) && !getenv("MMI_NO_NORM_FUSION");
     if (!fuse) {
         if (a8) {
-            add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn);
+            add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D, lm->dxnq, lm->sx_dxn, g.T);
             Q8 q{3, lm->sx_dxn};
             add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->dxnq), out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv, &q);
             return;
         }
-        add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D);
+        add_resid_rmsnorm(lm, x, Pending{}, alpha, xn_scratch, D, nullptr, nullptr, g.T);
         add_gemm(lm, g, xn_scratch, out, out_features, out_packed, epi, nullptr, nullptr, nullptr, 0, false, kv);
         return;
     }
@@ -670,13 +715,13 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.B = lm->batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
     a.out_ld = out_features;
-    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.out_ksteps = packed_ksteps_t(lm, g.T, out_features);
     a.alpha = alpha; a.D = D; a.eps = 1e-8f;
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = wq; a.xinv = g.xinv;
     a.osplit = 1;
-    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
+    const int T = g.T, mt = mmi_cdiv(lm->batch, g.T), NT = g.NT * (a.osplit > 1 ? a.osplit : 1);
     const long gbytes = (long)g.bytes;
     lm->prog.add([=](hipStream_t s) {
         mmi_record_bytes(gbytes);
@@ -685,8 +730,8 @@ void add_norm_gemm(mmi_lm* lm, const GemmW& g, uint16_t* x, const uint16_t* alph
 }
 
 // bf16 packed tensor -> its row-wise int8 copy + the rows' absmax (lm->act8): one workgroup per row
-void add_quant_rows(mmi_lm* lm, const uint16_t* xp, uint8_t* xq, float* sx, int features) {
-    const int B = lm->batch, T = lm->T, ksteps = packed_ksteps(lm, features);
+void add_quant_rows(mmi_lm* lm, const uint16_t* xp, uint8_t* xq, float* sx, int features, int tile = 0) {
+    const int B = lm->batch, T = tile ? tile : lm->T, ksteps = packed_ksteps_t(lm, T, features);
     lm->prog.add([=](hipStream_t s) {
         int nth = mmi_cdiv(features / 8, 64) * 64;
         if (nth > 1024) nth = 1024;
@@ -701,10 +746,10 @@ void add_quant_rows(mmi_lm* lm, const uint16_t* xp, uint8_t* xq, float* sx, int 
 // (into the gated tensor's scratch) + the plain int8 x int8 GEMM.
 void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features, uint16_t* out, int out_features, bool out_packed, int epi,
                  const uint16_t* resid) {
-    const int T = lm->T, mt = mmi_cdiv(lm->batch, lm->T);
+    const int T = g.T, mt = mmi_cdiv(lm->batch, g.T);
     const int kmax = q8_fused_kmax(g);
     if (!kmax || getenv("MMI_NO_NORM_FUSION")) {
-        add_quant_rows(lm, x, lm->hbq, lm->sx_hb, in_features);
+        add_quant_rows(lm, x, lm->hbq, lm->sx_hb, in_features, g.T);
         Q8 q{3, lm->sx_hb};
         add_gemm(lm, g, reinterpret_cast<const uint16_t*>(lm->hbq), out, out_features, out_packed, epi, resid, nullptr, nullptr, 0, false, nullptr, &q);
         return;
@@ -714,7 +759,7 @@ void add_q8_gemm(mmi_lm* lm, const GemmW& g, const uint16_t* x, int in_features,
     a.xp = reinterpret_cast<const u32x4*>(x); a.out = out; a.epi = epi; a.resid = resid; a.B = lm->batch; a.tok_rows = lm->gen_batch;
     a.out_mode = out_packed ? MMI_OUT_PACKED : MMI_OUT_ROWMAJOR;
     a.out_ld = out_features;
-    a.out_ksteps = packed_ksteps(lm, out_features);
+    a.out_ksteps = packed_ksteps_t(lm, g.T, out_features);
     a.wp = g.wp; a.N = g.N; a.KSTEPS = g.KSTEPS; a.NT = g.NT;
     a.wscale = g.scale; a.wscb = g.scb; a.gate_rows = g.gate ? g.N : 0;
     a.wq = 3; a.xinv = g.xinv;
@@ -748,7 +793,7 @@ void add_sample(mmi_lm* lm, uint16_t* logits, int ld, int V, bool text, int site
         const int dd = lm->cfg.depformer_dim;
         sa.nx_pre = lm->dpre + (size_t)next_k * dd; sa.nx_ld = lm->cfg.dep_q * dd;
         sa.nx_emb = lm->dep_emb[next_k]; sa.nx_out = lm->dx;
-        sa.nx_D = dd; sa.nx_T = lm->T; sa.nx_ksteps = packed_ksteps(lm, dd);
+        sa.nx_D = dd; sa.nx_T = lm->Td; sa.nx_ksteps = packed_ksteps_t(lm, lm->Td, dd);
     }
     sa.logits = logits; sa.ld = ld; sa.V = V;
     sa.k = text ? lm->samp.top_k_text : lm->samp.top_k;
@@ -1029,7 +1074,7 @@ int build_program(mmi_lm* lm) {
             DepAttnArgs da;
             da.qkv = lm->dqkv; da.kc = lm->dkc + l * dkv_layer; da.vc = lm->dvc + l * dkv_layer; da.out = lm->datt;
             da.B = B; da.H = Hd; da.Dh = Dhd; da.steps = c.dep_q; da.k = k;
-            da.T = lm->T; da.out_ksteps = packed_ksteps(lm, dd);
+            da.T = lm->Td; da.out_ksteps = packed_ksteps_t(lm, lm->Td, dd);
             P.site("dep.attn");
             const bool attn8 = Dhd % 8 == 0 && c.dep_q <= 8;        // else the general one-wave-per-(session, head) kernel
             const bool attn_in_gemm = !skip_attn0 && attn8 && dep_attn_fusable(lm, L.out_proj[k], Hd, Dhd, c.dep_q);
@@ -1267,8 +1312,17 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
             lm->dep_in_grouped = true;
         }
     }
+    // the depth transformer's own tile (mmi_lm::Td): two 16-row batch tiles at 17..32 sessions.  Needs the grouped depformer_in
+    // (its row-major output is the boundary between the two tiles) and bf16 weights (the int8 / fp8 forms of the 16-row kernels
+    // are instantiated for one batch tile only)
+    lm->Td = lm->T;
+    {
+        const char* e = getenv("MMI_DEP_TILE");
+        if (lm->T == 32 && max_batch <= 32 && lm->q8 == 0 && lm->dep_in_grouped && dd % 16 == 0 && e && atoi(e) == 16) lm->Td = 16;
+    }
+    const int Td = lm->Td;
     for (int k = 0; k < c.dep_q; ++k)
-        if ((rc = load_linear(lm, W, "linears." + std::to_string(k) + ".weight", c.card, dd, 0, &lm->dep_lin[k]))) return fail(rc);
+        if ((rc = load_linear(lm, W, "linears." + std::to_string(k) + ".weight", c.card, dd, 0, &lm->dep_lin[k], nullptr, nullptr, nullptr, Td))) return fail(rc);
     lm->dep_layers.resize(c.depformer_num_layers);
     for (int l = 0; l < c.depformer_num_layers; ++l) {
         DepLayerW& L = lm->dep_layers[l];
@@ -1276,10 +1330,10 @@ extern "C" int mmi_lm_create(const mmi_lm_cfg* cfg, const mmi_tensor_desc* weigh
         L.in_proj.resize(c.dep_q); L.out_proj.resize(c.dep_q); L.ffn_in.resize(c.dep_q); L.ffn_out.resize(c.dep_q);
         for (int k = 0; k < c.dep_q; ++k) {
             std::string ks = std::to_string(k);
-            if ((rc = load_linear(lm, W, p + ".self_attn.in_projs." + ks + ".weight", 3 * dd, dd, 0, &L.in_proj[k]))) return fail(rc);
-            if ((rc = load_linear(lm, W, p + ".self_attn.out_projs." + ks + ".weight", dd, dd, 0, &L.out_proj[k]))) return fail(rc);
-            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_in.weight", 2 * c.depformer_ffn_hidden, dd, c.depformer_ffn_hidden, &L.ffn_in[k]))) return fail(rc);
-            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_out.weight", dd, c.depformer_ffn_hidden, 0, &L.ffn_out[k]))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".self_attn.in_projs." + ks + ".weight", 3 * dd, dd, 0, &L.in_proj[k], nullptr, nullptr, nullptr, Td))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".self_attn.out_projs." + ks + ".weight", dd, dd, 0, &L.out_proj[k], nullptr, nullptr, nullptr, Td))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_in.weight", 2 * c.depformer_ffn_hidden, dd, c.depformer_ffn_hidden, &L.ffn_in[k], nullptr, nullptr, nullptr, Td))) return fail(rc);
+            if ((rc = load_linear(lm, W, p + ".gating." + ks + ".linear_out.weight", dd, c.depformer_ffn_hidden, 0, &L.ffn_out[k], nullptr, nullptr, nullptr, Td))) return fail(rc);
         }
         if ((rc = load_copy(lm, W, p + ".norm1.alpha", 3, dd, &L.n1))) return fail(rc);
         if ((rc = load_copy(lm, W, p + ".norm2.alpha", 3, dd, &L.n2))) return fail(rc);
@@ -1406,11 +1460,11 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
             ok &= hipSuccess == A.alloc(&lm->sx_hb, rows);
         }
     }
-    ok &= hipSuccess == A.alloc(&lm->dx, packed_elems(lm, dd));
-    ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems(lm, dd));
+    ok &= hipSuccess == A.alloc(&lm->dx, packed_elems_t(lm, lm->Td, dd));
+    ok &= hipSuccess == A.alloc(&lm->dxn, packed_elems_t(lm, lm->Td, dd));
     ok &= hipSuccess == A.alloc(&lm->dqkv, (size_t)B * 3 * dd);
-    ok &= hipSuccess == A.alloc(&lm->datt, packed_elems(lm, dd));
-    ok &= hipSuccess == A.alloc(&lm->dhb, packed_elems(lm, c.depformer_ffn_hidden));
+    ok &= hipSuccess == A.alloc(&lm->datt, packed_elems_t(lm, lm->Td, dd));
+    ok &= hipSuccess == A.alloc(&lm->dhb, packed_elems_t(lm, lm->Td, c.depformer_ffn_hidden));
     ok &= hipSuccess == A.alloc(&lm->dlogits, (size_t)c.dep_q * B * c.card);
     ok &= hipSuccess == A.alloc(&lm->dpre, (size_t)B * c.dep_q * dd);
     ok &= hipSuccess == A.alloc(&lm->dkc, dkvn);
@@ -1441,9 +1495,10 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     MMI_HIP_CHECK(hipMemsetAsync(lm->use_forced, 0, sizeof(int), s));
     lm->forced_armed = false;
     {   // packed activations: the padding rows / columns of a fragment are never written and must read as zero
-        struct { uint16_t* p; int f; } pk[] = {{lm->x, d}, {lm->xn, d}, {lm->att, d}, {lm->hb, c.ffn_hidden}, {lm->tout, d},
-                                               {lm->dx, dd}, {lm->dxn, dd}, {lm->datt, dd}, {lm->dhb, c.depformer_ffn_hidden}};
-        for (auto& e : pk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, packed_elems(lm, e.f) * sizeof(uint16_t), s));
+        struct { uint16_t* p; int f; int T; } pk[] = {{lm->x, d, lm->T}, {lm->xn, d, lm->T}, {lm->att, d, lm->T}, {lm->hb, c.ffn_hidden, lm->T},
+                                                      {lm->tout, d, lm->T}, {lm->dx, dd, lm->Td}, {lm->dxn, dd, lm->Td}, {lm->datt, dd, lm->Td},
+                                                      {lm->dhb, c.depformer_ffn_hidden, lm->Td}};
+        for (auto& e : pk) MMI_HIP_CHECK(hipMemsetAsync(e.p, 0, packed_elems_t(lm, e.T, e.f) * sizeof(uint16_t), s));
     }
     if (lm->act8) {   // the int8 operands: like their bf16 twins, padding rows / k-steps are never written and must read as zero
         const size_t mtiles = (size_t)mmi_cdiv(B, lm->T), rows = mtiles * lm->T;
@@ -1798,8 +1853,8 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
     if ((codes || absmax) && !(a8 && (path == MMI_DBG_PLAIN || path == MMI_DBG_SPLITK || path == MMI_DBG_NORM)))
         return mmi_fail(MMI_ERR_UNSUPPORTED, "mmi_lm_debug_linear: codes / absmax exist on the int8 x int8 paths that materialise the operand (plain, split-K, norm)");
     hipStream_t s = (hipStream_t)stream;
-    const int T = lm->T, mt = mmi_cdiv(rows, T), KS = mmi_kstep(T);
-    const int K = g.K, N = g.N, kin = packed_ksteps(lm, K), kout = packed_ksteps(lm, N);
+    const int T = g.T, mt = mmi_cdiv(rows, T), KS = mmi_kstep(T);
+    const int K = g.K, N = g.N, kin = packed_ksteps_t(lm, T, K), kout = packed_ksteps_t(lm, T, N);
     const int nthK = [&] { int n = mmi_cdiv(K / 8, 64) * 64; return n > 1024 ? 1024 : n; }();
     MmiArena A;
     uint16_t *xp = nullptr, *yp = nullptr, *xres = nullptr, *zeros = nullptr, *outp = (uint16_t*)out_bf16;
@@ -1905,6 +1960,7 @@ extern "C" int64_t mmi_lm_stat(const mmi_lm* lm, int32_t which) {
         return m;
     }
     if (which == 2) return (int64_t)lm->depth_bound;
+    if (which == 3) return (int64_t)lm->Td;               // the depth transformer's MFMA tile (16 / 32)
     return -1;
 }
 

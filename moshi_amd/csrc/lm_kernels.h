@@ -650,6 +650,62 @@ __global__ __launch_bounds__(WAVES * 64, (TN == 16 && MT == 1 && NTW == 1 && WQ 
     mmi_gemm_epilogue<TN, MT, NTW, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
 }
 
+// k_gemm_xp for GEMMs that are a LATENCY chain, not a stream (the depth transformer's linear_out: 5.8 MB behind 128 workgroups,
+// 22 k-steps per wave): the wave's WHOLE K-slice (<= KMAX k-steps: weight fragment + MT activation fragments each) is requested
+// before the first MFMA - one memory round trip where the double-buffered loop of k_gemm_xp makes three (U = 4: 8 fragments in
+// flight, 22 to fetch).  Same K partition over waves / workgroups, same k order inside a wave, same reduction and epilogue:
+// bit-identical to k_gemm_xp<TN, MT, 1, WAVES, U>.  bf16 weights, one n-tile per workgroup, octet sharing and split-K over
+// gridDim.y as in k_gemm_xp.  Registers: KMAX * (1 + MT) fragments of 4 (TN = 32, KMAX = 22: 176).
+template <int TN, int MT, int WAVES, int KMAX>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_xp_once(GemmArgs a) {
+    constexpr int R = TN == 32 ? 16 : 4;
+    typedef float acc_t __attribute__((ext_vector_type(R)));
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int os = a.osplit > 1 ? a.osplit : 1;
+    const int nt0 = (int)blockIdx.x / os, part = (int)blockIdx.x - nt0 * os;
+    const int g_lo = part * ((TN / 8) / os), g_hi = os > 1 ? g_lo + (TN / 8) / os : TN / 8;
+    const int ro = (lane >> 3) & (TN / 8 - 1);
+    const int wlane = (ro >= g_lo && ro < g_hi) ? lane : ((lane & ~((TN / 8 - 1) << 3)) | (g_lo << 3));
+    const u32x4 pre = mmi_gemm_prefetch_addend<TN, MT, 1>(a, nt0);
+    const int kb_per = (a.KSTEPS + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = min(a.KSTEPS, (int)blockIdx.y * kb_per), kb1 = min(a.KSTEPS, kb0 + kb_per);
+    const int kper = (kb1 - kb0 + WAVES - 1) / WAVES;            // <= KMAX (checked by the launcher)
+    const int ks0 = min(kb1, kb0 + wave * kper);
+    const int nks = min(kb1, ks0 + kper) - ks0;
+    const int ksl = min(ks0, a.KSTEPS - 1), last = nks > 0 ? nks - 1 : 0;
+    const u32x4* wp = a.wp + ((long)min(nt0, a.NT - 1) * a.KSTEPS + ksl) * 64 + wlane;
+    u32x4 wv[KMAX], xv[MT][KMAX];
+    // unconditional loads from clamped (valid) addresses; the entries past the slice never meet the matrix core
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        const int uu = min(u, last);
+        wv[u] = mmi_load_nt(wp + uu * 64);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xv[m][u] = a.xp[((long)m * a.KSTEPS + ksl + uu) * 64 + lane];
+    }
+    acc_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        if (u < nks) {                                           // wave-uniform
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (TN == 32) acc[m] = mmi_mfma_bf16_32x32x16(wv[u], xv[m][u], acc[m]);
+                else acc[m] = mmi_mfma_bf16_16x16x32(wv[u], xv[m][u], acc[m]);
+            }
+        }
+    }
+    float accv[1][MT][R];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) accv[0][m][r] = acc[m][r];
+    mmi_gemm_epilogue<TN, MT, 1, WAVES>(a, accv, wave, lane, nt0, pre, nullptr, g_lo, g_hi);
+}
+
 // RMSNorm fused into the GEMM that consumes it (the depth transformer: norm1 -> in_proj, norm2 -> linear_in; rows of
 // 1024 features): y = (x.float() * (alpha.float() * rsqrt(eps + mean(x^2)))).to(bf16) (transformer.py:45-58), then
 // out = y @ W^T.  A wave's whole K-slice of activation and weight fragments (<= KMAX k-steps) is loaded in one go -
@@ -2190,6 +2246,18 @@ __device__ __forceinline__ void mmi_philox_round(unsigned& c0, unsigned& c1, uns
     unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
+// Philox4x32-10, all four output words: counter (step, a, b), key = seed
+__device__ __forceinline__ void mmi_philox4(unsigned long long seed, unsigned long long step, unsigned a, unsigned b, unsigned (&out)[4]) {
+    unsigned c0 = (unsigned)step, c1 = (unsigned)(step >> 32), c2 = a, c3 = b;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        mmi_philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
 // Philox4x32-10 -> one Exp(1) draw
 __device__ __forceinline__ float mmi_exp_noise(unsigned long long seed, unsigned long long step, unsigned a, unsigned b) {
     unsigned c0 = (unsigned)step, c1 = (unsigned)(step >> 32), c2 = a, c3 = b;
@@ -2253,6 +2321,8 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     MMI_SHARED int sel_idx[256];
     MMI_SHARED int s_bin;
     MMI_SHARED int s_want;
+    MMI_SHARED unsigned redk[NT / 64];
+    MMI_SHARED unsigned wcnt[NT / 64][4];
     const int lane = tid & 63, wave = tid >> 6;
     const int i0 = tid * E;
     constexpr int NV = E / 8;
@@ -2374,11 +2444,94 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         return;
     }
 
-    // ---- radix select of the k-th largest key: high byte, then low byte
     const int k = a.k < V ? a.k : V;
     int want = k;
     unsigned Tkey = 0u;
-    for (int pass = 0; pass < 2; ++pass) {
+    // ---- production path (round 6): the k-th largest key WITHOUT the two 256-bin LDS histograms over every entry.  The logits of
+    // a head share a handful of exponents, so the first histogram is 2048 (text head: 32000) LDS atomics on two or three
+    // addresses - serialised - and each pass costs six workgroup barriers.  Instead: the block's largest key, then per-thread
+    // PRIVATE counts (8 bits each, packed in 64) of the 8 high bytes at and below it, summed over the wave by shuffles and over
+    // the waves through 16 words of LDS; the high byte that holds the k-th largest key is then known to every thread, and only
+    // the entries carrying it (typically a few hundred, spread over the low byte's 256 bins) go through an LDS histogram, which
+    // every wave scans for itself.  Three barriers instead of twelve.  A set that reaches below those 8 high bytes (more than
+    // 2^16 in magnitude under the maximum: never with trained or random-init heads) falls through to the generic select below.
+    bool have_t = false;
+    int cnt_at_t = -1;                   // entries equal to the threshold key (window select only)
+    if (fast) {
+        unsigned km = 0u;
+        MMI_S_FOREACH({ const unsigned ky = mmi_bf16_key(bits); km = ky > km ? ky : km; })
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const unsigned o = mmi_shfl_xor(km, m); km = o > km ? o : km; }
+        if (lane == 0) redk[wave] = km;
+        for (int j = tid; j < 256; j += NT) hist[j] = 0;
+        __syncthreads();
+        km = redk[0];
+        for (int w = 1; w < NT / 64; ++w) km = redk[w] > km ? redk[w] : km;
+        const int hi_max = (int)(km >> 8);
+        unsigned long long pc = 0ull;
+        MMI_S_FOREACH({
+            const int d = hi_max - (int)(mmi_bf16_key(bits) >> 8);
+            if (d < 8) pc += 1ull << (8 * d);
+        })
+        // 8 x 8-bit counters (<= E <= 32 each) -> 4 words of two 16-bit fields: wave sums <= 64 * 32, block sums <= NT * E <= 32768
+        unsigned f[4] = {(unsigned)pc & 0x00ff00ffu, ((unsigned)pc >> 8) & 0x00ff00ffu, (unsigned)(pc >> 32) & 0x00ff00ffu, ((unsigned)(pc >> 32) >> 8) & 0x00ff00ffu};
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] += mmi_shfl_xor(f[q], m);
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wcnt[wave][q] = f[q];
+        __syncthreads();
+        unsigned t4[4] = {0u, 0u, 0u, 0u};
+        for (int w = 0; w < NT / 64; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t4[q] += wcnt[w][q];
+        // counter d of the packed word: byte d -> word (d >> 2) * 2 + (d & 1), field (d >> 1) & 1
+        int cum = 0, dsel = -1, want1 = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const unsigned wq = t4[(d >> 2) * 2 + (d & 1)];
+            const int c = (int)(((d >> 1) & 1) ? (wq >> 16) : (wq & 0xffffu));
+            if (dsel < 0 && cum + c >= k) { dsel = d; want1 = k - cum; }
+            cum += c;
+        }
+        if (dsel >= 0 && hi_max - dsel >= 0) {                     // block-uniform
+            const unsigned hi_sel = (unsigned)(hi_max - dsel);
+            MMI_S_FOREACH({
+                const unsigned ky = mmi_bf16_key(bits);
+                if ((ky >> 8) == hi_sel) mmi_atomic_add(reinterpret_cast<unsigned*>(&hist[ky & 255u]), 1u);
+            })
+            __syncthreads();
+            // every wave for itself: lane l looks at bins 255 - 4l .. 252 - 4l (descending keys); `above` = entries in higher bins
+            int c4[4], s4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c4[j] = hist[255 - 4 * lane - j]; s4 += c4[j]; }
+            int inc = s4;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int o = mmi_shfl(inc, lane - dlt);
+                if (lane >= dlt) inc += o;
+            }
+            int run = inc - s4, fb = 0, fw = 0, fc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (run < want1 && want1 <= run + c4[j]) { fb = 256 - 4 * lane - j; fw = want1 - run; fc = c4[j]; }   // exactly one (lane, j)
+                run += c4[j];
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {        // the finder's values are the only non-zero ones
+                const int ob = mmi_shfl_xor(fb, m), ow = mmi_shfl_xor(fw, m), oc = mmi_shfl_xor(fc, m);
+                fb = ob > fb ? ob : fb; fw = ow > fw ? ow : fw; fc = oc > fc ? oc : fc;
+            }
+            Tkey = (hi_sel << 8) | (unsigned)(fb - 1);
+            want = fw;
+            cnt_at_t = fc;
+            have_t = true;
+        }
+    }
+    // ---- radix select of the k-th largest key: high byte, then low byte (supplied noise: the parity taps; and the fallback)
+    for (int pass = 0; pass < 2 && !have_t; ++pass) {
         for (int j = tid; j < 256; j += NT) hist[j] = 0;
         __syncthreads();
         MMI_S_FOREACH({
@@ -2408,26 +2561,56 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         n_gt += ky > Tkey ? 1 : 0;
         n_eq += ky == Tkey ? 1 : 0;
     })
-    int tot;
-    const int eq_base = mmi_block_excl_scan<NT>(n_eq, wsum, &tot);
-    int eq_take = want_eq - eq_base;
-    eq_take = eq_take < 0 ? 0 : (eq_take > n_eq ? n_eq : eq_take);
+    int tot = 0;
+    int eq_take = n_eq;                // window select and every entry at the threshold belongs to the set: no scan (block-uniform)
+    if (!(have_t && cnt_at_t == want_eq)) {
+        const int eq_base = mmi_block_excl_scan<NT>(n_eq, wsum, &tot);
+        eq_take = want_eq - eq_base;
+        eq_take = eq_take < 0 ? 0 : (eq_take > n_eq ? n_eq : eq_take);
+    }
     if (fast) {
-        // every member of the set scores logit / temp - log(q), q ~ Exp(1) drawn at (site, session, entry); the largest wins
+        // every member of the set scores logit / temp - log(q), q ~ Exp(1); the largest wins.  One Philox4x32-10 call serves the
+        // four entries 4j .. 4j + 3 of the vocabulary (counter (step, site * B + session, j), one output word each) and is skipped
+        // when none of the four is in the set: two calls per thread for an audio head instead of eight, ~one for the text head
         float best = -INFINITY;
         int bi = 0x7fffffff;
         int eq_seen_f = 0;
         const float inv_t = 1.0f / a.temp;
-        MMI_S_FOREACH({
-            const unsigned ky = mmi_bf16_key(bits);
-            bool take = ky > Tkey;
-            if (ky == Tkey) { take = eq_seen_f < eq_take; ++eq_seen_f; }
-            if (take) {
-                const float q = mmi_exp_noise(a.rng[0], a.rng[1], (unsigned)(a.site * a.B + b), (unsigned)i);
-                const float sc_ = mmi_bf16_to_f32(bits) * inv_t - logf(q);
-                if (sc_ > best || (sc_ == best && i < bi)) { best = sc_; bi = i; }
+        const unsigned long long seed = a.rng[0], step = a.rng[1];
+#pragma unroll
+        for (int v_ = 0; v_ < NV; ++v_) {
+            if (i0 + v_ * 8 >= V) break;
+            u32x4 r4_;
+            if constexpr (CACHE) r4_ = cache[v_];
+            else r4_ = *reinterpret_cast<const u32x4*>(lg + i0 + v_ * 8);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bool tk[4];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int e_ = 4 * h + e;
+                    const uint16_t bits = (uint16_t)((e_ & 1) ? (r4_[e_ >> 1] >> 16) : (r4_[e_ >> 1] & 0xffffu));
+                    const unsigned ky = mmi_bf16_key(bits);
+                    bool take = ky > Tkey;
+                    if (ky == Tkey) { take = eq_seen_f < eq_take; ++eq_seen_f; }
+                    tk[e] = take;
+                    any = any || take;
+                }
+                if (!any) continue;
+                unsigned r[4];
+                mmi_philox4(seed, step, (unsigned)(a.site * a.B + b), (unsigned)((i0 + v_ * 8 + 4 * h) >> 2), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!tk[e]) continue;
+                    const int e_ = 4 * h + e, i = i0 + v_ * 8 + e_;
+                    const uint16_t bits = (uint16_t)((e_ & 1) ? (r4_[e_ >> 1] >> 16) : (r4_[e_ >> 1] & 0xffffu));
+                    const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+                    const float sc_ = mmi_bf16_to_f32(bits) * inv_t - logf(-logf(u));
+                    if (sc_ > best || (sc_ == best && i < bi)) { best = sc_; bi = i; }
+                }
             }
-        })
+        }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             const float ob = mmi_shfl_xor(best, m);
@@ -2436,17 +2619,12 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         }
         if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
         __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < NT / 64; ++w)
-                if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
-            bi = mmi_apply_forced(a, b, bi);
-            a.out[(long)b * a.out_stride] = bi;
-            redi[0] = bi;
-        }
-        if (a.nx_out) {
-            __syncthreads();
-            mmi_sample_next_input(a, b, redi[0]);
-        }
+        best = redf[0]; bi = redi[0];                   // every thread folds the waves' winners itself: no second barrier
+        for (int w = 1; w < NT / 64; ++w)
+            if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+        bi = mmi_apply_forced(a, b, bi);
+        if (tid == 0) a.out[(long)b * a.out_stride] = bi;
+        mmi_sample_next_input(a, b, bi);
         return;
     }
     int pos = mmi_block_excl_scan<NT>(n_gt + eq_take, wsum, &tot);

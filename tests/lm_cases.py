@@ -382,6 +382,8 @@ def oracle_vs_engine(device, lib, cfg, seed, B, S, use_masks=True, quantize=Fals
             import collections
             stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
             stats["launch_sites"] = dict(collections.Counter(site for site, _ in gen.launch_list()))
+            stats["launch_list"] = list(gen.launch_list())
+            stats["dep_tile"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 3))
 
 
 class ErrorLog:
@@ -1023,6 +1025,64 @@ def check_full_multinomial(device, lib, steps=4, B=3, seed=77):
             prev = (text, audio)
 
 
+def philox4_words(seed: int, step: int, a: int, idx: np.ndarray) -> np.ndarray:
+    """lm_kernels.h mmi_philox4: the four output words of Philox4x32-10 at counter (step lo, step hi, a, idx), key = seed: [n, 4] uint64."""
+    M = np.uint64(0xFFFFFFFF)
+    c0 = np.full(idx.shape, step & 0xFFFFFFFF, np.uint64); c1 = np.full(idx.shape, (step >> 32) & 0xFFFFFFFF, np.uint64)
+    c2 = np.full(idx.shape, a, np.uint64); c3 = idx.astype(np.uint64)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return np.stack([c0, c1, c2, c3], -1)
+
+
+def check_topk_device_rng(device, lib, cfg=None, top_k=20, top_k_text=10, steps=4, B=3, seed=77):
+    """The sampler's PRODUCTION form (top-k, the engine's own counter RNG, no supplied noise), token for token: the top-k set of the
+    bf16 logits (ties at the threshold towards the lower index), each member scored logit / temp - log(q) with q = -log(u) and u
+    from word (i & 3) of Philox4x32-10 at counter (step, site * B + session, i >> 2), the largest score wins (lm_kernels.h
+    k_sample, fast path) - recomputed here from the logits taps.  A different token is accepted only where the two best scores are
+    closer than the device's logf can tell apart."""
+    cfg = cfg or tiny_lm_config()
+    sd = random_lm_state_dict(cfg, seed=21)
+    temp, temp_text = 0.9, 0.8
+    gen = make_engine(cfg, sd, device, lib, B, use_sampling=True, temp=temp, temp_text=temp_text, top_k=top_k, top_k_text=top_k_text,
+                      seed=seed, support_out_of_sync=True)
+    rng = np.random.default_rng(1)
+    near = [0]
+
+    def pick(logits, t, k, step, site, got):
+        for b in range(B):
+            bits = (logits[b].astype(np.float32).view(np.uint32) >> 16).astype(np.uint32)
+            key = np.where(bits & 0x8000, (~bits) & 0xFFFF, bits | 0x8000).astype(np.int64)
+            V = len(key)
+            order = np.lexsort((np.arange(V), -key))[:min(k, V)]
+            words = philox4_words(seed, step, site * B + b, order >> 2)[np.arange(len(order)), order & 3]
+            u = ((words >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+            sc = (logits[b][order].astype(np.float32) * (np.float32(1.0) / np.float32(t))).astype(np.float32) - np.log(-np.log(u)).astype(np.float32)
+            best = order[np.lexsort((order, -sc))]
+            if int(got[b]) != int(best[0]):
+                s0 = float(sc[order == best[0]][0])
+                assert int(got[b]) in order.tolist(), f"step {step} site {site} row {b}: token {int(got[b])} is not in the top-{k} set"
+                s1 = float(sc[order == int(got[b])][0])
+                assert abs(s0 - s1) <= 2e-5 * max(1.0, abs(s0)), f"step {step} site {site} row {b}: token {int(got[b])} (score {s1}) instead of {int(best[0])} ({s0})"
+                near[0] += 1
+    prev = None
+    with gen.streaming(B):
+        for s in range(steps):
+            codes = rng.integers(0, cfg.card, (B, cfg.n_q - cfg.dep_q, 1))
+            out, tl, al = gen.step_with_taps(torch.from_numpy(codes).to(device))
+            out, tl, al = out.cpu().numpy()[:, :, 0], tl.cpu().numpy(), al.cpu().numpy()
+            if prev is not None:      # the ring returns text and codebook 0 one step late (delays 0), the others at once (delays 1)
+                pick(prev[0], temp_text, top_k_text, s - 1, 0, out[:, 0])
+                pick(prev[1][:, 0], temp, top_k, s - 1, 1, out[:, 1])
+                for kq in range(1, cfg.dep_q):
+                    pick(al[:, kq], temp, top_k, s, 1 + kq, out[:, 1 + kq])
+            prev = (tl, al)
+    assert near[0] <= 2, f"{near[0]} sampled tokens sat on a near-tie of the two best scores"
+
+
 # ---- C5, per linear, bit for bit (VERDICT r4 item 1: "the int8 GEMM is integer work") ------------------------------------------------
 # `QLinear.forward` (utils/quantize.py:24-40) of ONE module on the same bf16 rows, engine (`mmi_lm_debug_linear`: the kernels the
 # step uses) against the oracle's restatement of bitsandbytes' rule: the int8 codes, the row absmax and the bf16 output must be
@@ -1179,6 +1239,8 @@ def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=No
             import collections
             stats["xlds_launches"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 0))
             stats["launch_sites"] = dict(collections.Counter(site for site, _ in gen.launch_list()))
+            stats["launch_list"] = list(gen.launch_list())
+            stats["dep_tile"] = int(gen._lib.mmi_lm_stat(gen.lm_model._handle, 3))
     e, y = np.array(eng), np.array(yd)
 
     def summ(v):

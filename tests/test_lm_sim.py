@@ -29,6 +29,19 @@ def test_sampling_without_top_k_is_a_multinomial_over_the_whole_vocabulary(sim_l
     lm_cases.check_full_multinomial("cpu", sim_lib)
 
 
+@pytest.mark.parametrize("top_k,top_k_text,card", [(20, 10, None), (1, 3, None), (60, 90, None), (250, 25, (2048, 8200))])
+def test_production_sampler_token_for_token(sim_lib, top_k, top_k_text, card):
+    """top-k + the engine's own counter RNG (no supplied noise): every sampled token recomputed from the logits taps - the
+    threshold found through the window of 8 high bytes under the largest key, ties at the threshold, one Philox call per four
+    vocabulary entries; k = 1; a set that reaches into the negative logits, i.e. below the window (60 of 64: the generic two-pass
+    select takes over); the default k (250 / 25) on vocabularies of the real size classes."""
+    cfg = tiny_lm_config()
+    if card:
+        from dataclasses import replace
+        cfg = replace(cfg, card=card[0], text_card=card[1])
+    lm_cases.check_topk_device_rng("cpu", sim_lib, cfg, top_k=top_k, top_k_text=top_k_text, steps=3, B=2 if card else 3)
+
+
 def test_sampler_large_vocabulary_variants(sim_lib):
     """Vocabularies above 2048 / 8192 entries take the wider / uncached sampler kernels (lm_kernels.h k_sample)."""
     from dataclasses import replace
@@ -45,6 +58,36 @@ def test_matches_oracle_with_masks_and_reset(sim_lib, B):
 def test_wide_batch_tiles_match_oracle(sim_lib, B):
     """17..32 sessions use the 32x32x16 MFMA tile, 33..64 two batch tiles per weight fragment (lm_kernels.h)."""
     lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=60 + B, B=B, S=3)
+
+
+@pytest.mark.parametrize("B", [18, 32, 17])
+def test_depth_transformer_on_its_own_tile(sim_lib, monkeypatch, B):
+    """MMI_DEP_TILE=16 at 17..32 sessions with bf16 weights: the depth transformer on a 16-row tile (mmi_lm::Td; two batch tiles
+    per 16-row weight tile, k_gemm_xp<16, 2, ..> / k_gemm_xp_norm<16, 2, ..>) while the temporal transformer keeps the 32-row
+    tile.  An opt-in (measured slower inside the step, lm_engine.hip mmi_lm::Td); checked against the oracle at the edges of the
+    range so that the per-weight tile (GemmW::T) stays honest."""
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=160 + B, B=B, S=3, stats=st)
+    assert st["dep_tile"] == 32
+    monkeypatch.setenv("MMI_DEP_TILE", "16")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=160 + B, B=B, S=3, stats=st)
+    assert st["dep_tile"] == 16
+
+
+@pytest.mark.parametrize("B,tile", [(18, None), (18, "16"), (3, None)])
+def test_gemm_with_the_whole_slice_requested_at_once(sim_lib, monkeypatch, B, tile):
+    """k_gemm_xp_once (a wave's whole K-slice in flight before its first MFMA: the depth transformer's linear_out at the 7B
+    widths) forced onto every bf16 GEMM of the tiny model whose slices fit (MMI_GEMM_ONCE=a): residual, embedding, split-K
+    partial, RoPE / ring and row-major epilogues, octet sharing, 16- and 32-row tiles, one and two batch tiles."""
+    monkeypatch.setenv("MMI_GEMM_ONCE", "a")
+    monkeypatch.setenv("MMI_GEMM_LDS", "0")
+    if tile:
+        monkeypatch.setenv("MMI_DEP_TILE", tile)
+    st = {}
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=170 + B, B=B, S=3, stats=st)
+    assert sum("k_gemm_xp_once" in k for _, k in st["launch_list"]) >= 20
+    monkeypatch.setenv("MMI_GEMM_KSPLIT", "2")
+    lm_cases.oracle_vs_engine("cpu", sim_lib, tiny_lm_config(), seed=171 + B, B=B, S=2, stats=st)
 
 
 @pytest.mark.parametrize("kernel", ["wave", "wave-solo", "wave-switch", "wave-kernel", "split"])
