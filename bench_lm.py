@@ -221,6 +221,32 @@ def extra_c3(dev, args, steps=30):
     return out
 
 
+def extra_c5(args):
+    """`c5` of the default line (BASELINE configs[4]: q8 weights on the 8-bit matrix core, 64 sessions per GPU): the same duplex
+    step - Mimi encode -> LMGen.step -> Mimi decode, pipelined, mid-run ring depth - with row-wise int8 linears x row-wise int8
+    activations (the reference's bitsandbytes arithmetic) and the e4m3 KV ring, measured by a child process running this very
+    benchmark with `--batch 64 --quant q8 --kv fp8` (its own handles, its own memory; the parent's stay resident), plus the same
+    with the reference's bf16 ring.  The child's whole-step roofline fraction travels with it."""
+    import subprocess
+    import sys
+    out = {}
+    for key, kv in (("fp8_ring", "fp8"), ("bf16_ring", "bf16")):
+        cmd = [sys.executable, str(Path(__file__).resolve().parent / "bench.py"), "--no-cpu-baseline", "--no-extras", "--batch", "64",
+               "--quant", "q8", "--kv", kv, "--steps", str(min(args.steps, 40)), "--warmup", str(min(args.warmup, 8))]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+            d = json.loads(line)
+            step = (d.get("roofline") or {}).get("step") or {}
+            out[key] = {"ms_per_step": d["ms_per_step"], "p50_ms_per_step": d.get("p50_ms_per_step"), "frames_per_s": d["value"],
+                        "algorithmic_bytes": step.get("algorithmic_bytes"), "achieved_GBps": step.get("achieved"), "frac": step.get("frac")}
+        except Exception as e:      # noqa: BLE001 - an extra, never worth the line
+            out[key] = {"error": repr(e)[:300]}
+    out["workload"] = ("duplex step (Mimi encode -> LMGen.step -> Mimi decode, pipelined), 64 sessions, Moshi-7B with row-wise int8 linears x int8 "
+                       "activations on v_mfma_i32_*_i8 (BASELINE configs[4]), mid-run ring depth; fp8_ring = e4m3 KV ring, bf16_ring = the reference's")
+    return out
+
+
 def _mem_available_gib():
     try:
         for line in open("/proc/meminfo"):

@@ -104,6 +104,7 @@ class LMConfig:
     card: int = 2048
     text_card: int = 32000
     existing_text_padding_id: int = 3
+    existing_text_end_padding_id: int = 0   # lm.py:100,123: what `LMModel.end_of_text_padding_id` returns (a checkpoint's lm_kwargs may set it)
     depformer_dim: int = 1024
     depformer_dim_feedforward: int = int(4.125 * 1024)
     depformer_num_heads: int = 16

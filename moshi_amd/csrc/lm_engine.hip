@@ -139,6 +139,7 @@ struct mmi_lm {
     long depth_bound = 0;                           // no session's offset exceeds this (steps since streaming_start / the last seek; resets
                                                     // only lower offsets): picks the step program's variant (attn_variant)
     long xlds_launches = 0;         // launches (or graph nodes captured) that took k_gemm_xlds: mmi_lm_stat(lm, 0)
+    bool precapture_failed = false; // capturing the second attention program ahead of time failed once: not tried again for this stream
     bool dominant_xlds = false;     // the profiled (dominant) GEMM ran on k_gemm_xlds
     MmiProgram prog;
     // MMI_DEBUG_TRACE=<prefix> (debug: finding which launch of the step is not reproducible): every step runs its launch list
@@ -1393,6 +1394,7 @@ extern "C" int mmi_lm_streaming_start_guided(mmi_lm* lm, int32_t batch, const mm
     if (lm->kmax < 1) lm->kmax = 1;
     lm->offset_cpu = 0;
     lm->depth_bound = 0;
+    lm->precapture_failed = false;
     const int G = batch;
     const int B = rows, d = c.dim, H = c.num_heads, Dh = d / H, dd = c.depformer_dim, Hd = c.depformer_num_heads, Dhd = dd / Hd;
     const int NS = attn_splits(c, B);
@@ -1652,9 +1654,19 @@ extern "C" int mmi_lm_step(mmi_lm* lm, const int64_t* user_codes, int32_t n_user
     if (lm->attn_ns > 1 && lm->use_graph && !lm->profiling && !hooked && attn_wave_kernel() && !getenv("MMI_NO_PRECAPTURE")) {
         // both attention programs exist from the stream's first step on: the switch at depth solo_rows is then a graph launch
         // like any other (without this the deep program was captured + instantiated ~61 s into a live single-session stream)
+        // The step above is already committed: a failure to capture the OTHER program (out of memory at instantiate, ...) must not
+        // turn it into a failed call - the program is then captured when first needed, as before round 5.  The capture
+        // re-runs every op closure: its GEMMs are not launches of this stream (mmi_lm_stat 0).
         const bool split = lm->phase_fn != nullptr;
-        for (int v = 0; v < MmiProgram::NV; ++v)
-            if (!lm->prog.ready(v, split) && (rc = lm->prog.precapture(v, lm->cap_stream, split, lm->op_depformer))) return rc;
+        const long counted = lm->xlds_launches;
+        for (int v = 0; v < MmiProgram::NV && !lm->precapture_failed; ++v)
+            if (!lm->prog.ready(v, split) && lm->prog.precapture(v, lm->cap_stream, split, lm->op_depformer) != MMI_OK) {
+                lm->precapture_failed = true;
+                (void)hipGetLastError();
+                fprintf(stderr, "moshi_mi: the second attention step program could not be captured ahead of time (%s); it will be captured when first needed\n",
+                        mmi_last_error());
+            }
+        lm->xlds_launches = counted;
     }
     MMI_LAUNCH(k_i32_to_i64, mmi_cdiv(B * (c.dep_q + 1), 256), 256, 0, s, (const int*)lm->out_i32, (long*)out_tokens, B * (c.dep_q + 1));
     if (opt_text_logits)
@@ -1833,6 +1845,18 @@ extern "C" int mmi_lm_seek(mmi_lm* lm, const int64_t* offsets, mmi_stream stream
 
 // Parity tap: ONE linear of the model on caller-supplied rows, through the kernels the step uses for it (include/moshi_mi.h).
 // Works on its own scratch (a streaming session is not disturbed) and synchronises.
+// failures after the scratch arena exists leave through done(): the launches are drained and the arena released
+#define MMI_DBG_HIP(call)                                                                                          \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess) return done(mmi_fail(MMI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+#define MMI_DBG_LAUNCHED()                                                                                         \
+    do {                                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                                         \
+        if (e_ != hipSuccess) return done(mmi_fail(MMI_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e_))); \
+    } while (0)
+
 extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const char* alpha_name, int32_t path, const void* x_bf16,
                                    int32_t rows, void* out_bf16, int8_t* codes, float* absmax, void* norm_out, mmi_stream stream) {
     MmiDeviceGuard dev_guard_(lm ? lm->device : -1);
@@ -1871,14 +1895,14 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
     ok &= hipSuccess == A.alloc(&partial, (size_t)4 * rows * N);
     auto done = [&](int rc) { hipStreamSynchronize(s); A.release(); return rc; };
     if (!ok) return done(mmi_fail(MMI_ERR_HIP, "out of device memory (mmi_lm_debug_linear)"));
-    MMI_HIP_CHECK(hipMemsetAsync(xp, 0, xelems * 2, s));
-    MMI_HIP_CHECK(hipMemsetAsync(yp, 0, xelems * 2, s));
-    MMI_HIP_CHECK(hipMemsetAsync(xq, 0, (size_t)mt * (kin / 2 + 1) * 1024, s));
-    MMI_HIP_CHECK(hipMemsetAsync(sx, 0, (size_t)mt * T * sizeof(float), s));
-    MMI_HIP_CHECK(hipMemsetAsync(xres, 0, oelems * 2, s));
-    MMI_HIP_CHECK(hipMemsetAsync(zeros, 0, ((size_t)N + 8) * 2, s));
+    MMI_DBG_HIP(hipMemsetAsync(xp, 0, xelems * 2, s));
+    MMI_DBG_HIP(hipMemsetAsync(yp, 0, xelems * 2, s));
+    MMI_DBG_HIP(hipMemsetAsync(xq, 0, (size_t)mt * (kin / 2 + 1) * 1024, s));
+    MMI_DBG_HIP(hipMemsetAsync(sx, 0, (size_t)mt * T * sizeof(float), s));
+    MMI_DBG_HIP(hipMemsetAsync(xres, 0, oelems * 2, s));
+    MMI_DBG_HIP(hipMemsetAsync(zeros, 0, ((size_t)N + 8) * 2, s));
     MMI_LAUNCH(k_pack_rows, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint16_t*)x_bf16, rows, K, xp, T, kin);
-    MMI_CHECK_LAUNCH();
+    MMI_DBG_LAUNCHED();
     const uint16_t* operand = xp;              // the packed bf16 rows the GEMM (or its quantiser) reads
     const bool gated = g.gate != 0;
     GemmArgs a;
@@ -1889,12 +1913,12 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
     if (path == MMI_DBG_NORM) {                // the norm launch of the step: y (+ its int8 copy) = rms_norm(x) * alpha
         MMI_LAUNCH(k_resid_rmsnorm, rows, nthK, 0, s, xp, (const float*)nullptr, 0, rows, alpha, yp, K, T, kin, 1e-8f,
                    a8 ? xq : (uint8_t*)nullptr, a8 ? sx : (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
-        MMI_CHECK_LAUNCH();
+        MMI_DBG_LAUNCHED();
         operand = yp;
         if (norm_out) MMI_LAUNCH(k_unpack_rows, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint16_t*)yp, rows, K, (uint16_t*)norm_out, T, kin);
     } else if (a8 && (path == MMI_DBG_PLAIN || path == MMI_DBG_SPLITK)) {
         MMI_LAUNCH(k_quant_rows_i8, rows, nthK, 0, s, (const uint16_t*)xp, rows, K, T, kin, xq, sx);
-        MMI_CHECK_LAUNCH();
+        MMI_DBG_LAUNCHED();
     }
     if (path == MMI_DBG_PLAIN || path == MMI_DBG_NORM || path == MMI_DBG_SPLITK) {
         a.xp = reinterpret_cast<const u32x4*>(operand);
@@ -1917,7 +1941,7 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
             MMI_LAUNCH(k_resid_rmsnorm, rows, nthN, 0, s, xres, (const float*)partial, pd.P, rows, (const uint16_t*)zeros, ytmp, N, T, kout, 1e-8f,
                        (uint8_t*)nullptr, (float*)nullptr, pd.sx, pd.scb);
             MMI_LAUNCH(k_unpack_rows, mmi_cdiv(rows * N, 256), 256, 0, s, (const uint16_t*)xres, rows, N, outp, T, kout);
-            MMI_CHECK_LAUNCH();
+            MMI_DBG_LAUNCHED();
         }
     } else if (path == MMI_DBG_FUSED) {
         const int kmax = q8_fused_kmax(g);
@@ -1941,8 +1965,8 @@ extern "C" int mmi_lm_debug_linear(mmi_lm* lm, const char* weight_name, const ch
         return done(mmi_fail(MMI_ERR_INVALID, "mmi_lm_debug_linear: unknown path"));
     }
     if (codes) MMI_LAUNCH(k_unpack_q8, mmi_cdiv(rows * K, 256), 256, 0, s, (const uint8_t*)xq, rows, K, codes, T, kin);
-    if (absmax) MMI_HIP_CHECK(hipMemcpyAsync(absmax, sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, s));
-    MMI_CHECK_LAUNCH();
+    if (absmax) MMI_DBG_HIP(hipMemcpyAsync(absmax, sx, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MMI_DBG_LAUNCHED();
     (void)KS;
     if (hipStreamSynchronize(s) != hipSuccess) { A.release(); return mmi_fail(MMI_ERR_HIP, "mmi_lm_debug_linear: the launches failed"); }
     A.release();

@@ -162,9 +162,10 @@ __device__ __forceinline__ u32x2 mmi_quant_i8x8(u32x4 v, float scale) {
     return r;
 }
 __device__ __forceinline__ float mmi_i8_scale(float sca) { return sca > 0.f ? 127.0f / sca : 0.f; }
-// bitsandbytes' int8_mm_dequant: `out32 * (row_stats * col_stats) * (1 / 127^2)` evaluated left to right in fp32 - the
-// expression of its "default" backend (restated in oracle/lm_oracle.py linear_int8); the engine's int8 x int8 linears are
-// bit-identical to that restatement for the same bf16 input row (tests: *_int8_linear_bit_exact_*)
+// The dequantisation of oracle/lm_oracle.py `linear_int8` - a RESTATEMENT of bitsandbytes' int8_mm_dequant, `out32 * (row_stats *
+// col_stats) * (1 / 127^2)` left to right in fp32, as its "default" backend writes it; not verified against the library, whose CUDA
+// kernel multiplies by a literal constant and returns fp16 (PARITY UNPINNED).  The engine's int8 x int8 linears
+// are bit-identical to THAT RESTATEMENT for the same bf16 input row (tests: *_int8_linear_bit_exact_*)
 __device__ __forceinline__ float mmi_i8_dequant(int out32, float sca, float scb) {
     return ((float)out32 * (sca * scb)) * (1.0f / (127.0f * 127.0f));
 }
@@ -195,7 +196,7 @@ struct GemmArgs {
     int epi;
     const float* wscale;    // int8 / fp8 weights: dequantisation factor per ORIGINAL weight row (gate rows [0,H), value rows [H,2H)); else null
     const float* wscb;      // int8 weights: the raw row absmax SCB (`weight_scb`), read by the int8 x int8 dequantisation
-                            // out32 * (SCA[b] * SCB[n]) * (1 / 127^2) - bitsandbytes' int8_mm_dequant expression, in its order
+                            // out32 * (SCA[b] * SCB[n]) * (1 / 127^2) - the oracle's restatement of bitsandbytes' int8_mm_dequant, in its order
     float xinv;             // fp8: 1 / input_scale, applied to the activations before the e4m3 conversion
     int wq;                 // host side only: 0 bf16, 1 int8 (widened to bf16), 2 fp8 (fp8 MFMA) weights, 3 int8 weights x int8 activations
     const float* sx;        // WQ = 3 with pre-quantised activations: xp holds int8 entries Xq[mt][kp][lane][16] (k_quant_rows_i8 / the
@@ -2306,9 +2307,13 @@ __device__ __forceinline__ unsigned mmi_bf16_key(uint16_t h) {       // order-pr
     return (h & 0x8000u) ? (unsigned)(uint16_t)~h : (unsigned)(h | 0x8000u);
 }
 
+#ifndef MMI_SAMPLE_STAMP
+#define MMI_SAMPLE_STAMP(i)          // scripts/sample_microbench.hip defines it: device-clock stamps at the kernel's stages
+#endif
 template <int NT, int E, bool CACHE>
 __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    MMI_SAMPLE_STAMP(0)
     const uint16_t* lg = a.logits + (long)b * a.ld;
     const int V = a.V;
     MMI_SHARED float redf[NT / 64];
@@ -2326,6 +2331,11 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int i0 = tid * E;
     constexpr int NV = E / 8;
+    // the step's control words, requested together with the logits: each is a memory round trip of its own where it is first
+    // read otherwise (the RNG words in the middle of the scoring, the forcing words behind the last barrier: ~2 us of an 8 us kernel)
+    const int c_use_noise = *a.use_noise;
+    const unsigned long long c_seed = a.rng[0], c_step = a.rng[1];
+    const int c_forced = *a.use_forced ? a.forced[(long)b * a.forced_stride] : -1;
 
     u32x4 cache[CACHE ? NV : 1];
     if constexpr (CACHE) {
@@ -2340,6 +2350,24 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     {                                                                                              \
         _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) {                                        \
             if (i0 + v_ * 8 >= V) break;                                                           \
+            u32x4 r4_;                                                                             \
+            if constexpr (CACHE) r4_ = cache[v_];                                                  \
+            else r4_ = *reinterpret_cast<const u32x4*>(lg + i0 + v_ * 8);                          \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                     \
+                const int i = i0 + v_ * 8 + e_;                                                    \
+                const uint16_t bits = (uint16_t)((e_ & 1) ? (r4_[e_ >> 1] >> 16) : (r4_[e_ >> 1] & 0xffffu)); \
+                BODY                                                                               \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    // the same, skipping the thread's 8-entry vectors for which SKIP (an expression in v_) holds - the production path keeps the
+    // largest key of each vector (vmax) and most vectors of a large vocabulary lie wholly under the top-k threshold
+#define MMI_S_FOREACH_UNLESS(SKIP, BODY)                                                           \
+    {                                                                                              \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; ++v_) {                                        \
+            if (i0 + v_ * 8 >= V) break;                                                           \
+            if (SKIP) continue;                                                                    \
             u32x4 r4_;                                                                             \
             if constexpr (CACHE) r4_ = cache[v_];                                                  \
             else r4_ = *reinterpret_cast<const u32x4*>(lg + i0 + v_ * 8);                          \
@@ -2388,7 +2416,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     // removes the two softmax passes, the ordered compaction and the rank computation from the critical path of every
     // sampling site; what stays is the radix select of the k-th largest logit.  Supplied noise (the parity taps) keeps the
     // reference's rank-indexed form below.
-    const bool fast = a.k > 0 && *a.use_noise == 0;
+    const bool fast = a.k > 0 && c_use_noise == 0;
     float mx = -INFINITY, sum = 1.f;
     if (!fast) {
     // ---- softmax statistics of logits / temp (fp32)
@@ -2457,14 +2485,22 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     // 2^16 in magnitude under the maximum: never with trained or random-init heads) falls through to the generic select below.
     bool have_t = false;
     int cnt_at_t = -1;                   // entries equal to the threshold key (window select only)
+    unsigned vmax[NV];                   // largest key of each of the thread's vectors (production path)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) vmax[v] = 0xffffu;
     if (fast) {
         unsigned km = 0u;
-        MMI_S_FOREACH({ const unsigned ky = mmi_bf16_key(bits); km = ky > km ? ky : km; })
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const unsigned o = mmi_shfl_xor(km, m); km = o > km ? o : km; }
+        for (int v = 0; v < NV; ++v) vmax[v] = 0u;
+        MMI_S_FOREACH({ const unsigned ky = mmi_bf16_key(bits); vmax[v_] = ky > vmax[v_] ? ky : vmax[v_]; })
+#pragma unroll
+        for (int v = 0; v < NV; ++v) km = vmax[v] > km ? vmax[v] : km;
+        km = mmi_wave_max_u32(km);
         if (lane == 0) redk[wave] = km;
         for (int j = tid; j < 256; j += NT) hist[j] = 0;
+        MMI_SAMPLE_STAMP(1)
         __syncthreads();
+        MMI_SAMPLE_STAMP(2)
         km = redk[0];
         for (int w = 1; w < NT / 64; ++w) km = redk[w] > km ? redk[w] : km;
         const int hi_max = (int)(km >> 8);
@@ -2476,13 +2512,13 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         // 8 x 8-bit counters (<= E <= 32 each) -> 4 words of two 16-bit fields: wave sums <= 64 * 32, block sums <= NT * E <= 32768
         unsigned f[4] = {(unsigned)pc & 0x00ff00ffu, ((unsigned)pc >> 8) & 0x00ff00ffu, (unsigned)(pc >> 32) & 0x00ff00ffu, ((unsigned)(pc >> 32) >> 8) & 0x00ff00ffu};
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) f[q] += mmi_shfl_xor(f[q], m);
+        for (int q = 0; q < 4; ++q) f[q] = mmi_wave_sum_u32(f[q]);
         if (lane == 0)
 #pragma unroll
             for (int q = 0; q < 4; ++q) wcnt[wave][q] = f[q];
+        MMI_SAMPLE_STAMP(3)
         __syncthreads();
+        MMI_SAMPLE_STAMP(4)
         unsigned t4[4] = {0u, 0u, 0u, 0u};
         for (int w = 0; w < NT / 64; ++w)
 #pragma unroll
@@ -2498,11 +2534,13 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         }
         if (dsel >= 0 && hi_max - dsel >= 0) {                     // block-uniform
             const unsigned hi_sel = (unsigned)(hi_max - dsel);
-            MMI_S_FOREACH({
+            MMI_S_FOREACH_UNLESS((vmax[v_] >> 8) < hi_sel, {
                 const unsigned ky = mmi_bf16_key(bits);
                 if ((ky >> 8) == hi_sel) mmi_atomic_add(reinterpret_cast<unsigned*>(&hist[ky & 255u]), 1u);
             })
+            MMI_SAMPLE_STAMP(5)
             __syncthreads();
+            MMI_SAMPLE_STAMP(6)
             // every wave for itself: lane l looks at bins 255 - 4l .. 252 - 4l (descending keys); `above` = entries in higher bins
             int c4[4], s4 = 0;
 #pragma unroll
@@ -2519,10 +2557,9 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
                 if (run < want1 && want1 <= run + c4[j]) { fb = 256 - 4 * lane - j; fw = want1 - run; fc = c4[j]; }   // exactly one (lane, j)
                 run += c4[j];
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {        // the finder's values are the only non-zero ones
-                const int ob = mmi_shfl_xor(fb, m), ow = mmi_shfl_xor(fw, m), oc = mmi_shfl_xor(fc, m);
-                fb = ob > fb ? ob : fb; fw = ow > fw ? ow : fw; fc = oc > fc ? oc : fc;
+            {   // the finder's values are the only non-zero ones: a sum over the wave hands them to every lane
+                const unsigned p0 = mmi_wave_sum_u32((unsigned)fb | ((unsigned)fw << 16)), p1 = mmi_wave_sum_u32((unsigned)fc);
+                fb = (int)(p0 & 0xffffu); fw = (int)(p0 >> 16); fc = (int)p1;
             }
             Tkey = (hi_sel << 8) | (unsigned)(fb - 1);
             want = fw;
@@ -2553,10 +2590,11 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         __syncthreads();
     }
     const int want_eq = want;          // how many entries equal to the threshold belong to the set (lowest indices first)
+    MMI_SAMPLE_STAMP(7)
 
     // ---- ordered compaction of the top-k set (index order)
     int n_gt = 0, n_eq = 0;
-    MMI_S_FOREACH({
+    MMI_S_FOREACH_UNLESS(vmax[v_] < Tkey, {
         const unsigned ky = mmi_bf16_key(bits);
         n_gt += ky > Tkey ? 1 : 0;
         n_eq += ky == Tkey ? 1 : 0;
@@ -2568,6 +2606,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         eq_take = want_eq - eq_base;
         eq_take = eq_take < 0 ? 0 : (eq_take > n_eq ? n_eq : eq_take);
     }
+    MMI_SAMPLE_STAMP(8)
     if (fast) {
         // every member of the set scores logit / temp - log(q), q ~ Exp(1); the largest wins.  One Philox4x32-10 call serves the
         // four entries 4j .. 4j + 3 of the vocabulary (counter (step, site * B + session, j), one output word each) and is skipped
@@ -2576,10 +2615,11 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         int bi = 0x7fffffff;
         int eq_seen_f = 0;
         const float inv_t = 1.0f / a.temp;
-        const unsigned long long seed = a.rng[0], step = a.rng[1];
+        const unsigned long long seed = c_seed, step = c_step;
 #pragma unroll
         for (int v_ = 0; v_ < NV; ++v_) {
             if (i0 + v_ * 8 >= V) break;
+            if (vmax[v_] < Tkey) continue;          // no member of the set in this vector
             u32x4 r4_;
             if constexpr (CACHE) r4_ = cache[v_];
             else r4_ = *reinterpret_cast<const u32x4*>(lg + i0 + v_ * 8);
@@ -2606,7 +2646,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
                     const int e_ = 4 * h + e, i = i0 + v_ * 8 + e_;
                     const uint16_t bits = (uint16_t)((e_ & 1) ? (r4_[e_ >> 1] >> 16) : (r4_[e_ >> 1] & 0xffffu));
                     const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
-                    const float sc_ = mmi_bf16_to_f32(bits) * inv_t - logf(-logf(u));
+                    const float sc_ = mmi_bf16_to_f32(bits) * inv_t - mmi_fast_logf(-mmi_fast_logf(u));
                     if (sc_ > best || (sc_ == best && i < bi)) { best = sc_; bi = i; }
                 }
             }
@@ -2617,14 +2657,21 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
             const int oi = mmi_shfl_xor(bi, m);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
+        MMI_SAMPLE_STAMP(9)
         if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
         __syncthreads();
-        best = redf[0]; bi = redi[0];                   // every thread folds the waves' winners itself: no second barrier
+        MMI_SAMPLE_STAMP(10)
+        // only the threads that write the next micro-step's input row (and thread 0, for the token) go on: a 1024-thread workgroup
+        // would otherwise run this tail sixteen times over on its four SIMDs
+        if (tid != 0 && (!a.nx_out || tid >= (a.nx_dup ? 2 : 1) * (a.nx_D / 8))) return;
+        best = redf[0]; bi = redi[0];                   // every remaining thread folds the waves' winners itself: no second barrier
         for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
-        bi = mmi_apply_forced(a, b, bi);
+        bi = c_forced >= 0 ? c_forced : bi;            // (mmi_apply_forced, on the words requested at the top)
         if (tid == 0) a.out[(long)b * a.out_stride] = bi;
+        MMI_SAMPLE_STAMP(11)
         mmi_sample_next_input(a, b, bi);
+        MMI_SAMPLE_STAMP(12)
         return;
     }
     int pos = mmi_block_excl_scan<NT>(n_gt + eq_take, wsum, &tot);
@@ -2643,6 +2690,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
         }
     })
 #undef MMI_S_FOREACH
+#undef MMI_S_FOREACH_UNLESS
     __syncthreads();
     // ---- rank inside the set (descending logit, then index) and the noisy argmax
     float score = -INFINITY;

@@ -66,6 +66,27 @@ __device__ __forceinline__ float mmi_group_sum(float x) {
     if constexpr (W >= 16) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
     return x;
 }
+// sum / maximum of an unsigned over the whole wave, every lane gets it: four DPP steps inside the rows of 16, two crossbar steps
+// across the rows (a six-step __shfl_xor butterfly is six dependent trips through the LDS crossbar)
+__device__ __forceinline__ unsigned mmi_wave_sum_u32(unsigned x) {
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true);
+    x += mmi_shfl_xor(x, 16);
+    x += mmi_shfl_xor(x, 32);
+    return x;
+}
+__device__ __forceinline__ unsigned mmi_wave_max_u32(unsigned x) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true); x = o > x ? o : x;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true); x = o > x ? o : x;
+    o = mmi_shfl_xor(x, 16); x = o > x ? o : x;
+    o = mmi_shfl_xor(x, 32); x = o > x ? o : x;
+    return x;
+}
 __device__ __forceinline__ float mmi_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // c + a.lo * b.lo + a.hi * b.hi on two packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16): no unpacking of either operand
 typedef __bf16 mmi_bf16x2v __attribute__((ext_vector_type(2)));
@@ -179,6 +200,9 @@ __device__ __forceinline__ u32x4 mmi_load_nt(const u32x4* p) { return __builtin_
 __device__ __forceinline__ f32x4 mmi_load_nt(const f32x4* p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }  // IEEE, matches torch.rsqrt closely
+// natural log on the hardware's v_log_f32 (log2, ~1 ulp) - for the sampler's own noise only (nothing the reference's arithmetic
+// fixes): the library logf is ~25 dependent instructions on a one-wave-per-SIMD kernel that runs at ~9 cycles per instruction
+__device__ __forceinline__ float mmi_fast_logf(float x) { return __logf(x); }
 __device__ __forceinline__ unsigned mmi_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 
 // Cross-stream hand-off flags (duplex.hip): a monotonic counter in device memory, published with release semantics by a

@@ -172,6 +172,8 @@ class LMModel:
         lib = self._lib
         x = x.to(device=self.device, dtype=torch.bfloat16).contiguous()
         rows, K = x.shape
+        # the C entry sizes its operand from the packed weight: rows of another width would be read and written out of bounds
+        assert K == self._linear_in_features(weight_name), f"{weight_name} takes rows of {self._linear_in_features(weight_name)} features, got {K}"
         w = weight_name.encode()
         # out_features from the config-independent side: ask for a generous buffer, the engine writes [rows][N]
         n_out = self._linear_out_features(weight_name)
@@ -189,6 +191,13 @@ class LMModel:
         if norm is not None:
             res["norm"] = norm
         return res
+
+    def _linear_in_features(self, weight_name: str) -> int:
+        c = self.config
+        dep = weight_name.startswith("depformer.") or weight_name.startswith("linears.")
+        if "linear_out" in weight_name:
+            return c.depformer_ffn_hidden if dep else c.ffn_hidden
+        return c.depformer_dim if dep else c.dim          # (depformer_in.* and text_linear read the temporal transformer's output)
 
     def _linear_out_features(self, weight_name: str) -> int:
         c = self.config
@@ -266,8 +275,8 @@ class LMModel:
 
     @property
     def end_of_text_padding_id(self) -> int:
-        # lm.py:260-263: `existing_text_end_padding_id` (constructor default 0; no released config overrides it)
-        return 0
+        # lm.py:260-263: the constructor's `existing_text_end_padding_id` (default 0), carried by LMConfig / loaders
+        return self.config.existing_text_end_padding_id
 
     @property
     def existing_text_padding_id(self) -> int:

@@ -110,6 +110,7 @@ def lm_config_from_kwargs(lm_kwargs: Optional[dict]) -> LMConfig:
         dim=kw["dim"], num_heads=kw["num_heads"], num_layers=kw["num_layers"], hidden_scale=kw.get("hidden_scale", 4.125),
         context=kw["context"], max_period=float(kw.get("max_period", 10000)), n_q=kw["n_q"], dep_q=kw["dep_q"], card=kw["card"],
         text_card=kw["text_card"], existing_text_padding_id=kw.get("existing_text_padding_id", 3),
+        existing_text_end_padding_id=kw.get("existing_text_end_padding_id", 0),
         depformer_dim=kw["depformer_dim"], depformer_dim_feedforward=int(kw["depformer_dim_feedforward"]),
         depformer_num_heads=kw["depformer_num_heads"], depformer_num_layers=kw["depformer_num_layers"],
         delays=list(kw["delays"]), extra_heads_num_heads=kw.get("extra_heads_num_heads", 0),

@@ -351,7 +351,9 @@ int main(int argc, char** argv) {
             a.out_mode = MMI_OUT_PACKED; a.out_ld = sh.N; a.out_ksteps = out_ks;
             a.epi = sh.gate ? MMI_EPI_GATE : (ksplit > 1 ? MMI_EPI_PARTIAL : MMI_EPI_RESID);
             a.partial = partial;
-            const dim3 groups((NT + v.NTW - 1) / v.NTW, sh.gate ? 1 : ksplit);
+            const int osplit = (getenv("MB_OSPLIT") && !sh.gate && v.NTW == 1) ? atoi(getenv("MB_OSPLIT")) : 1;   // row octets of a tile over several workgroups
+            a.osplit = osplit;
+            const dim3 groups((NT + v.NTW - 1) / v.NTW * osplit, sh.gate ? 1 : ksplit);
             const int reps = wbytes > 50e6 ? 3 : 10;
             for (int i = 0; i < nbuf; ++i) { a.wp = (const u32x4*)(w + welems * i); v.fn(groups, s, a); }   // warm-up
             CK(hipStreamSynchronize(s));

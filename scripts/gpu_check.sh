@@ -4,6 +4,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 O=$GRAFT_REPO_ROOT/gpurun_out
+python scripts/isa_scan_packed_swizzle.py moshi_amd/libmoshi_mi.so | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
 # exactly as the driver runs it (-x: the first failure stops the run), plus the slowest tests for the suite's time budget (600 s)
 timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -18 $O/pytest_gpu.log | cut -c1-200

@@ -347,6 +347,9 @@ inline void mmi_store_relaxed_agent(unsigned* p, unsigned v) { __atomic_store_n(
 inline u32x4 mmi_load_nt(const u32x4* p) { return *p; }
 inline f32x4 mmi_load_nt(const f32x4* p) { return *p; }
 inline float mmi_rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float mmi_fast_logf(float x) { return logf(x); }
+inline unsigned mmi_wave_sum_u32(unsigned x) { for (int m = 1; m < 64; m <<= 1) x += mmi_shfl_xor(x, m); return x; }
+inline unsigned mmi_wave_max_u32(unsigned x) { for (int m = 1; m < 64; m <<= 1) { const unsigned o = mmi_shfl_xor(x, m); x = o > x ? o : x; } return x; }
 inline unsigned mmi_atomic_add(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // hand-off flags (duplex.hip).  The simulator runs every launch synchronously in host order, so a wait whose producer has not

@@ -1194,11 +1194,22 @@ def int8_linears_bit_exact(device, lib, cfg, B, seed, report=None, weights_seed=
 INT8_NET_GROSS_MAX, INT8_NET_GROSS_MEAN = 0.35, 0.10
 
 
-def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=None, stats=None):
+def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=None, stats=None, on_device_draw=False):
     from moshi_amd.weights import quantize_lm_state_dict
-    sd = quantize_lm_state_dict(cached_lm_state_dict(cfg, seed))
-    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
-    orc, yard = LMOracle(sd, cfg), LMOracle(sd, cfg, stat64=True)
+    if on_device_draw:
+        # the benchmark model (32 layers, 7.7 B parameters): drawn and quantised on the GPU (seconds instead of minutes on the
+        # host), and the two checkers SHARE one host copy of the int8 weights (the yardstick differs in its statistics only)
+        import copy
+        sd = quantize_lm_state_dict(random_lm_state_dict(cfg, seed=seed, device=device))
+        gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+        orc = LMOracle(sd, cfg)
+        yard = copy.copy(orc)
+        yard.stat64 = True
+    else:
+        sd = quantize_lm_state_dict(cached_lm_state_dict(cfg, seed))
+        gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+        orc, yard = LMOracle(sd, cfg), LMOracle(sd, cfg, stat64=True)
+    del sd
     orc.streaming(B); yard.streaming(B)
     rng = np.random.default_rng(seed)
     eng, yd = [], []
@@ -1263,8 +1274,79 @@ def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=No
     return res
 
 
+# ---- C5 against the PINNED reference ("C5 parity = against the bf16 oracle with a stated quantisation tolerance") ------
+# The int8 rule itself cannot be pinned (bitsandbytes is not in /root/reference and cannot run here), but the distance of the int8
+# ENGINE to the reference's own bf16 logits can be measured: the goldens lm_wide.npz (7B layer shapes, 1 temporal layer) and
+# lm_full.npz (the benchmark model, 32 layers) are outputs of the reference itself.  The int8 network is a different function than
+# the bf16 one (weights and activations rounded to 8 bits row by row), so the gate has two parts: a STATED quantisation tolerance
+# per (row, site) pair - max |d| <= 25 % and mean |d| <= 6 % of max|logit| of the reference, what row-wise int8 costs a random-init
+# network at these widths, read off the int8 ORACLE's own distance to the same goldens - and, the part that binds, the engine no
+# further from the reference than 1.5 x the int8 oracle is, statistic by statistic.
+INT8_VS_BF16_MAX_REL = 0.25
+INT8_VS_BF16_MEAN_REL = 0.06
+
+
+def int8_engine_vs_bf16_reference(device, lib, which="wide", max_batch=None, name=None, sd=None):
+    from dataclasses import replace
+    from moshi_amd.weights import quantize_lm_state_dict
+    g, cfg = load_wide() if which == "wide" else load_full()
+    if sd is None:
+        sd = random_lm_state_dict(cfg, seed=int(g["seed"][0]))          # the generator's (CPU) draw
+    sdq = quantize_lm_state_dict(sd)
+    del sd
+    S, B = g["g_text_tok"].shape
+    gen = make_engine(cfg, sdq, device, lib, max_batch or B, use_sampling=False, support_out_of_sync=True)
+    orc = LMOracle(sdq, replace(cfg, context=min(cfg.context, 64)))      # (no wrap inside the golden's few steps)
+    del sdq
+    orc.streaming(B)
+    eng, ora = [], []
+
+    def rel(a, ref):
+        sc = float(np.abs(ref).max()) + 1e-6
+        dlt = np.abs(a - ref)
+        return float(dlt.max()) / sc, float(dlt.mean()) / sc
+    with gen.streaming(B):
+        for s in range(S):
+            mask = g["masks"][s] if "masks" in g else np.ones(B, bool)
+            gen.set_exec_mask(torch.from_numpy(mask).to(device))
+            orc.set_exec_mask(mask)
+            forced = np.concatenate([g["g_text_tok"][s][:, None], g["g_audio_tok"][s]], 1)
+            out, tl, al = gen.step_with_taps(torch.from_numpy(g["codes"][s]).to(device), forced_tokens=torch.from_numpy(forced).to(device))
+            out, tl, al = out.cpu().numpy(), tl.cpu().numpy(), al.cpu().numpy()
+            oo, (otl, oal, _, _) = orc.step(g["codes"][s], use_sampling=False, support_out_of_sync=True, forced=forced)
+            for b in range(B):
+                if not mask[b]:
+                    assert (out[b] == -2).all()
+                    continue
+                assert np.array_equal(out[b], g["g_tokens"][s, b]), f"step {s} row {b}: ring output differs from the reference's"
+                assert np.array_equal(out[b], oo[b])
+                eng.append(rel(tl[b], g["g_text_logits"][s, b])); ora.append(rel(otl[b], g["g_text_logits"][s, b]))
+                for k in range(cfg.dep_q):
+                    eng.append(rel(al[b, k], g["g_audio_logits"][s, b, k])); ora.append(rel(oal[b, k], g["g_audio_logits"][s, b, k]))
+    e, o = np.array(eng), np.array(ora)
+
+    def summ(v):
+        inside = (v[:, 0] <= INT8_VS_BF16_MAX_REL) & (v[:, 1] <= INT8_VS_BF16_MEAN_REL)
+        return {"pairs": int(len(v)), "inside_quantisation_tolerance": float(inside.mean()),
+                "max_rel_median": float(np.median(v[:, 0])), "max_rel_p90": float(np.quantile(v[:, 0], 0.9)), "max_rel_worst": float(v[:, 0].max()),
+                "mean_rel_median": float(np.median(v[:, 1])), "mean_rel_p90": float(np.quantile(v[:, 1], 0.9)), "mean_rel_worst": float(v[:, 1].max())}
+    es, os_ = summ(e), summ(o)
+    case = name or f"c5_int8_vs_reference_{which}"
+    res = {"case": case, "golden": f"lm_{which}.npz (the reference's bf16 logits)", "tolerance": [INT8_VS_BF16_MAX_REL, INT8_VS_BF16_MEAN_REL],
+           "int8_engine_vs_bf16_reference": es, "int8_oracle_vs_bf16_reference": os_}
+    print(f"[parity] {case}: engine {es}\n[parity] {case}: int8 oracle {os_}")
+    out_dir = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if out_dir.is_dir():
+        import json
+        (out_dir / f"parity_{case}.json").write_text(json.dumps(res, indent=1))
+    assert es["inside_quantisation_tolerance"] >= min(0.9, os_["inside_quantisation_tolerance"] - 0.05), f"{case}: too few pairs inside the quantisation tolerance: {es} vs the int8 oracle {os_}"
+    for key, slack in (("max_rel_median", 0.005), ("max_rel_p90", 0.01), ("mean_rel_median", 0.002), ("mean_rel_p90", 0.004)):
+        assert es[key] <= 1.5 * os_[key] + slack, f"{case} {key}: engine {es[key]:.4f} vs the int8 oracle's {os_[key]:.4f} from the same reference"
+    return res
+
+
 # ---- the step is a function of its inputs: two streams of one handle fed the same frames produce the same bits ----------------------
-def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, repeats=4, seed=77, before_repeat=None):
+def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, repeats=4, seed=77, before_repeat=None, guided_cross=None):
     """Round 5's root cause (the driver's round-4 failure) was a launch whose output changed from run to run; what caught it was
     comparing runs, not comparing with the checker.  Greedy, masks and a partial reset, hidden taps on: every repeat must equal the
     first in tokens, text / audio logits and the residual stream after the first and the last temporal layer, bit for bit."""
@@ -1275,7 +1357,16 @@ def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, r
     elif quantize:
         from moshi_amd.weights import quantize_lm_state_dict
         sd = quantize_lm_state_dict(sd)
-    gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
+    if guided_cross:            # (T_c, coef): a cross-attention model under classifier-free guidance - two model rows per session, the
+        from moshi_amd.lm import ConditionFuser     # norm_cross / query GEMM / cross-attention / out_proj launches, k_cfg_mix at every site
+        Tc, coef = guided_cross
+        g = torch.Generator().manual_seed(seed)
+        cx = (0.7 * torch.randn(2 * B, Tc, cfg.dim, generator=g)).to(torch.bfloat16)
+        lm = LMModel(sd, cfg, device=device, max_batch=2 * B, lib=lib, fuser=ConditionFuser({"sum": [], "cross": ["x"]}))
+        gen = LMGen(lm, use_sampling=False, support_out_of_sync=True, cfg_coef=coef,
+                    condition_tensors={"x": (cx, torch.ones(2 * B, Tc, dtype=torch.bool))})      # conditioned rows first, then the null twins
+    else:
+        gen = make_engine(cfg, sd, device, lib, B, use_sampling=False, support_out_of_sync=True)
     gen.lm_model.enable_hidden_taps()
     rng = np.random.default_rng(seed)
     plan = []
@@ -1306,6 +1397,7 @@ def reproducible_between_streams(device, lib, cfg, B, quantize=False, steps=3, r
             m = torch.from_numpy(plan[s][0])
             for name, x, y in zip(("tokens", "text logits", "audio logits"), a[:3], b[:3]):
                 assert torch.equal(x[m], y[m]), f"repeat {r} step {s}: {name} differ between two streams fed the same frames"
+            mt = torch.cat([m, m]) if guided_cross else m          # guidance: the twins' rows follow the sessions'
             for w in (0, 1):
-                rows = torch.nonzero((a[3][w][m] != b[3][w][m]).any(1)).flatten().tolist()
+                rows = torch.nonzero((a[3][w][mt] != b[3][w][mt]).any(1)).flatten().tolist()
                 assert not rows, f"repeat {r} step {s}: the residual stream after temporal layer {'0' if w == 0 else 'last'} differs in executing rows {rows[:8]}"

@@ -118,6 +118,31 @@ def test_batch_rows_are_independent_and_graph_equals_eager(factory, monkeypatch)
     assert torch.equal(c2, codes) and torch.equal(p2, pcm)
 
 
+@pytest.mark.parametrize("B", [8, 32])
+def test_codec_is_bit_reproducible_between_streams(factory, B):
+    """The full-size codec at the C2 batch (8 streams) and the benchmark batch (32): three frames encoded and decoded, then four
+    more streams on the SAME handle fed the same PCM - codes and PCM bit for bit equal to the first stream's (a launch that is not
+    a function of its inputs - round 4's LM failure - is the one bug class a tolerance against the checker cannot see)."""
+    cfg = MimiConfig()
+    sd = random_mimi_state_dict(cfg, seed=1234)
+    g = torch.Generator().manual_seed(19 + B)
+    x = (0.25 * torch.randn(B, 1, cfg.frame_size * 3, generator=g)).to(DEV)
+    m = factory(sd, cfg, 8, max_batch=B)
+
+    def run():
+        out = []
+        with m.streaming(B):
+            for f in range(3):
+                codes = m.encode(x[:, :, f * cfg.frame_size:(f + 1) * cfg.frame_size])
+                out.append((codes.clone(), m.decode(codes).clone()))
+        return out
+    first = run()
+    for r in range(4):
+        for f, ((c0, p0), (c1, p1)) in enumerate(zip(first, run())):
+            assert torch.equal(c0, c1), f"repeat {r} frame {f}: codes differ between two streams fed the same PCM"
+            assert torch.equal(p0, p1), f"repeat {r} frame {f}: PCM differs between two streams fed the same PCM"
+
+
 def test_round_trip_sine_c1(factory):
     """BASELINE.json configs[0] restated: 1 s 440 Hz sine, streaming == non-streaming codes, PCM shape."""
     cfg = MimiConfig()

@@ -155,7 +155,15 @@ def test_benchmark_kernels_match_the_reference_at_full_depth(gpu_lib):
     """The same golden run on a handle built for 32 sessions: the 32-row tile, k_gemm_xlds, the split-K temporal GEMMs - the
     kernels `bench.py` times - against the reference's own logits (a 2-session handle takes the 16-row tile)."""
     lm_cases.check_golden_full(DEV, None, max_batch=32, name="golden_full_cuda_tile32")
-    lm_cases.release_full_golden_state_dict()       # the three tests above shared one host draw of the 7.7 B parameters
+
+
+def test_c5_int8_engine_against_the_reference_at_full_depth(gpu_lib):
+    """C5 anchored to the PINNED reference at the benchmark's depth: the int8 x int8 engine (the golden's weights quantised row-wise)
+    against the reference's own bf16 logits of its 32-layer run (tests/golden/lm_full.npz), within the stated quantisation tolerance
+    and no further from them than 1.5 x the int8 oracle is - on a handle built for 64 sessions (two batch tiles, the C5 kernels).
+    Here rather than in test_y_c5_int8_gpu.py because the benchmark model's 7.7 B parameters are drawn once for this file."""
+    lm_cases.int8_engine_vs_bf16_reference(DEV, None, "full", max_batch=64, sd=lm_cases.full_golden_state_dict(DEV))
+    lm_cases.release_full_golden_state_dict()       # the four tests above shared one host draw of the 7.7 B parameters
 
 
 @pytest.mark.parametrize("B", [40, 64])
@@ -290,3 +298,18 @@ def test_attention_program_switch_is_a_graph_launch_not_a_capture(gpu_lib, monke
 def test_benchmark_batch_step_is_bit_reproducible_between_streams(gpu_lib):
     """32 sessions, bf16, 7B layer widths (the benchmark's kernels): repeated streams on one handle equal the first bit for bit."""
     lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=32, quantize=False, seed=15, repeats=3)
+
+
+@pytest.mark.parametrize("B", [3, 12])
+def test_16_row_tile_step_is_bit_reproducible_between_streams(gpu_lib, B):
+    """<= 16 sessions (the 16-row MFMA tile: C3's kernels - k_gemm_xp<16, ..>, k_gemm_xp_norm<16, ..>, k_gemm_xp_once<16, ..>, the
+    ring split over workgroups at 3 sessions), 7B layer widths: repeated streams on one handle equal the first bit for bit."""
+    lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=B, quantize=False, seed=21 + B, repeats=3)
+
+
+def test_guided_cross_attention_step_is_bit_reproducible_between_streams(gpu_lib):
+    """A cross-attention model under classifier-free guidance at the 7B layer widths (9 sessions = 18 model rows: the 32-row tile,
+    norm_cross / query GEMM / k_lm_cross_attn / out_proj, k_cfg_mix at all nine sampling sites): repeated streams are bit-identical."""
+    from dataclasses import replace
+    cfg = replace(LMConfig(num_layers=2, context=64), cross_attention=True)
+    lm_cases.reproducible_between_streams(DEV, None, cfg, B=9, quantize=False, seed=33, repeats=3, guided_cross=(7, 2.0))

@@ -72,10 +72,24 @@ def test_perturbed_schedules_expose_a_missing_barrier(sim_lib, tmp_path):
     (18, False, {"MMI_GEMM_LDS": "2", "MMI_GEMM_KSPLIT": "2"}),        # 32-row tile, LDS-resident GEMM with split-K (the benchmark's form)
     (34, True, {}),                                                    # two batch tiles, int8 x int8: k_gemm_xp<32, 2> + k_gemm_q8 per tile
     (5, "fp8", {"MMI_ATTN_NS": "3"}),                                  # fp8 MFMA; the ring split over workgroups + merge
+    (18, False, {"MMI_GEMM_ONCE": "a", "MMI_GEMM_LDS": "0"}),          # round 6: k_gemm_xp_once on every GEMM whose slices fit
+    (9, "guided-cross", {}),                                           # guidance twins + cross-attention block + k_cfg_mix
 ])
 def test_lm_step_is_independent_of_the_wave_schedule(sim_lib, monkeypatch, B, quantize, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    if quantize == "guided-cross":
+        from dataclasses import replace
+
+        def perturb_gc(r):
+            mode, seed = SCHEDULES[r]
+            sim_lib.cdll.hipsim_set_schedule(mode, seed)
+        try:
+            lm_cases.reproducible_between_streams("cpu", sim_lib, replace(tiny_lm_config(), cross_attention=True), B=B, steps=2,
+                                                  repeats=len(SCHEDULES), seed=31 + B, before_repeat=perturb_gc, guided_cross=(5, 2.0))
+        finally:
+            sim_lib.cdll.hipsim_set_schedule(FORWARD, 1)
+        return
 
     def perturb(r):
         mode, seed = SCHEDULES[r]

@@ -79,3 +79,22 @@ def test_pmc_summary_clusters_a_kernels_dispatches_by_shape(tmp_path):
     assert abs(float(big.split(",")[-2]) - 93160.0 * 1024 * 2) < 4096          # bytes_corrected = KiB x 1024 x 2
     r = subprocess.run([sys.executable, script, str(db), "--clusters", "k_gemm_xlds", "--by-duration"], capture_output=True, text=True)
     assert r.returncode == 0 and sum(l.startswith('"k_gemm_xlds') for l in r.stdout.splitlines()) == 2
+
+
+def test_built_library_has_no_in_place_cross_swizzled_packed_fp32_instruction():
+    """The instruction form that stood in k_gemm_xp's RoPE epilogue when its output was not reproducible (round 4's driver failure;
+    HISTORY.md round 5 10a: `v_pk_mul_f32 v[14:15], v[30:31], v[14:15] op_sel:[0,1] op_sel_hi:[1,0]`) must not come back through a
+    compiler update or a new epilogue: the gfx950 code objects of the library `build()` produced are disassembled and scanned
+    (scripts/isa_scan_packed_swizzle.py; the sequence alone is exact on the chip - scripts/pk_hazard_repro.hip, 6.6e8 wave executions -
+    so this is a tripwire around a context-dependent failure that was never explained, not a proven erratum)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "moshi_amd" / "libmoshi_mi.so"
+    if not lib.exists():
+        import pytest
+        pytest.skip("the HIP library is not built")
+    r = subprocess.run([sys.executable, str(root / "scripts" / "isa_scan_packed_swizzle.py"), str(lib)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("0 kernel(s)"), r.stdout[-2000:]

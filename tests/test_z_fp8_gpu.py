@@ -56,3 +56,10 @@ def test_fp8_full_width_within_the_conditioning_of_the_fp8_network(gpu_lib):
 def test_c5_shape_fp8_linears_at_64_sessions_within_the_conditioning_of_the_fp8_network(gpu_lib):
     """BASELINE configs[4]'s own shape: 64 sessions, 7B layer widths (2 temporal layers), e4m3 linears on the fp8 MFMA."""
     print(lm_cases.fp8_engine_within_format_conditioning(DEV, None, LMConfig(num_layers=2, context=64), seed=464, B=64, S=2))
+
+
+@pytest.mark.parametrize("B", [18, 40])
+def test_fp8_step_is_bit_reproducible_between_streams(gpu_lib, B):
+    """fp8 linears on the fp8 MFMA (one and two batch tiles), 7B layer widths: the hardware's dot-product unit is not an exact fp32
+    accumulation, but it is a FUNCTION of its inputs - repeated streams on one handle equal the first bit for bit."""
+    lm_cases.reproducible_between_streams(DEV, None, LMConfig(num_layers=2, context=64), B=B, quantize="fp8", seed=41 + B, repeats=3)
