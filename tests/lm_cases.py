@@ -1268,8 +1268,13 @@ def int8_network_vs_oracle(device, lib, cfg, seed, B, S, use_masks=True, name=No
         import json
         (out_dir / f"parity_{name}.json").write_text(json.dumps(res, indent=1))
     assert es["inside_bf16_tolerance"] >= min(0.85, ys["inside_bf16_tolerance"] - 0.10), f"too few (row, site) pairs inside the bf16 tolerance: {es} vs yardstick {ys}"
-    for key, slack in (("max_rel_median", 0.005), ("max_rel_p90", 0.01), ("mean_rel_median", 0.002), ("mean_rel_p90", 0.004)):
-        assert es[key] <= 1.5 * ys[key] + slack, f"{key}: engine {es[key]:.4f} vs yardstick {ys[key]:.4f}"
+    # quantile against quantile, the yardstick's taken 5 points higher: at full depth ~90 % of the pairs are BIT-IDENTICAL to the oracle
+    # on both sides (engine 87.5 %, yardstick 91.6 % at 32 layers / 64 sessions), so a percentile can be exactly 0 for one and the
+    # first non-identical pair for the other - the comparison must tolerate a few points of difference in where the identical block ends
+    for col, what, q, slack in ((0, "max_rel", 0.5, 0.005), (0, "max_rel", 0.9, 0.01), (0, "max_rel", 0.99, 0.02), (1, "mean_rel", 0.5, 0.002), (1, "mean_rel", 0.9, 0.004)):
+        eq, yq = float(np.quantile(e[:, col], q)), float(np.quantile(y[:, col], min(q + 0.05, 1.0)))
+        assert eq <= 1.5 * yq + slack, f"{what} quantile {q}: engine {eq:.4f} vs yardstick's quantile {min(q + 0.05, 1.0):.2f} {yq:.4f}"
+    assert es["identical"] >= ys["identical"] - 0.10, f"share of pairs bit-identical to the oracle: engine {es['identical']:.3f} vs yardstick {ys['identical']:.3f}"
     assert es["max_rel_worst"] <= INT8_NET_GROSS_MAX and es["mean_rel_worst"] <= INT8_NET_GROSS_MEAN, f"a (row, site) pair is grossly wrong: {es}"
     return res
 
