@@ -1777,6 +1777,21 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(a.vc) + (long)bh * a.cap * DH * ES;
     const unsigned loff = (unsigned)(seg * EPL * ES);
     const float scale = 1.0f / sqrtf((float)DH);
+    // One workgroup per (session, head) (gridDim.y == 1: which wave walks which row group does not depend on the ring depth): the
+    // FIRST round's keys and values are requested before the session's offset - a cold scalar load of its own, ~1 us into a
+    // ~40 us launch - has come back: row groups wave, wave + 4, ... of the ring's first slots, any of which lies inside the
+    // allocation; rows past the valid part are masked where they are used (slot < L), as the clamped re-reads always were
+    u32x4 kA[NB], vA[NB], kB[NB], vB[NB];
+    const bool early = gridDim.y == 1;
+    if (early) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int slot_ = min((wave + i * 4) * RPW + rsub, a.cap - 1);
+            const unsigned o_ = (unsigned)slot_ * (unsigned)(DH * ES) + loff;
+            kA[i] = *reinterpret_cast<const u32x4*>(kbase + o_);
+            vA[i] = *reinterpret_cast<const u32x4*>(vbase + o_);
+        }
+    }
     // context >= capacity (the LM's ring: both 3000): every written slot is inside the window - slot s < L holds a position p with
     // 0 <= offset - p < cap - so the mask (transformer.py:574-582) reduces to `slot < L` and the per-row position arithmetic is
     // skipped (wave-uniform branch); a ring longer than its attention window keeps it
@@ -1794,7 +1809,6 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
     float m_run = -INFINITY, l_run = 0.f, acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    u32x4 kA[NB], vA[NB], kB[NB], vB[NB];
     // every load is unconditional from a clamped (valid) slot - a load under a branch would be serialised behind
     // s_waitcnt vmcnt(0) - and rows past the end carry probability 0
 #define MMI_AW_LOAD(KK, VV, j0)                                                                  \
@@ -1856,7 +1870,7 @@ __global__ __launch_bounds__(256, KV8 ? 2 : 4) void k_lm_attn_wave(LmAttnArgs a)
         }                                                                                        \
     }
     if (nrounds > 0) {
-        MMI_AW_LOAD(kA, vA, 0)
+        if (!early) { MMI_AW_LOAD(kA, vA, 0) }
         for (int r = 0; r < nrounds; r += 2) {
             MMI_AW_LOAD(kB, vB, (r + 1) * NB)          // clamped past the end: re-reads the last row (cache hit), masked on use
             MMI_AW_USE(kA, vA, r * NB)
