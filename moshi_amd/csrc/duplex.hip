@@ -190,9 +190,14 @@ int create_impl(mmi_duplex* d) {
         MMI_HIP_CHECK(hipExtStreamCreateWithCUMask(&d->sD, 8, mask));
     } else
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, lo));
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, hi));
-        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, hi));
+        // MMI_DUPLEX_PRIO = lm / none (experiment): the LM's stream in the high-priority pool and the codec's in the low one / all three
+        // at the default priority, instead of codec high, LM low
+        const char* pe = getenv("MMI_DUPLEX_PRIO");
+        const int mid = (lo + hi) / 2;
+        const int pl = pe && pe[0] == 'l' ? hi : (pe && pe[0] == 'n' ? mid : lo), pc = pe && pe[0] == 'l' ? lo : (pe && pe[0] == 'n' ? mid : hi);
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, pl));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, pc));
+        MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, pc));
     } else {
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sL, hipStreamNonBlocking));
         MMI_HIP_CHECK(hipStreamCreateWithFlags(&d->sE, hipStreamNonBlocking));
