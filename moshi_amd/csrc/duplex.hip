@@ -171,8 +171,8 @@ int create_impl(mmi_duplex* d) {
     if (mc.q_bins != lc.card) return mmi_fail(MMI_ERR_SHAPE, "codec cardinality != LM card");
     // Stream priorities.  Streams of one priority share a pool of GPU_MAX_HW_QUEUES (4) hardware queues with everything else the
     // process created at that priority, and two streams that land on one queue do not overlap (profiles/r03_logs: the encoder
-    // and the LM shared queue 4 without priorities).  The codec streams get the high-priority pool: distinct queues, and their
-    // short latency-bound launches win arbitration against the bulk LM stream.
+    // and the LM shared queue 4 without priorities).  The LM and the codec are therefore given DIFFERENT priorities (distinct queue
+    // pools); which of the two is the high one matters little (below).
     MMI_HIP_CHECK(hipMalloc((void**)&d->flags, (size_t)F_COUNT * 16 * sizeof(long)));
     MMI_HIP_CHECK(hipMemset(d->flags, 0, (size_t)F_COUNT * 16 * sizeof(long)));
     int lo = 0, hi = 0;
@@ -190,11 +190,13 @@ int create_impl(mmi_duplex* d) {
         MMI_HIP_CHECK(hipExtStreamCreateWithCUMask(&d->sD, 8, mask));
     } else
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
-        // MMI_DUPLEX_PRIO = lm / none (experiment): the LM's stream in the high-priority pool and the codec's in the low one / all three
-        // at the default priority, instead of codec high, LM low
+        // The LM's stream in the high-priority pool, the codec's two in the low one: the step's critical path is the LM's launch
+        // chain, the codec only has to be done by the time the next step wants its codes.  Same-box pairs (round 6,
+        // profiles/r06_logs/ab_stream_priorities.txt): -0.02 ms per 32-session step on average against the reverse (rounds 3-5),
+        // -0.06 ms at 64 sessions; equal priorities: +0.5 ms.  MMI_DUPLEX_PRIO = codec / none select those for an A/B.
         const char* pe = getenv("MMI_DUPLEX_PRIO");
         const int mid = (lo + hi) / 2;
-        const int pl = pe && pe[0] == 'l' ? hi : (pe && pe[0] == 'n' ? mid : lo), pc = pe && pe[0] == 'l' ? lo : (pe && pe[0] == 'n' ? mid : hi);
+        const int pl = pe && pe[0] == 'c' ? lo : (pe && pe[0] == 'n' ? mid : hi), pc = pe && pe[0] == 'c' ? hi : (pe && pe[0] == 'n' ? mid : lo);
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sL, hipStreamNonBlocking, pl));
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sE, hipStreamNonBlocking, pc));
         MMI_HIP_CHECK(hipStreamCreateWithPriority(&d->sD, hipStreamNonBlocking, pc));
