@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--kv-seek", type=int, default=-1,
                     help="debug / tuning: move every session to this ring depth instead (overrides --kv-depth; not a named configuration)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the extra figures of the default line: `full_context` (every session 3000 positions deep), `c3` (one session) and `c5` (64 sessions, int8 x int8)")
+                    help="skip the extra figures of the default line: `full_context` (every session 3000 positions deep), `c3` (one session), `c5` (64 sessions, int8 x int8) and `c2` (the codec alone, 8 streams)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank's host thread to its own block of cores")
     return ap.parse_args()
 
@@ -550,8 +550,9 @@ def main():
                                          "note": "same pipelined step with the rings as shallow as rounds 1-3 measured them (depth 8 b); BENCH_r03: 6.19 ms"}
             out["full_context"] = extra_full_context(lm_gen, user_codes, B, dev)
             out["c3"] = extra_c3(dev, args)
-            from bench_lm import extra_c5
+            from bench_lm import extra_c5, extra_c2
             out["c5"] = extra_c5(args)
+            out["c2"] = extra_c2(args)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would sit in the barrier)
             unpin_host_thread()
             cpu_sd = {k: v.cpu() for k, v in msd.items()}

@@ -247,6 +247,23 @@ def extra_c5(args):
     return out
 
 
+def extra_c2(args):
+    """`c2` of the default line (BASELINE configs[1]: Mimi streaming encode + RVQ + decode, 8 streams, one GPU): a child process running
+    this very benchmark with `--workload mimi --batch 8` (fp32 codec, the reference's own width - what keeps the codes bit-exact)."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, str(Path(__file__).resolve().parent / "bench.py"), "--no-cpu-baseline", "--no-extras", "--workload", "mimi", "--batch", "8",
+           "--steps", str(max(args.steps, 60)), "--warmup", str(max(args.warmup, 12))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+        d = json.loads(line)
+        return {"workload": "Mimi streaming encode + RVQ + decode, 8 streams, fp32 (BASELINE configs[1])", "ms_per_step": d["ms_per_step"],
+                "p50_ms_per_step": d.get("p50_ms_per_step"), "frames_per_s": d["value"], "steps": d.get("steps")}
+    except Exception as e:      # noqa: BLE001 - an extra, never worth the line
+        return {"error": repr(e)[:300]}
+
+
 def _mem_available_gib():
     try:
         for line in open("/proc/meminfo"):
