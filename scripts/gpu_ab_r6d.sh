@@ -1,3 +1,4 @@
+# (needs scripts/experiments/mimi_tr_grouped.patch applied: MMI_MIMI_TR is read by the patched engine only)
 # round 6, second session: the grouped Mimi transformer (mimi_tr_kernels.h) - parity first, then same-box A/B of the three forms
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

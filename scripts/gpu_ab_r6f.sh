@@ -1,3 +1,4 @@
+# (needs scripts/experiments/rvq_grouped.patch or rvq_select_last_arriver.patch applied: MMI_RVQ is read by the patched engine only)
 # round 6: the residual quantiser as one launch (the select step in the last-arriving workgroup) - parity, then same-box A/B against the level-by-level launch list
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -1,3 +1,4 @@
+# (needs scripts/experiments/mimi_tr_grouped.patch applied: MMI_MIMI_TR is read by the patched engine only)
 # per-phase kernel time of the grouped Mimi transformer in its one-launch-per-phase form (MMI_MIMI_TR=phases): the kernel trace's
 # k_mimi_tr dispatches, averaged by position inside a transformer (41 phases: gather, then 8 x [in_proj, attention, out_proj, linear1, linear2])
 cd /tmp && export TMPDIR=/tmp
